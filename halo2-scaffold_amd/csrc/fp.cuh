@@ -1,0 +1,240 @@
+// BN254 prime-field arithmetic for gfx950 (CDNA4), 8 x 32-bit limbs, Montgomery form R = 2^256.
+//
+// Replaces (on the device) halo2curves::bn256::{Fq, Fr} — reference call site src/scaffold.rs:14
+// (`halo2curves::bn256::{Bn256, Fr, G1Affine}`), SURVEY.md 8a row a6.  The in-memory layout is the
+// crate's: [u64; 4] little-endian limbs, Montgomery form, always fully reduced (< modulus); on a
+// little-endian machine that is bit-identical to the [u32; 8] used here.
+//
+// gfx950 has 32-bit integer multipliers only: the inner product is v_mad_u64_u32 (32x32+64 -> 64).
+// No MFMA: this is carry-chain integer work, not a dense contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace h2 {
+
+struct alignas(16) fe {
+  uint32_t v[8];
+};
+
+// ---- moduli -------------------------------------------------------------------------------------
+struct FqP {  // base field q
+  static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                      0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod q
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};  // R^2 mod q
+  static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
+};
+struct FrP {  // scalar field r
+  static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                      0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+  static constexpr uint32_t INV = 0xefffffffu;
+};
+
+// ---- helpers ------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ fe fe_const(const uint32_t (&c)[8]) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c[i];
+  return r;
+}
+template <class F>
+__device__ __forceinline__ fe fe_one() {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = F::ONE[i];
+  return r;
+}
+__device__ __forceinline__ fe fe_zero() {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r;
+}
+__device__ __forceinline__ bool fe_is_zero(const fe& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+__device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+__device__ __forceinline__ fe fe_load(const void* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 lo = q[0], hi = q[1];
+  fe r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+__device__ __forceinline__ void fe_store(void* p, const fe& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+__device__ __forceinline__ fe fe_select(bool c, const fe& a, const fe& b) {  // c ? a : b
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+// raw 256-bit add / sub with carry / borrow out
+__device__ __forceinline__ fe raw_add(const fe& a, const fe& b, uint32_t& carry) {
+  fe r;
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  carry = c;
+  return r;
+}
+__device__ __forceinline__ fe raw_sub(const fe& a, const fe& b, uint32_t& borrow) {
+  fe r;
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(a.v[i], b.v[i], c, &c);
+  borrow = c;
+  return r;
+}
+template <class F>
+__device__ __forceinline__ fe raw_sub_mod(const fe& a, uint32_t& borrow) {  // a - MOD
+  fe r;
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(a.v[i], F::MOD[i], c, &c);
+  borrow = c;
+  return r;
+}
+// a in [0, 2*MOD) -> [0, MOD)
+template <class F>
+__device__ __forceinline__ fe fe_reduce_once(const fe& a) {
+  uint32_t bo;
+  fe d = raw_sub_mod<F>(a, bo);
+  return fe_select(bo != 0, a, d);
+}
+
+template <class F>
+__device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {
+  uint32_t c;
+  fe s = raw_add(a, b, c);  // a + b < 2^255: no carry out of 256 bits
+  return fe_reduce_once<F>(s);
+}
+template <class F>
+__device__ __forceinline__ fe fe_dbl(const fe& a) {
+  fe s;
+#pragma unroll
+  for (int i = 7; i > 0; i--) s.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 31);
+  s.v[0] = a.v[0] << 1;
+  return fe_reduce_once<F>(s);
+}
+template <class F>
+__device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {
+  uint32_t bo;
+  fe d = raw_sub(a, b, bo);
+  // add MOD back when the subtraction borrowed
+  fe r;
+  unsigned c = 0;
+  const uint32_t mask = bo ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_addc(d.v[i], F::MOD[i] & mask, c, &c);
+  return r;
+}
+template <class F>
+__device__ __forceinline__ fe fe_neg(const fe& a) {
+  fe m = fe_const<F>(F::MOD);
+  uint32_t bo;
+  fe d = raw_sub(m, a, bo);
+  return fe_select(fe_is_zero(a), a, d);
+}
+
+// ---- Montgomery multiplication ------------------------------------------------------------------
+// Product-scanning (column-wise) Montgomery: column k sums a[j]*b[k-j] and m[j]*MOD[k-j] into a
+// 64-bit accumulator (v_mad_u64_u32 with the running sum as its 64-bit addend) plus a carry word.
+// MOD < 2^254, so the result of the loop is < 2*MOD and one conditional subtract finishes.
+__device__ __forceinline__ void mac(uint64_t& acc, uint32_t& ov, uint32_t a, uint32_t b) {
+  // acc += a*b ; ov += carry-out
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(ov)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+__device__ __forceinline__ void mac_nc(uint64_t& acc, uint32_t a, uint32_t b) {  // no carry possible
+  acc = (uint64_t)a * b + acc;
+}
+
+template <class F>
+__device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) {
+  uint32_t m[8];
+  uint32_t t[8];
+  uint64_t acc = 0;
+  uint32_t ov = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int j = 0; j <= k; j++) mac(acc, ov, a.v[j], b.v[k - j]);
+#pragma unroll
+    for (int j = 0; j < k; j++) mac(acc, ov, m[j], F::MOD[k - j]);
+    m[k] = (uint32_t)acc * F::INV;
+    mac(acc, ov, m[k], F::MOD[0]);  // low word becomes 0
+    acc = (acc >> 32) | ((uint64_t)ov << 32);
+    ov = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; k++) {
+#pragma unroll
+    for (int j = k - 7; j < 8; j++) mac(acc, ov, a.v[j], b.v[k - j]);
+#pragma unroll
+    for (int j = k - 7; j < 8; j++) mac(acc, ov, m[j], F::MOD[k - j]);
+    t[k - 8] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)ov << 32);
+    ov = 0;
+  }
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return fe_reduce_once<F>(r);
+}
+
+template <class F>
+__device__ __forceinline__ fe fe_sqr(const fe& a) {
+  return fe_mul<F>(a, a);
+}
+
+template <class F>
+__device__ __forceinline__ fe fe_from_mont(const fe& a) {  // a * R^-1 : Montgomery -> canonical
+  fe one = fe_zero();
+  one.v[0] = 1;
+  return fe_mul<F>(a, one);
+}
+template <class F>
+__device__ __forceinline__ fe fe_to_mont(const fe& a) {  // canonical -> Montgomery
+  return fe_mul<F>(a, fe_const<F>(F::R2));
+}
+
+// a^(MOD-2) by square-and-multiply over the fixed exponent (Fermat inversion); inv(0) = 0.
+template <class F>
+__device__ __noinline__ fe fe_inv(const fe& a) {
+  fe r = fe_one<F>();
+  // exponent = MOD - 2 (MOD is odd and its low word is > 2, so only limb 0 changes)
+  for (int i = 7; i >= 0; i--) {
+    uint32_t e = F::MOD[i] - (i == 0 ? 2u : 0u);
+    for (int b = 31; b >= 0; b--) {
+      r = fe_sqr<F>(r);
+      if ((e >> b) & 1u) r = fe_mul<F>(r, a);
+    }
+  }
+  return r;
+}
+
+}  // namespace h2

@@ -1,0 +1,346 @@
+// libh2mi.so — lifecycle, device memory, profiling, elementwise test hooks and the small G1 helpers.
+#include "g1.cuh"
+#include "h2mi_internal.h"
+
+namespace h2 {
+
+Ctx& ctx() {
+  static Ctx c;
+  return c;
+}
+
+void note_hip_error(hipError_t e, const char* file, int line) {
+  snprintf(ctx().last_err, sizeof(ctx().last_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+  if (getenv("H2MI_VERBOSE")) fprintf(stderr, "[h2mi] %s\n", ctx().last_err);
+}
+
+void prof_begin(const char* name, hipStream_t s) {
+  ProfRec r;
+  r.name = name;
+  hipEventCreate(&r.a);
+  hipEventCreate(&r.b);
+  hipEventRecord(r.a, s);
+  ctx().prof.push_back(r);
+}
+void prof_end(hipStream_t s) { hipEventRecord(ctx().prof.back().b, s); }
+
+// ---- elementwise field kernels (test hooks) -------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_dbg_field(int op, const fe* a, const fe* b, fe* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_load(&a[i]);
+  fe y = b ? fe_load(&b[i]) : fe_zero();
+  fe r;
+  switch (op) {
+    case 0: r = fe_mul<F>(x, y); break;
+    case 1: r = fe_add<F>(x, y); break;
+    case 2: r = fe_sub<F>(x, y); break;
+    case 3: r = fe_sqr<F>(x); break;
+    case 4: r = fe_inv<F>(x); break;
+    case 5: r = fe_from_mont<F>(x); break;
+    case 6: r = fe_to_mont<F>(x); break;
+    case 7: r = fe_neg<F>(x); break;
+    default: r = fe_dbl<F>(x); break;
+  }
+  fe_store(&out[i], r);
+}
+
+__global__ void __launch_bounds__(256) k_dbg_g1(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine P = affine_load(p + i * 64);
+  xyzz acc;
+  if (op == 0) {
+    affine Q = affine_load(q + i * 64);
+    acc = xyzz_from_affine(P);
+    xyzz_madd(acc, Q);
+  } else if (op == 1) {
+    acc = xyzz_from_affine(P);
+    acc = xyzz_dbl(acc);
+  } else {
+    affine Q = affine_load(q + i * 64);
+    acc = xyzz_from_affine(P);
+    // make the second operand a non-trivial XYZZ representative: (2Q) - Q computed as 2Q + (-Q)
+    xyzz b = xyzz_dbl(xyzz_from_affine(Q));
+    affine nq = Q;
+    nq.y = fe_neg<Fq>(Q.y);
+    xyzz_madd(b, nq);
+    xyzz_add(acc, b);
+  }
+  jac_store(out + i * 96, xyzz_to_jac(acc));
+}
+
+// sum of k Jacobian points by one thread (k is tiny: the number of GPUs)
+__global__ void k_g1_sum_jac(const uint8_t* pts, size_t k, uint8_t* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz acc = xyzz_identity();
+  for (size_t i = 0; i < k; i++) {
+    xyzz p = jac_to_xyzz(jac_load(pts + i * 96));
+    xyzz_add(acc, p);
+  }
+  jac_store(out, xyzz_to_jac(acc));
+}
+
+__global__ void __launch_bounds__(256) k_g1_normalize(const uint8_t* pts, size_t k, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  xyzz p = jac_to_xyzz(jac_load(pts + i * 96));
+  affine_store(out + i * 64, xyzz_to_affine(p));
+}
+
+// ---- fixed-base table of the generator: T[w][d] = d * 2^(8w) * G, d in 1..255 (d = 0 unused) -------
+__global__ void __launch_bounds__(256) k_fixed_base_table(uint8_t* table) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // t = w*256 + d
+  if (t >= 32 * 256) return;
+  uint32_t w = t >> 8, d = t & 255;
+  affine g;
+  g.x = fe_one<Fq>();
+  g.y = fe_dbl<Fq>(fe_one<Fq>());  // (1, 2) in Montgomery form
+  affine outp;
+  if (d == 0) {
+    outp.x = fe_zero();
+    outp.y = fe_zero();
+  } else {
+    // scalar = d << (8w): left-to-right double-and-add over the 8 bits of d, then 8w doublings
+    xyzz acc = xyzz_identity();
+    for (int b = 7; b >= 0; b--) {
+      acc = xyzz_dbl(acc);
+      if ((d >> b) & 1u) xyzz_madd(acc, g);
+    }
+    for (uint32_t i = 0; i < 8 * w; i++) acc = xyzz_dbl(acc);
+    outp = xyzz_to_affine(acc);
+  }
+  affine_store(table + (size_t)t * 64, outp);
+}
+
+__global__ void __launch_bounds__(256) k_fixed_base_mul(const fe* scalars, size_t n, const uint8_t* table, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+  xyzz acc = xyzz_identity();
+  for (int w = 0; w < 32; w++) {
+    uint32_t d = (s.v[w >> 2] >> ((w & 3) * 8)) & 255u;
+    if (d) {
+      affine p = affine_load(table + ((size_t)(w * 256 + d)) * 64);
+      xyzz_madd(acc, p);
+    }
+  }
+  affine_store(out + i * 64, xyzz_to_affine(acc));
+}
+
+static uint8_t* g_fixed_table = nullptr;
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2mi_init(int device) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (ctx().inited) return ctx().device == device ? H2MI_OK : H2MI_EINVAL;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return H2MI_ENODEV;
+  if (device < 0 || device >= count) return H2MI_EINVAL;
+  H2_HIP(hipSetDevice(device));
+  H2_HIP(hipStreamCreateWithFlags(&ctx().stream, hipStreamNonBlocking));
+  ctx().device = device;
+  ctx().inited = true;
+  return H2MI_OK;
+}
+
+void h2mi_shutdown(void) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (!ctx().inited) return;
+  hipStreamSynchronize(ctx().stream);
+  if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; }
+  hipStreamDestroy(ctx().stream);
+  ctx().stream = nullptr;
+  ctx().inited = false;
+}
+
+const char* h2mi_strerror(int code) {
+  switch (code) {
+    case H2MI_OK: return "ok";
+    case H2MI_EINVAL: return "invalid argument";
+    case H2MI_ENODEV: return "no usable GPU (h2mi_init not called or failed); there is no CPU fallback";
+    case H2MI_ENOMEM: return "out of memory";
+    case H2MI_EHIP: return ctx().last_err[0] ? ctx().last_err : "HIP runtime error";
+    case H2MI_EHANDLE: return "unknown bases handle";
+    case H2MI_ERANGE: return "size out of range";
+    default: return "unknown error";
+  }
+}
+
+const char* h2mi_version(void) { return "h2mi 0.1 (gfx950)"; }
+
+int h2mi_malloc(size_t bytes, void** d_ptr) {
+  H2_REQUIRE_INIT();
+  if (!d_ptr) return H2MI_EINVAL;
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+  H2_HIP(e);
+  return H2MI_OK;
+}
+int h2mi_free(void* d_ptr) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipFree(d_ptr));
+  return H2MI_OK;
+}
+int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  H2_HIP(hipStreamSynchronize(ctx().stream));
+  return H2MI_OK;
+}
+int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+  H2_HIP(hipStreamSynchronize(ctx().stream));
+  return H2MI_OK;
+}
+int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+  return H2MI_OK;
+}
+int h2mi_sync(void) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipStreamSynchronize(ctx().stream));
+  return H2MI_OK;
+}
+
+int h2mi_profile_enable(int on) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  ctx().profiling = on != 0;
+  return H2MI_OK;
+}
+int h2mi_profile_reset(void) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (ctx().inited) hipDeviceSynchronize();
+  for (auto& r : ctx().prof) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  ctx().prof.clear();
+  return H2MI_OK;
+}
+int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  H2_HIP(hipDeviceSynchronize());
+  double tot = 0;
+  uint64_t cnt = 0;
+  size_t pl = prefix ? strlen(prefix) : 0;
+  for (auto& r : ctx().prof) {
+    if (pl && r.name.compare(0, pl, prefix) != 0) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      tot += ms;
+      cnt++;
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
+  return H2MI_OK;
+}
+
+int h2mi_dbg_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  H2_REQUIRE_INIT();
+  if (!a || !out || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  fe *da = nullptr, *db = nullptr, *dout = nullptr;
+  H2_HIP(hipMalloc(&da, n * 32));
+  H2_HIP(hipMalloc(&dout, n * 32));
+  H2_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, s));
+  if (b) {
+    H2_HIP(hipMalloc(&db, n * 32));
+    H2_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, s));
+  }
+  uint32_t grid = ceil_div_u32(n, 256);
+  if (field == 0) {
+    H2_LAUNCH("k_dbg_field_fq", k_dbg_field<FqP>, grid, 256, 0, s, op, da, db, dout, n);
+  } else {
+    H2_LAUNCH("k_dbg_field_fr", k_dbg_field<FrP>, grid, 256, 0, s, op, da, db, dout, n);
+  }
+  H2_HIP(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  hipFree(da);
+  hipFree(dout);
+  if (db) hipFree(db);
+  return H2MI_OK;
+}
+
+int h2mi_dbg_g1_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {
+  H2_REQUIRE_INIT();
+  if (!p || !out_jac || n == 0 || (op != 1 && !q)) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  uint8_t *dp = nullptr, *dq = nullptr, *dout = nullptr;
+  H2_HIP(hipMalloc(&dp, n * 64));
+  H2_HIP(hipMalloc(&dout, n * 96));
+  H2_HIP(hipMemcpyAsync(dp, p, n * 64, hipMemcpyHostToDevice, s));
+  if (q) {
+    H2_HIP(hipMalloc(&dq, n * 64));
+    H2_HIP(hipMemcpyAsync(dq, q, n * 64, hipMemcpyHostToDevice, s));
+  }
+  H2_LAUNCH("k_dbg_g1", k_dbg_g1, ceil_div_u32(n, 256), 256, 0, s, op, dp, dq, dout, n);
+  H2_HIP(hipMemcpyAsync(out_jac, dout, n * 96, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  hipFree(dp);
+  hipFree(dout);
+  if (dq) hipFree(dq);
+  return H2MI_OK;
+}
+
+int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]) {
+  H2_REQUIRE_INIT();
+  if (!points || !out_jacobian || k == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  uint8_t *dp = nullptr, *dout = nullptr;
+  H2_HIP(hipMalloc(&dp, k * 96));
+  H2_HIP(hipMalloc(&dout, 96));
+  H2_HIP(hipMemcpyAsync(dp, points, k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_sum_jac", k_g1_sum_jac, 1, 64, 0, s, dp, k, dout);
+  H2_HIP(hipMemcpyAsync(out_jacobian, dout, 96, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  hipFree(dp);
+  hipFree(dout);
+  return H2MI_OK;
+}
+
+int h2mi_g1_batch_normalize(const uint64_t* jacp, size_t k, uint64_t* affine_out) {
+  H2_REQUIRE_INIT();
+  if (!jacp || !affine_out || k == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  uint8_t *dp = nullptr, *dout = nullptr;
+  H2_HIP(hipMalloc(&dp, k * 96));
+  H2_HIP(hipMalloc(&dout, k * 64));
+  H2_HIP(hipMemcpyAsync(dp, jacp, k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_normalize", k_g1_normalize, ceil_div_u32(k, 256), 256, 0, s, dp, k, dout);
+  H2_HIP(hipMemcpyAsync(affine_out, dout, k * 64, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  hipFree(dp);
+  hipFree(dout);
+  return H2MI_OK;
+}
+
+int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_scalars || !d_out_affine || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  if (!g_fixed_table) {
+    H2_HIP(hipMalloc(&g_fixed_table, 32 * 256 * 64));
+    H2_LAUNCH("k_fixed_base_table", k_fixed_base_table, 32, 256, 0, s, g_fixed_table);
+  }
+  H2_LAUNCH("k_fixed_base_mul", k_fixed_base_mul, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n,
+            (const uint8_t*)g_fixed_table, (uint8_t*)d_out_affine);
+  return H2MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal host-side plumbing shared by the libh2mi.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/h2mi.h"
+
+namespace h2 {
+
+struct ProfRec {
+  std::string name;
+  hipEvent_t a, b;
+};
+
+struct Ctx {
+  bool inited = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::recursive_mutex mu;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  char last_err[256] = {0};
+};
+
+Ctx& ctx();
+
+inline hipStream_t pick_stream(h2mi_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+
+void note_hip_error(hipError_t e, const char* file, int line);
+
+#define H2_HIP(x)                                   \
+  do {                                              \
+    hipError_t e_ = (x);                            \
+    if (e_ != hipSuccess) {                         \
+      ::h2::note_hip_error(e_, __FILE__, __LINE__); \
+      return H2MI_EHIP;                             \
+    }                                               \
+  } while (0)
+
+#define H2_REQUIRE_INIT()                   \
+  do {                                      \
+    if (!::h2::ctx().inited) return H2MI_ENODEV; \
+  } while (0)
+
+// Event-bracketed launch: when profiling is on, record a HIP event before and after the kernel on the
+// stream it is launched on (device time of exactly this launch); otherwise a plain launch.
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+
+#define H2_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                       \
+  do {                                                                                 \
+    if (::h2::ctx().profiling) ::h2::prof_begin(name, stream);                         \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__);   \
+    if (::h2::ctx().profiling) ::h2::prof_end(stream);                                 \
+    H2_HIP(hipGetLastError());                                                         \
+  } while (0)
+
+inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace h2

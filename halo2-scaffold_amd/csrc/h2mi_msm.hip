@@ -1,0 +1,497 @@
+// libh2mi.so — multi-scalar multiplication over BN254 G1 on gfx950 (Pippenger bucket method).
+//
+// Replaces halo2_proofs::arithmetic::best_multiexp for C = bn256::G1Affine as reached through
+// ParamsKZG::commit / commit_lagrange inside create_proof and keygen_vk (SURVEY.md 8a rows a2/a5;
+// reference call sites examples/standard_plonk.rs:33,41-49 and src/scaffold.rs:132,191-199,322-331).
+//
+// MI355X-first design (not the reference's per-thread serial Pippenger):
+//  * bases are registered once and kept in HBM together with the table 2^(c*w) * P_i for every window
+//    w (W x n x 64 B; 1 GiB at n = 2^20, c = 16 — HBM is 288 GB).  All windows then feed ONE set of
+//    2^(c-1) buckets, so there is no per-window reduction and no c-doubling Horner chain;
+//  * scalars: Montgomery -> canonical, signed c-bit digits (halves the bucket count), zero digits skipped;
+//  * (digit, point) pairs are counting-sorted by bucket (histogram, scan, scatter);
+//  * bucket accumulation is load-balanced: a bucket's sorted run is cut into tasks of <= 64 points, one
+//    thread per task, mixed additions in XYZZ coordinates on 64-B gathered table points, so a hot
+//    bucket (witness columns full of 0/1) never serialises a wavefront; partial sums are folded by
+//    fixed-depth segmented levels;
+//  * the weighted bucket sum  sum_b (b+1) B_b  is done without long serial chains: row/column sums of
+//    the bucket matrix (LDS tree reductions), bit-decomposed weights, then <= 15 doublings.
+// All arithmetic is 254-bit integer work on v_mad_u64_u32; no MFMA (not a dense contraction).
+#include <map>
+
+#include "g1.cuh"
+#include "h2mi_internal.h"
+
+namespace h2 {
+
+constexpr uint32_t S0 = 64;  // points per accumulation task
+constexpr uint32_t S1 = 32;  // partials per fold task
+
+struct Bases {
+  size_t n = 0;
+  uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
+  uint8_t* table = nullptr;     // [W][n] affine, 64 B each
+  uint16_t* digits = nullptr;   // [W][n]
+  uint32_t* entries = nullptr;  // sorted (sign<<31 | w*n+i)
+  uint32_t* hist = nullptr;     // nb
+  uint32_t* off = nullptr;      // nb+1
+  uint32_t* cursor = nullptr;   // nb
+  uint32_t* np[3] = {nullptr, nullptr, nullptr};    // partial counts per bucket after level 0,1,2
+  uint32_t* toff[3] = {nullptr, nullptr, nullptr};  // task offsets (nb+1)
+  uint8_t* part[2] = {nullptr, nullptr};            // XYZZ partial buffers (ping-pong)
+  uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
+  uint8_t* g = nullptr;                             // weighted partials (<= 32)
+  uint64_t* stats = nullptr;                        // [0] = insertions
+  uint32_t max_tasks0 = 0, max_tasks1 = 0, max_tasks2 = 0;
+};
+
+static std::map<uint64_t, Bases*> g_bases;
+static uint64_t g_next_handle = 1;
+
+// ---- registration: table[w][i] = 2^(c*w) * P_i ----------------------------------------------------
+__global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uint8_t* next, size_t n, uint32_t c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine p = affine_load(prev + i * 64);
+  if (affine_is_identity(p)) {
+    affine_store(next + i * 64, p);
+    return;
+  }
+  xyzz acc = xyzz_dbl_affine(p);
+  for (uint32_t k = 1; k < c; k++) acc = xyzz_dbl(acc);
+  affine_store(next + i * 64, xyzz_to_affine(acc));
+}
+
+// ---- per call -------------------------------------------------------------------------------------
+// signed-digit recoding: digit d_w in [-2^(c-1)+1, 2^(c-1)], stored as u16 two's complement
+// (0 = skip, v <= 0x8000 positive, v > 0x8000 negative with |d| = 0x10000 - v).
+__global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n, uint16_t* digits, uint32_t* hist, uint32_t c, uint32_t W) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+  uint32_t carry = 0;
+  const uint32_t half = 1u << (c - 1);
+  for (uint32_t w = 0; w < W; w++) {
+    uint32_t bit = w * c;
+    uint32_t limb = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (limb < 8) {
+      uint64_t two = s.v[limb];
+      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
+      raw = (uint32_t)(two >> sh) & ((1u << c) - 1);
+    }
+    uint32_t d = raw + carry;  // 0 .. 2^c
+    uint32_t v;
+    if (d > half) {            // negative digit d - 2^c, carry 1
+      uint32_t mag = (1u << c) - d;  // 0 .. 2^(c-1)-1
+      carry = 1;
+      v = mag ? (0x10000u - mag) : 0;
+      if (mag) atomicAdd(&hist[mag - 1], 1u);
+    } else {
+      carry = 0;
+      v = d;
+      if (d) atomicAdd(&hist[d - 1], 1u);
+    }
+    digits[(size_t)w * n + i] = (uint16_t)v;
+  }
+}
+
+// single-block exclusive scan of f(count) = ceil(count / chunk) over nb entries (nb multiple of 1024 or
+// smaller); writes np[b] = f(count[b]) and off[0..nb] (off[nb] = total).
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* counts, uint32_t nb, uint32_t chunk, uint32_t* np, uint32_t* off) {
+  __shared__ uint32_t sums[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (nb + 1023) / 1024;
+  uint32_t b0 = tid * per, b1 = min(b0 + per, nb);
+  uint32_t local = 0;
+  for (uint32_t b = b0; b < b1; b++) local += (counts[b] + chunk - 1) / chunk;
+  sums[tid] = local;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 values
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = (tid >= d) ? sums[tid - d] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = sums[tid] - local;
+  for (uint32_t b = b0; b < b1; b++) {
+    uint32_t f = (counts[b] + chunk - 1) / chunk;
+    if (np) np[b] = f;
+    off[b] = run;
+    run += f;
+  }
+  if (tid == 1023) off[nb] = sums[1023];
+}
+
+__global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* digits, size_t n, size_t n_reg, uint32_t W, const uint32_t* off,
+                                                      uint32_t* cursor, uint32_t* entries) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * W) return;
+  uint32_t w = (uint32_t)(t / n);
+  size_t i = t - (size_t)w * n;
+  uint32_t v = digits[t];
+  if (v == 0) return;
+  uint32_t neg = v > 0x8000u;
+  uint32_t mag = neg ? (0x10000u - v) : v;
+  uint32_t b = mag - 1;
+  uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
+  entries[pos] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
+}
+
+// largest b with toff[b] <= t (toff has nb+1 monotone entries, toff[nb] = total > t)
+__device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t nb, uint32_t t) {
+  uint32_t lo = 0, hi = nb;  // invariant: toff[lo] <= t < toff[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (toff[mid] <= t) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
+// accumulates with mixed additions.
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* hist, const uint32_t* toff,
+                                                    uint32_t nb, const uint8_t* table, uint8_t* part) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= toff[nb]) return;
+  uint32_t b = find_bucket(toff, nb, t);
+  uint32_t j = t - toff[b];
+  uint32_t start = off[b] + j * S0;
+  uint32_t len = min(S0, hist[b] - j * S0);
+  xyzz acc = xyzz_identity();
+  uint32_t e = entries[start];
+  affine nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
+  uint32_t nneg = e >> 31;
+  for (uint32_t k = 0; k < len; k++) {
+    affine p = nxt;
+    uint32_t neg = nneg;
+    if (k + 1 < len) {
+      e = entries[start + k + 1];
+      nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
+      nneg = e >> 31;
+    }
+    if (neg) p.y = fe_neg<Fq>(p.y);
+    xyzz_madd(acc, p);
+  }
+  xyzz_store(part + (size_t)t * 128, acc);
+}
+
+// fold level: one thread per task of <= S1 partials of one bucket
+__global__ void __launch_bounds__(256) k_msm_fold(const uint8_t* pin, const uint32_t* toff_in, const uint32_t* np_in, const uint32_t* toff_out,
+                                                   uint32_t nb, uint8_t* pout) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= toff_out[nb]) return;
+  uint32_t b = find_bucket(toff_out, nb, t);
+  uint32_t j = t - toff_out[b];
+  uint32_t start = toff_in[b] + j * S1;
+  uint32_t len = min(S1, np_in[b] - j * S1);
+  xyzz acc = xyzz_load(pin + (size_t)start * 128);
+  for (uint32_t k = 1; k < len; k++) {
+    xyzz p = xyzz_load(pin + (size_t)(start + k) * 128);
+    xyzz_add(acc, p);
+  }
+  xyzz_store(pout + (size_t)t * 128, acc);
+}
+
+__device__ __forceinline__ xyzz load_bucket(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t b) {
+  uint32_t cnt = np[b];
+  if (cnt == 0) return xyzz_identity();
+  uint32_t s = toff[b];
+  xyzz acc = xyzz_load(part + (size_t)s * 128);
+  for (uint32_t k = 1; k < cnt; k++) {  // only adversarial inputs (one bucket > S0*S1*S1 points) get here
+    xyzz p = xyzz_load(part + (size_t)(s + k) * 128);
+    xyzz_add(acc, p);
+  }
+  return acc;
+}
+
+// block-wide tree sum of up to 256 XYZZ values held in LDS
+__device__ __forceinline__ void block_tree_sum(xyzz* lds, uint32_t count_pow2) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t s = count_pow2 >> 1; s > 0; s >>= 1) {
+    if (tid < s) {
+      xyzz a = lds[tid];
+      xyzz b = lds[tid + s];
+      xyzz_add(a, b);
+      lds[tid] = a;
+    }
+    __syncthreads();
+  }
+}
+
+extern __shared__ uint4 h2_msm_smem[];
+
+// bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
+__global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t logNh, uint32_t logNl,
+                                                     uint8_t* rc) {
+  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  xyzz v = xyzz_identity();
+  if (blk < Nh) {
+    if (tid < Nl) v = load_bucket(part, toff, np, (blk << logNl) + tid);
+  } else {
+    if (tid < Nh) v = load_bucket(part, toff, np, (tid << logNl) + (blk - Nh));
+  }
+  lds[tid] = v;
+  __syncthreads();
+  block_tree_sum(lds, 256);
+  if (tid == 0) xyzz_store(rc + (size_t)blk * 128, lds[0]);
+}
+
+// bit-decomposed weights: block beta < logNh sums rows with bit beta of hi set; block logNh + beta sums
+// columns with bit beta of (lo+1) set (beta <= logNl).
+__global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_t logNh, uint32_t logNl, uint8_t* g) {
+  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  xyzz v = xyzz_identity();
+  if (blk < logNh) {
+    if (tid < Nh && ((tid >> blk) & 1u)) v = xyzz_load(rc + (size_t)tid * 128);
+  } else {
+    uint32_t beta = blk - logNh;
+    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = xyzz_load(rc + (size_t)(Nh + tid) * 128);
+  }
+  lds[tid] = v;
+  __syncthreads();
+  block_tree_sum(lds, 256);
+  if (tid == 0) xyzz_store(g + (size_t)blk * 128, lds[0]);
+}
+
+// result = sum_beta 2^(beta + logNl) G_row[beta] + sum_beta 2^beta G_col[beta]
+__global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t logNh, uint32_t logNl, uint8_t* out_jac, const uint32_t* off,
+                                                   uint32_t nb, uint64_t* stats) {
+  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t terms = logNh + logNl + 1;
+  xyzz v = xyzz_identity();
+  if (tid < terms) {
+    v = xyzz_load(g + (size_t)tid * 128);
+    uint32_t shift = tid < logNh ? tid + logNl : tid - logNh;
+    for (uint32_t k = 0; k < shift; k++) v = xyzz_dbl(v);
+  }
+  lds[tid] = v;
+  __syncthreads();
+  block_tree_sum(lds, 64);
+  if (tid == 0) {
+    jac_store(out_jac, xyzz_to_jac(lds[0]));
+    if (stats) stats[0] = off[nb];
+  }
+}
+
+// ---- host -----------------------------------------------------------------------------------------
+static uint32_t pick_window(size_t n) {
+  const char* ev = getenv("H2MI_MSM_C");
+  if (ev) {
+    int c = atoi(ev);
+    if (c >= 4 && c <= 16) return (uint32_t)c;
+  }
+  uint32_t lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  // buckets 2^(c-1) ~ n/32 keeps the bucket phase small against n*W point additions
+  int c = (int)lg - 4;
+  if (c < 6) c = 6;
+  if (c > 16) c = 16;
+  return (uint32_t)c;
+}
+
+static void free_bases(Bases* B) {
+  hipFree(B->table); hipFree(B->digits); hipFree(B->entries); hipFree(B->hist); hipFree(B->off); hipFree(B->cursor);
+  for (int i = 0; i < 3; i++) { hipFree(B->np[i]); hipFree(B->toff[i]); }
+  hipFree(B->part[0]); hipFree(B->part[1]); hipFree(B->rc); hipFree(B->g); hipFree(B->stats);
+  delete B;
+}
+
+#define H2_ALLOC(ptr, bytes)                                   \
+  do {                                                         \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));        \
+    if (e_ != hipSuccess) {                                    \
+      note_hip_error(e_, __FILE__, __LINE__);                  \
+      free_bases(B);                                           \
+      return e_ == hipErrorOutOfMemory ? H2MI_ENOMEM : H2MI_EHIP; \
+    }                                                          \
+  } while (0)
+
+static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s) {
+  if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
+  Bases* B = new Bases();
+  B->n = n;
+  B->c = pick_window(n);
+  B->W = (256 + B->c - 1) / B->c;
+  B->nb = 1u << (B->c - 1);
+  B->logNl = (B->c - 1 + 1) / 2;
+  B->logNh = (B->c - 1) - B->logNl;
+  if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
+  const size_t nW = n * B->W;
+  B->max_tasks0 = (uint32_t)(nW / S0 + B->nb);
+  B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
+  B->max_tasks2 = B->max_tasks1 / S1 + B->nb;
+  H2_ALLOC(B->table, nW * 64);
+  H2_ALLOC(B->digits, nW * 2);
+  H2_ALLOC(B->entries, nW * 4);
+  H2_ALLOC(B->hist, (size_t)B->nb * 4);
+  H2_ALLOC(B->off, (size_t)(B->nb + 1) * 4);
+  H2_ALLOC(B->cursor, (size_t)B->nb * 4);
+  for (int i = 0; i < 3; i++) {
+    H2_ALLOC(B->np[i], (size_t)B->nb * 4);
+    H2_ALLOC(B->toff[i], (size_t)(B->nb + 1) * 4);
+  }
+  H2_ALLOC(B->part[0], (size_t)B->max_tasks0 * 128);
+  H2_ALLOC(B->part[1], (size_t)B->max_tasks1 * 128);
+  H2_ALLOC(B->rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * 128);
+  H2_ALLOC(B->g, (size_t)64 * 128);
+  H2_ALLOC(B->stats, 64);
+  if (hipMemcpyAsync(B->table, d_bases, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
+  for (uint32_t w = 1; w < B->W; w++) {
+    if (ctx().profiling) prof_begin("k_msm_table_next", s);
+    hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * n * 64),
+                       B->table + (size_t)w * n * 64, n, B->c);
+    if (ctx().profiling) prof_end(s);
+  }
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
+  uint64_t h = g_next_handle++;
+  g_bases[h] = B;
+  *handle_out = h;
+  return H2MI_OK;
+}
+
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
+  const uint32_t nb = B->nb, W = B->W;
+  H2_HIP(hipMemsetAsync(B->hist, 0, (size_t)nb * 4, s));
+  H2_HIP(hipMemsetAsync(B->cursor, 0, (size_t)nb * 4, s));
+  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->digits, B->hist, B->c, W);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->hist, nb, 1u, (uint32_t*)nullptr, B->off);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->hist, nb, S0, B->np[0], B->toff[0]);
+  H2_LAUNCH("k_msm_scatter", k_msm_scatter, ceil_div_u32(n * W, 256), 256, 0, s, (const uint16_t*)B->digits, n, B->n, W,
+            (const uint32_t*)B->off, B->cursor, B->entries);
+  uint32_t tasks0 = (uint32_t)(n * W / S0 + nb);
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)B->entries, (const uint32_t*)B->off,
+            (const uint32_t*)B->hist, (const uint32_t*)B->toff[0], nb, (const uint8_t*)B->table, B->part[0]);
+  // fold level 1: part[0] -> part[1]
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->np[0], nb, S1, B->np[1], B->toff[1]);
+  uint32_t tasks1 = tasks0 / S1 + nb;
+  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, s, (const uint8_t*)B->part[0], (const uint32_t*)B->toff[0],
+            (const uint32_t*)B->np[0], (const uint32_t*)B->toff[1], nb, B->part[1]);
+  // fold level 2: part[1] -> part[0] (part[0] holds max_tasks0 >= max_tasks2 slots)
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->np[1], nb, S1, B->np[2], B->toff[2]);
+  uint32_t tasks2 = tasks1 / S1 + nb;
+  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks2, 256), 256, 0, s, (const uint8_t*)B->part[1], (const uint32_t*)B->toff[1],
+            (const uint32_t*)B->np[1], (const uint32_t*)B->toff[2], nb, B->part[0]);
+  // weighted bucket sum
+  const uint32_t Nh = 1u << B->logNh, Nl = 1u << B->logNl;
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * 128, s, (const uint8_t*)B->part[0], (const uint32_t*)B->toff[2],
+            (const uint32_t*)B->np[2], B->logNh, B->logNl, B->rc);
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * 128, s, (const uint8_t*)B->rc, B->logNh, B->logNl, B->g);
+  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * 128, s, (const uint8_t*)B->g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)B->off,
+            nb, B->stats);
+  return H2MI_OK;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2mi_bases_register_dev(const void* d_bases, size_t n, uint64_t* handle_out) {
+  H2_REQUIRE_INIT();
+  if (!d_bases || !handle_out) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return register_dev(d_bases, n, handle_out, ctx().stream);
+}
+
+int h2mi_bases_register(const uint64_t* bases, size_t n, uint64_t* handle_out) {
+  H2_REQUIRE_INIT();
+  if (!bases || !handle_out || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, n * 64);
+  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+  H2_HIP(e);
+  int rc = H2MI_OK;
+  if (hipMemcpyAsync(d, bases, n * 64, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rc = H2MI_EHIP;
+  if (!rc) rc = register_dev(d, n, handle_out, ctx().stream);
+  hipStreamSynchronize(ctx().stream);
+  hipFree(d);
+  return rc;
+}
+
+int h2mi_bases_release(uint64_t handle) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto it = g_bases.find(handle);
+  if (it == g_bases.end()) return H2MI_EHANDLE;
+  hipDeviceSynchronize();
+  free_bases(it->second);
+  g_bases.erase(it);
+  return H2MI_OK;
+}
+
+int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* buckets, uint64_t* n) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto it = g_bases.find(handle);
+  if (it == g_bases.end()) return H2MI_EHANDLE;
+  if (c) *c = it->second->c;
+  if (windows) *windows = it->second->W;
+  if (buckets) *buckets = it->second->nb;
+  if (n) *n = it->second->n;
+  return H2MI_OK;
+}
+
+int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_scalars || !d_out_jacobian || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto it = g_bases.find(handle);
+  if (it == g_bases.end()) return H2MI_EHANDLE;
+  if (n > it->second->n) return H2MI_ERANGE;
+  return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream));
+}
+
+int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out[12]) {
+  H2_REQUIRE_INIT();
+  if (!scalars || !out || n == 0) return H2MI_EINVAL;
+  if (handle == 0 && !bases) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  uint64_t h = handle;
+  int rc = H2MI_OK;
+  if (handle == 0) {
+    rc = h2mi_bases_register(bases, n, &h);
+    if (rc) return rc;
+  }
+  auto it = g_bases.find(h);
+  if (it == g_bases.end()) return H2MI_EHANDLE;
+  if (n > it->second->n) return H2MI_ERANGE;
+  hipStream_t s = ctx().stream;
+  uint8_t* d = nullptr;
+  if (hipMalloc(&d, n * 32 + 96) != hipSuccess) rc = H2MI_ENOMEM;
+  if (!rc && hipMemcpyAsync(d + 96, scalars, n * 32, hipMemcpyHostToDevice, s) != hipSuccess) rc = H2MI_EHIP;
+  if (!rc) rc = msm_dev(it->second, d + 96, n, d, s);
+  if (!rc && hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
+  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
+  if (d) hipFree(d);
+  if (handle == 0) h2mi_bases_release(h);
+  return rc;
+}
+
+int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto it = g_bases.find(handle);
+  if (it == g_bases.end()) return H2MI_EHANDLE;
+  Bases* B = it->second;
+  H2_HIP(hipDeviceSynchronize());
+  uint64_t st = 0;
+  H2_HIP(hipMemcpy(&st, B->stats, 8, hipMemcpyDeviceToHost));
+  if (bucket_adds) *bucket_adds = st;
+  if (reduce_adds) {
+    // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))
+    uint64_t Nh = 1ull << B->logNh, Nl = 1ull << B->logNl;
+    *reduce_adds = 2ull * B->nb + (B->logNh * Nh + (B->logNl + 1) * Nl) / 2 + (B->logNh + B->logNl + 1) * (uint64_t)(B->c);
+  }
+  return H2MI_OK;
+}
+
+}  // extern "C"

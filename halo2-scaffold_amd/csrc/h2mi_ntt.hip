@@ -1,0 +1,450 @@
+// libh2mi.so — radix-2 NTT over the BN254 scalar field on gfx950.
+//
+// Replaces halo2_proofs::arithmetic::best_fft (G = bn256::Fr) and the scaling sweeps of
+// poly::EvaluationDomain::{ifft, coeff_to_extended, extended_to_coeff} — SURVEY.md 8a rows a3/a4,
+// reached from the reference through create_proof / keygen_pk (examples/standard_plonk.rs:34,41-49).
+//
+// Algorithm (four-step / Stockham-style autosort, 1..3 passes).  n = N1*N2*N3, N_p = 2^m_p <= 1024:
+//   pass p < last : inside every segment of length SEG (n, n/N1, ...) run the size-N_p DFT down each
+//                   column (stride S = SEG/N_p), multiply element (k, j) by w_seg^(j*k), store in place;
+//   last pass     : size-N_P DFT of every contiguous row, scattered to the digit-reversed output slot.
+// Every size-2^m DFT runs in LDS: the tile (2^m x C columns, 32 B elements) and the 2^(m-1) local
+// twiddles are staged in LDS once; m radix-2 DIF stages exchange through LDS; the tile is read back
+// bit-reversed on the way out.  HBM sees each element once per pass (read + write, C*32 B segments).
+// The coset pre-scale (a[i] *= g^i) is fused into the first pass's load and the n^-1 post-scale into
+// the last pass's store, so EvaluationDomain's extra sweeps over memory disappear.
+// Twiddles: w^e for the inter-pass factors comes from two small tables (e = hi*2^h + lo, one extra
+// field mul) instead of an n-entry table, so all twiddle data stays L2/LDS resident.
+#include <map>
+
+#include "fp.cuh"
+#include "h2mi_internal.h"
+
+namespace h2 {
+
+using Fr = FrP;
+
+// out[i] = (base^(2^log_stride))^i
+__global__ void __launch_bounds__(256) k_pow_table(fe* out, uint32_t count, fe base, uint32_t log_stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe b = base;
+  for (uint32_t s = 0; s < log_stride; s++) b = fe_sqr<Fr>(b);
+  fe r = fe_one<Fr>();
+  for (int bit = 31; bit >= 0; bit--) {
+    r = fe_sqr<Fr>(r);
+    if ((i >> bit) & 1u) r = fe_mul<Fr>(r, b);
+  }
+  fe_store(&out[i], r);
+}
+
+struct PassParams {
+  const fe* in;
+  fe* out;
+  uint32_t log_n, log_seg, m, logC;
+  const fe* loc;  // local twiddles w_loc^e, e < 2^(m-1)
+  const fe* tlo;  // omega^i, i < 2^h
+  const fe* thi;  // omega^(i << h)
+  uint32_t h;
+  const fe* plo;  // pre-scale tables (first pass only) or null
+  const fe* phi;
+  uint32_t ph;
+  int has_post;
+  fe post;
+  uint32_t logN1, logN2;  // last pass: digit-reversal geometry
+  uint32_t remap;         // XCD-aware block remap on/off
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t m) { return m ? (__brev(x) >> (32 - m)) : 0; }
+
+// blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous run of tiles so that tiles
+// sharing 128-B lines (adjacent columns) hit the same L2.  Bijective when nblocks % 8 == 0.
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nb, uint32_t remap) {
+  if (!remap || (nb & 7u)) return b;
+  return (b & 7u) * (nb >> 3) + (b >> 3);
+}
+
+// m radix-2 DIF stages over C tiles of 2^m elements resident in LDS; result is bit-reversed per tile.
+__device__ __forceinline__ void local_ntt(fe* lds, const fe* tw, uint32_t m, uint32_t logC) {
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  if (m == 0) return;
+  const uint32_t nbf = 1u << (m - 1 + logC);
+  for (uint32_t s = 0; s < m; s++) {
+    const uint32_t lh = m - 1 - s;  // log2(half)
+    const uint32_t half = 1u << lh;
+    for (uint32_t b = tid; b < nbf; b += T) {
+      uint32_t c = b >> (m - 1);
+      uint32_t i_ = b & ((1u << (m - 1)) - 1);
+      uint32_t pos = i_ & (half - 1);
+      uint32_t grp = i_ >> lh;
+      uint32_t i = (c << m) | (grp << (lh + 1)) | pos;
+      fe u = lds[i], v = lds[i + half];
+      lds[i] = fe_add<Fr>(u, v);
+      fe d = fe_sub<Fr>(u, v);
+      if (s != m - 1) d = fe_mul<Fr>(d, tw[pos << s]);
+      lds[i + half] = d;
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ fe pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {
+  return fe_mul<Fr>(fe_load(&hi[e >> h]), fe_load(&lo[e & ((1u << h) - 1)]));
+}
+
+extern __shared__ uint4 h2_smem[];
+
+// non-final pass: column DFTs inside segments, in-place layout
+__global__ void __launch_bounds__(256) k_ntt_pass_col(PassParams p) {
+  fe* lds = reinterpret_cast<fe*>(h2_smem);
+  const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
+  fe* tw = lds + (C << m);
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  const uint32_t logS = p.log_seg - m;
+  const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
+  const uint32_t tiles_per_seg_log = logS - logC;
+  const uint32_t seg = tile >> tiles_per_seg_log;
+  const uint32_t jl0 = (tile & ((1u << tiles_per_seg_log) - 1)) << logC;
+  const size_t base = (size_t)seg << p.log_seg;
+
+  for (uint32_t o = tid; o < (C << m); o += T) {
+    uint32_t c = o & (C - 1), e = o >> logC;
+    size_t idx = base + ((size_t)e << logS) + jl0 + c;
+    fe x = fe_load(&p.in[idx]);
+    if (p.plo) x = fe_mul<Fr>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    lds[(c << m) | e] = x;
+  }
+  for (uint32_t i = tid; i < (1u << (m - 1)); i += T) tw[i] = fe_load(&p.loc[i]);
+  __syncthreads();
+  local_ntt(lds, tw, m, logC);
+  const uint32_t sh = p.log_n - p.log_seg;
+  for (uint32_t o = tid; o < (C << m); o += T) {
+    uint32_t c = o & (C - 1), k = o >> logC;
+    fe x = lds[(c << m) | bitrev(k, m)];
+    uint32_t ex = ((jl0 + c) * k) << sh;  // < n
+    x = fe_mul<Fr>(x, pow2tab(p.tlo, p.thi, p.h, ex));
+    fe_store(&p.out[base + ((size_t)k << logS) + jl0 + c], x);
+  }
+}
+
+// final pass: row DFTs, digit-reversed scatter
+__global__ void __launch_bounds__(256) k_ntt_pass_row(PassParams p) {
+  fe* lds = reinterpret_cast<fe*>(h2_smem);
+  const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
+  fe* tw = lds + (C << m);
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
+  const uint32_t k2 = tile & ((1u << p.logN2) - 1);
+  const uint32_t k1_0 = (tile >> p.logN2) << logC;
+
+  for (uint32_t o = tid; o < (C << m); o += T) {
+    uint32_t c = o >> m, e = o & ((1u << m) - 1);
+    size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
+    size_t idx = (rho << m) + e;
+    fe x = fe_load(&p.in[idx]);
+    if (p.plo) x = fe_mul<Fr>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    lds[(c << m) | e] = x;
+  }
+  if (m) for (uint32_t i = tid; i < (1u << (m - 1)); i += T) tw[i] = fe_load(&p.loc[i]);
+  __syncthreads();
+  local_ntt(lds, tw, m, logC);
+  for (uint32_t o = tid; o < (C << m); o += T) {
+    uint32_t c = o & (C - 1), k = o >> logC;
+    fe x = lds[(c << m) | bitrev(k, m)];
+    if (p.has_post) x = fe_mul<Fr>(x, p.post);
+    size_t oidx = (size_t)(k1_0 + c) + ((size_t)k2 << p.logN1) + ((size_t)k << (p.logN1 + p.logN2));
+    fe_store(&p.out[oidx], x);
+  }
+}
+
+// a[i] = a[i] * base^i (* post)
+__global__ void __launch_bounds__(256) k_scale_powers(fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, int has_post, fe post) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_load(&a[i]);
+  x = fe_mul<Fr>(x, pow2tab(lo, hi, h, (uint32_t)i));
+  if (has_post) x = fe_mul<Fr>(x, post);
+  fe_store(&a[i], x);
+}
+__global__ void __launch_bounds__(256) k_powers(fe* out, size_t n, const fe* lo, const fe* hi, uint32_t h) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store(&out[i], pow2tab(lo, hi, h, (uint32_t)i));
+}
+
+// ---- host side: plans and table caches -----------------------------------------------------------
+struct Key {
+  uint64_t w[4];
+  uint32_t log_n;
+  bool operator<(const Key& o) const {
+    if (log_n != o.log_n) return log_n < o.log_n;
+    return memcmp(w, o.w, 32) < 0;
+  }
+};
+struct PowTab {  // base^i split as hi/lo for i < 2^log_n
+  fe* lo = nullptr;
+  fe* hi = nullptr;
+  uint32_t h = 0;
+};
+struct Plan {
+  int P = 0;
+  uint32_t m[3] = {0, 0, 0};
+  PowTab tw;
+  fe* loc[3] = {nullptr, nullptr, nullptr};
+};
+
+static std::map<Key, PowTab> g_powtabs;
+static std::map<Key, Plan> g_plans;
+static fe* g_tmp = nullptr;
+static size_t g_tmp_elems = 0;
+
+static fe host_fe(const uint64_t w[4]) {
+  fe r;
+  memcpy(r.v, w, 32);
+  return r;
+}
+
+static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, PowTab* out) {
+  Key k;
+  memcpy(k.w, base, 32);
+  k.log_n = log_n;
+  auto it = g_powtabs.find(k);
+  if (it != g_powtabs.end()) {
+    *out = it->second;
+    return H2MI_OK;
+  }
+  if (g_powtabs.size() > 64) {  // bounded cache: drop everything (tables are tiny and cheap to rebuild)
+    H2_HIP(hipStreamSynchronize(s));
+    for (auto& kv : g_powtabs) {
+      hipFree(kv.second.lo);
+      hipFree(kv.second.hi);
+    }
+    g_powtabs.clear();
+    for (auto& kv : g_plans)
+      for (int i = 0; i < 3; i++)
+        if (kv.second.loc[i]) hipFree(kv.second.loc[i]);
+    g_plans.clear();
+  }
+  PowTab t;
+  t.h = (log_n + 1) / 2;
+  uint32_t nlo = 1u << t.h, nhi = 1u << (log_n - t.h);
+  H2_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
+  H2_HIP(hipMalloc(&t.hi, (size_t)nhi * 32));
+  fe b = host_fe(base);
+  H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nlo, 256), 256, 0, s, t.lo, nlo, b, 0u);
+  H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nhi, 256), 256, 0, s, t.hi, nhi, b, t.h);
+  g_powtabs[k] = t;
+  *out = t;
+  return H2MI_OK;
+}
+
+static void choose_split(uint32_t log_n, Plan* pl) {
+  const uint32_t MAXM = 10;
+  if (log_n <= MAXM) {
+    pl->P = 1;
+    pl->m[0] = log_n;
+  } else if (log_n <= 2 * MAXM) {
+    pl->P = 2;
+    pl->m[0] = (log_n + 1) / 2;
+    pl->m[1] = log_n - pl->m[0];
+  } else {
+    pl->P = 3;
+    pl->m[0] = (log_n + 2) / 3;
+    pl->m[1] = (log_n - pl->m[0] + 1) / 2;
+    pl->m[2] = log_n - pl->m[0] - pl->m[1];
+  }
+}
+
+static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan* out) {
+  Key k;
+  memcpy(k.w, omega, 32);
+  k.log_n = log_n;
+  auto it = g_plans.find(k);
+  if (it != g_plans.end()) {
+    *out = it->second;
+    return H2MI_OK;
+  }
+  Plan pl;
+  choose_split(log_n, &pl);
+  int rc = get_powtab(omega, log_n, s, &pl.tw);
+  if (rc) return rc;
+  fe w = host_fe(omega);
+  for (int p = 0; p < pl.P; p++) {
+    uint32_t m = pl.m[p];
+    if (m == 0) continue;
+    // reuse a table of the same m
+    for (int q = 0; q < p; q++)
+      if (pl.m[q] == m) pl.loc[p] = pl.loc[q];
+    if (pl.loc[p]) continue;
+    uint32_t cnt = 1u << (m - 1);
+    H2_HIP(hipMalloc(&pl.loc[p], (size_t)cnt * 32));
+    // w_loc = omega^(n / 2^m): order 2^m
+    H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m);
+  }
+  g_plans[k] = pl;
+  *out = pl;
+  return H2MI_OK;
+}
+
+static int ensure_tmp(size_t elems, hipStream_t s) {
+  if (g_tmp_elems >= elems) return H2MI_OK;
+  if (g_tmp) {
+    H2_HIP(hipStreamSynchronize(s));
+    H2_HIP(hipFree(g_tmp));
+    g_tmp = nullptr;
+    g_tmp_elems = 0;
+  }
+  hipError_t e = hipMalloc(&g_tmp, elems * 32);
+  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+  H2_HIP(e);
+  g_tmp_elems = elems;
+  return H2MI_OK;
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v ? (uint32_t)atoi(v) : dflt;
+}
+
+static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post, hipStream_t s) {
+  if (log_n > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  Plan pl;
+  int rc = get_plan(omega, log_n, s, &pl);
+  if (rc) return rc;
+  PowTab pt;
+  if (pre) {
+    rc = get_powtab(pre, log_n, s, &pt);
+    if (rc) return rc;
+  }
+  const size_t n = (size_t)1 << log_n;
+  if (pl.P > 1) {
+    rc = ensure_tmp(n, s);
+    if (rc) return rc;
+  }
+  const uint32_t tile_elems_log = env_u32("H2MI_NTT_TILE_LOG", 10);  // elements staged per block
+  const uint32_t remap = env_u32("H2MI_NTT_XCD_REMAP", 1);
+  // buffer schedule: P=1: a->a ; P=2: a->tmp, tmp->a ; P=3: a->tmp, tmp->tmp, tmp->a
+  uint32_t log_seg = log_n;
+  for (int p = 0; p < pl.P; p++) {
+    PassParams pp;
+    memset(&pp, 0, sizeof(pp));
+    const bool last = (p == pl.P - 1);
+    pp.in = (p == 0) ? d_a : g_tmp;
+    pp.out = last ? d_a : g_tmp;
+    pp.log_n = log_n;
+    pp.log_seg = log_seg;
+    pp.m = pl.m[p];
+    pp.loc = pl.loc[p];
+    pp.tlo = pl.tw.lo;
+    pp.thi = pl.tw.hi;
+    pp.h = pl.tw.h;
+    pp.remap = remap;
+    if (p == 0 && pre) {
+      pp.plo = pt.lo;
+      pp.phi = pt.hi;
+      pp.ph = pt.h;
+    }
+    uint32_t logC = pp.m >= tile_elems_log ? 0 : tile_elems_log - pp.m;
+    if (!last) {
+      uint32_t logS = log_seg - pp.m;
+      if (logC > logS) logC = logS;
+      pp.logC = logC;
+      uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
+      size_t shmem = (((size_t)1 << (pp.m + logC)) + ((size_t)1 << (pp.m - 1))) * 32;
+      H2_LAUNCH("k_ntt_pass_col", k_ntt_pass_col, nblocks, 256, shmem, s, pp);
+    } else {
+      pp.has_post = post ? 1 : 0;
+      if (post) pp.post = host_fe(post);
+      if (pl.P == 1) {
+        pp.logN1 = 0;
+        pp.logN2 = 0;
+      } else if (pl.P == 2) {
+        pp.logN1 = pl.m[0];
+        pp.logN2 = 0;
+      } else {
+        pp.logN1 = pl.m[0];
+        pp.logN2 = pl.m[1];
+      }
+      if (logC > pp.logN1) logC = pp.logN1;
+      pp.logC = logC;
+      uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
+      size_t shmem = (((size_t)1 << (pp.m + logC)) + (pp.m ? ((size_t)1 << (pp.m - 1)) : 1)) * 32;
+      uint32_t threads = 256;
+      H2_LAUNCH("k_ntt_pass_row", k_ntt_pass_row, nblocks, threads, shmem, s, pp);
+    }
+    log_seg -= pp.m;
+  }
+  return H2MI_OK;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post,
+                          h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_a || !omega) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return ntt_dev((fe*)d_a, log_n, omega, pre, post, pick_stream(stream));
+}
+
+int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post) {
+  H2_REQUIRE_INIT();
+  if (!a || !omega) return H2MI_EINVAL;
+  if (log_n > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  const size_t bytes = ((size_t)1 << log_n) * 32;
+  fe* d = nullptr;
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+  H2_HIP(e);
+  int rc = H2MI_OK;
+  if (hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, s) != hipSuccess) rc = H2MI_EHIP;
+  if (!rc) rc = ntt_dev(d, log_n, omega, pre, post, s);
+  if (!rc && hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
+  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
+  hipFree(d);
+  return rc;
+}
+
+int h2mi_ntt_bn254_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+  return h2mi_ntt_ext_bn254_fr(a, log_n, omega, nullptr, nullptr);
+}
+
+int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const uint64_t* post, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_a || !base || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 31) return H2MI_ERANGE;
+  PowTab pt;
+  int rc = get_powtab(base, log_n, s, &pt);
+  if (rc) return rc;
+  fe p = post ? host_fe(post) : fe{};
+  H2_LAUNCH("k_scale_powers", k_scale_powers, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_a, n, (const fe*)pt.lo, (const fe*)pt.hi, pt.h,
+            post ? 1 : 0, p);
+  return H2MI_OK;
+}
+
+int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_out || !base || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 31) return H2MI_ERANGE;
+  PowTab pt;
+  int rc = get_powtab(base, log_n, s, &pt);
+  if (rc) return rc;
+  H2_LAUNCH("k_powers", k_powers, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, (const fe*)pt.lo, (const fe*)pt.hi, pt.h);
+  return H2MI_OK;
+}
+
+}  // extern "C"

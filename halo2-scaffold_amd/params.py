@@ -1,0 +1,97 @@
+"""Mirror of halo2_proofs::poly::kzg::commitment::ParamsKZG<Bn256>.
+
+Reference call sites: ParamsKZG::setup (examples/standard_plonk.rs:29), gen_srs (src/scaffold.rs:119,
+174,271).  `setup(k, s)` takes the toxic-waste scalar explicitly (the reference draws it from OsRng);
+g[i] = s^i * G, g_lagrange[i] = L_i(s) * G with L_i(s) obtained as the inverse NTT of the powers of s —
+all computed by the device kernels and kept registered in HBM.  commit / commit_lagrange are
+best_multiexp against the matching base set (KZG ignores the blind).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import field as F
+from ._lib import check, lib
+from .device import DevBuf
+
+
+class ParamsKZG:
+    def __init__(self, k: int):
+        self.k = k
+        self.n = 1 << k
+        self.g_handle = None
+        self.g_lagrange_handle = None
+        self._g_dev = None
+        self._gl_dev = None
+
+    @classmethod
+    def setup(cls, k: int, s: int) -> "ParamsKZG":
+        p = cls(k)
+        n = p.n
+        s_m = F.fr_to_mont_limbs(s)
+        pw = DevBuf(n * 32)
+        check(lib.h2mi_fr_powers_dev(pw.ptr, n, s_m.ctypes.data, None), "powers")
+        p._g_dev = DevBuf(n * 64)
+        check(lib.h2mi_g1_fixed_base_mul_dev(pw.ptr, n, p._g_dev.ptr, None), "g")
+        # L_i(s) = (1/n) sum_j s^j omega^(-ij): inverse NTT of the powers vector
+        w_inv = F.fr_to_mont_limbs(F.fr_inv(F.omega_for(k)))
+        n_inv = F.fr_to_mont_limbs(F.fr_inv(n))
+        check(lib.h2mi_ntt_bn254_fr_dev(pw.ptr, k, w_inv.ctypes.data, None, n_inv.ctypes.data, None), "lagrange scalars")
+        p._gl_dev = DevBuf(n * 64)
+        check(lib.h2mi_g1_fixed_base_mul_dev(pw.ptr, n, p._gl_dev.ptr, None), "g_lagrange")
+        check(lib.h2mi_sync(), "sync")
+        pw.free()
+        p._register()
+        return p
+
+    @classmethod
+    def from_bases(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray = None) -> "ParamsKZG":
+        p = cls(k)
+        assert len(g) == p.n
+        p._g_dev = DevBuf.from_numpy(np.ascontiguousarray(g, dtype=np.uint64))
+        if g_lagrange is not None:
+            p._gl_dev = DevBuf.from_numpy(np.ascontiguousarray(g_lagrange, dtype=np.uint64))
+        p._register()
+        return p
+
+    def _register(self):
+        h = C.c_uint64()
+        check(lib.h2mi_bases_register_dev(self._g_dev.ptr, self.n, C.byref(h)), "register g")
+        self.g_handle = h.value
+        if self._gl_dev is not None:
+            h2 = C.c_uint64()
+            check(lib.h2mi_bases_register_dev(self._gl_dev.ptr, self.n, C.byref(h2)), "register g_lagrange")
+            self.g_lagrange_handle = h2.value
+
+    def get_g(self) -> np.ndarray:
+        return self._g_dev.to_numpy(shape=(self.n, 8))
+
+    def get_g_lagrange(self) -> np.ndarray:
+        return self._gl_dev.to_numpy(shape=(self.n, 8))
+
+    def _commit(self, handle, poly: np.ndarray) -> np.ndarray:
+        poly = np.ascontiguousarray(poly, dtype=np.uint64)
+        if len(poly) > self.n:
+            raise AssertionError("polynomial longer than the SRS")
+        out = np.zeros(12, dtype=np.uint64)
+        check(lib.h2mi_msm_bn254_g1(handle, None, poly.ctypes.data, len(poly), out.ctypes.data), "commit")
+        return out
+
+    def commit(self, poly_coeff: np.ndarray) -> np.ndarray:
+        return self._commit(self.g_handle, poly_coeff)
+
+    def commit_lagrange(self, poly_evals: np.ndarray) -> np.ndarray:
+        return self._commit(self.g_lagrange_handle, poly_evals)
+
+    def commit_dev(self, d_poly: DevBuf, d_out: DevBuf, n=None, lagrange=False, stream=None, out_offset=0):
+        h = self.g_lagrange_handle if lagrange else self.g_handle
+        check(lib.h2mi_msm_bn254_g1_dev(h, d_poly.ptr, self.n if n is None else n, d_out.ptr + out_offset, stream), "commit_dev")
+
+    def release(self):
+        for h in (self.g_handle, self.g_lagrange_handle):
+            if h:
+                lib.h2mi_bases_release(h)
+        self.g_handle = self.g_lagrange_handle = None
+        for b in (self._g_dev, self._gl_dev):
+            if b is not None:
+                b.free()

@@ -1,0 +1,132 @@
+/* h2mi.h — C ABI of libh2mi.so: BN254 MSM + NTT backend for AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary for the hot path of the Halo2/KZG prover that DCMMC/halo2-scaffold drives through
+ * create_proof() (reference examples/standard_plonk.rs:41-49, src/scaffold.rs:191-199,322-331).  The
+ * reference itself has no FFI seam; the seam is Cargo's [patch] of its halo2_proofs dependency
+ * (reference Cargo.toml:13,16), whose arithmetic::{best_multiexp, best_fft}, poly::EvaluationDomain and
+ * poly::kzg::commitment::ParamsKZG call the functions below (binding shown in INTEGRATION.md).
+ *
+ * Data layouts are those of halo2curves::bn256 (reference src/scaffold.rs:14):
+ *   Fr, Fq    4 x uint64 little-endian limbs, MONTGOMERY form (R = 2^256), fully reduced
+ *   G1Affine  {x, y} = 8 x uint64; the identity is (0, 0)
+ *   G1        {x, y, z} = 12 x uint64 Jacobian (x/z^2, y/z^3); the identity has z = 0
+ *
+ * Conventions: every function returns H2MI_OK (0) or a negative H2MI_E* code; h2mi_strerror() names
+ * it.  No C++ exception crosses this boundary.  Pointers named d_* are DEVICE pointers (HBM of the
+ * process's GPU); all others are host pointers owned by the caller for the duration of the call.
+ * One process drives one GPU (h2mi_init picks it); multi-GPU jobs run one process per GPU and combine
+ * the 96-byte partial MSM results themselves (all-gather + h2mi_g1_sum_jacobian).
+ * Calls are serialised by an internal mutex, so any thread may call.
+ * There is NO CPU fallback: without a usable GPU every compute entry point returns H2MI_ENODEV.
+ */
+#ifndef H2MI_H
+#define H2MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2MI_OK 0
+#define H2MI_EINVAL (-1)   /* bad argument (null pointer, size 0 where not allowed, log_n out of range) */
+#define H2MI_ENODEV (-2)   /* no usable GPU / h2mi_init not called                                      */
+#define H2MI_ENOMEM (-3)   /* device or host allocation failed                                          */
+#define H2MI_EHIP (-4)     /* a HIP runtime call or kernel launch failed                                */
+#define H2MI_EHANDLE (-5)  /* unknown or released bases handle                                          */
+#define H2MI_ERANGE (-6)   /* n larger than the registered base count / unsupported size                */
+
+#define H2MI_MAX_LOG_N 27  /* largest NTT the device path accepts (2^27 x 32 B = 4 GiB per buffer)       */
+
+typedef void* h2mi_stream_t; /* a hipStream_t, or NULL for the library's own stream */
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+/* Select GPU `device` (ordinal visible to this process) and create the library's stream.  Idempotent
+ * for the same device.  Replaces nothing in the reference (which has no device); the Rust shim calls
+ * it once from a `std::sync::Once`. */
+int h2mi_init(int device);
+void h2mi_shutdown(void);
+const char* h2mi_strerror(int code);
+const char* h2mi_version(void);
+
+/* ---- device memory (so a host can keep vectors resident between calls) ---------- */
+int h2mi_malloc(size_t bytes, void** d_ptr);
+int h2mi_free(void* d_ptr);
+int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
+int h2mi_sync(void); /* wait for all work queued on the library's stream */
+
+/* ---- bases (the KZG SRS): ParamsKZG::{g, g_lagrange}, SURVEY.md 8a row a5 ------------------------
+ * Replaces the `&params.g` / `&params.g_lagrange` slices that ParamsKZG::commit / commit_lagrange pass
+ * to best_multiexp (reached from reference examples/standard_plonk.rs:33,34,41-49).  Registration
+ * copies the n affine points to HBM and builds the per-window multiples table 2^(c*w) * P_i (all
+ * windows then share one bucket set), once; commits afterwards move only scalars. */
+int h2mi_bases_register(const uint64_t* bases /* n*8 limbs */, size_t n, uint64_t* handle_out);
+int h2mi_bases_register_dev(const void* d_bases /* n*64 B */, size_t n, uint64_t* handle_out);
+int h2mi_bases_release(uint64_t handle);
+/* window bits c, window count W, bucket count, registered n */
+int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* buckets, uint64_t* n);
+
+/* ---- MSM: halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ---------------------
+ * Replaces best_multiexp for C = bn256::G1Affine; computes sum_i s_i * P_i over
+ * the first n registered bases.  Scalars are Fr values exactly as they sit in memory (Montgomery).
+ * The result is a Jacobian representative of the exact group element (the caller batch-normalises
+ * before hashing, as create_proof does); identity is returned as (0, R, 0) = G1::identity().
+ * The reference asserts coeffs.len() == bases.len(); here n > registered n returns H2MI_ERANGE. */
+int h2mi_msm_bn254_g1(uint64_t handle_or_0, const uint64_t* bases_or_null /* used when handle==0 */,
+                      const uint64_t* scalars /* n*4 limbs */, size_t n, uint64_t out_jacobian[12]);
+/* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
+int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
+                          h2mi_stream_t stream);
+/* number of bucket insertions (non-zero signed digits) the last MSM on this handle performed, and the
+ * running-sum reduction adds — the numerator of "G1-adds/s" (SURVEY.md 8d).  Synchronises. */
+int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds);
+/* sum of k Jacobian points (k*12 limbs, host) -> one Jacobian point: the combine step of the sliced
+ * multi-GPU MSM (the fold `results.iter().fold(identity, |a, b| a + b)` of best_multiexp). */
+int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]);
+/* batch Jacobian -> affine (G1::batch_normalize, used by create_proof before transcript writes) */
+int h2mi_g1_batch_normalize(const uint64_t* jac /* k*12 */, size_t k, uint64_t* affine_out /* k*8 */);
+
+/* ---- NTT: halo2_proofs::arithmetic::best_fft(a, omega, log_n) ------------------------------------
+ * Replaces best_fft for G = bn256::Fr: in-place DFT out[i] = sum_j a[j] *
+ * omega^(i*j), natural order in and out.  The reference asserts a.len() == 1 << log_n; the caller
+ * passes log_n and the buffer must hold 2^log_n elements.  log_n in [0, H2MI_MAX_LOG_N]. */
+int h2mi_ntt_bn254_fr(uint64_t* a /* n*4 limbs, in place */, const uint64_t omega[4], uint32_t log_n);
+/* EvaluationDomain helpers fused into the first / last pass:
+ *   a[i] *= pre_scale_base^i  (distribute_powers_zeta with base = g_coset), then the DFT,
+ *   then a[i] *= post_scale   (the ifft divisor n^-1).  Either pointer may be NULL. */
+int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4],
+                          const uint64_t* pre_scale_base_or_null, const uint64_t* post_scale_or_null);
+/* device-resident form, asynchronous on `stream`; omega / scale constants are host pointers. */
+int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4],
+                          const uint64_t* pre_scale_base_or_null, const uint64_t* post_scale_or_null,
+                          h2mi_stream_t stream);
+/* a[i] *= base^i on the device (EvaluationDomain::distribute_powers_zeta after an inverse coset NTT) */
+int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const uint64_t* post_scale_or_null,
+                             h2mi_stream_t stream);
+
+/* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
+ * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
+ * generator (1, 2) with on-device normalisation. */
+int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, h2mi_stream_t stream);
+/* out[i] = base^i for i < n (the powers-of-s vector of ParamsKZG::setup), Montgomery in and out */
+int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_stream_t stream);
+
+/* ---- profiling: per-kernel device time measured with HIP events on the launching stream ---------- */
+int h2mi_profile_enable(int on);         /* 1 = record events around every kernel launch */
+int h2mi_profile_reset(void);
+/* total milliseconds and launch count for kernels whose name starts with `prefix`; synchronises */
+int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches);
+
+/* ---- test hooks (elementwise device arithmetic, used by the parity tests only) ------------------- */
+int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,4=inv,5=from_mont,6=to_mont,7=neg,8=dbl*/,
+                      const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* op 0: out = P + Q (affine inputs, via XYZZ mixed add); 1: 2P; 2: P + Q via XYZZ full add; output Jacobian (12 limbs each) */
+int h2mi_dbg_g1_op(int op, const uint64_t* p_affine, const uint64_t* q_affine, uint64_t* out_jac, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2MI_H */

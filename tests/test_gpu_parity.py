@@ -1,0 +1,230 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Bit-exact for every field-element output; MSM outputs are compared as group elements (the ABI returns
+a Jacobian representative, as best_multiexp does; the oracle normalises it to affine).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as o
+
+pytestmark = pytest.mark.gpu
+
+EDGE = [0, 1, 2, o.R - 1, o.R - 2, (1 << 253) % o.R, 0xFFFFFFFF, 1 << 32, (1 << 64) - 1, 1 << 64, (o.R - 1) // 2]
+
+
+def _field_vals(mod, n, seed):
+    rng = np.random.default_rng(seed)
+    vals = [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(n)]
+    edge = [e % mod for e in EDGE] + [mod - 1, mod - 2]
+    return edge + vals
+
+
+@pytest.mark.parametrize("field,mod", [(0, o.Q), (1, o.R)])
+def test_field_ops_bit_exact(gpu, field, mod):
+    a = _field_vals(mod, 500, 1)
+    b = list(reversed(_field_vals(mod, 500, 2)))
+    n = len(a)
+    A, B = o.pack(a, mod), o.pack(b, mod)
+    out = np.zeros((n, 4), dtype=np.uint64)
+
+    def run(op, second=True):
+        rc = gpu.lib.h2mi_dbg_field_op(field, op, A.ctypes.data, B.ctypes.data if second else None, out.ctypes.data, n)
+        assert rc == 0, gpu.lib.h2mi_strerror(rc)
+        return out.copy()
+
+    assert o.unpack(run(0), mod) == [x * y % mod for x, y in zip(a, b)]
+    assert o.unpack(run(1), mod) == [(x + y) % mod for x, y in zip(a, b)]
+    assert o.unpack(run(2), mod) == [(x - y) % mod for x, y in zip(a, b)]
+    assert o.unpack(run(3, False), mod) == [x * x % mod for x in a]
+    assert o.unpack(run(7, False), mod) == [(-x) % mod for x in a]
+    assert o.unpack(run(8, False), mod) == [2 * x % mod for x in a]
+    assert o.unpack(run(4, False), mod) == [pow(x, -1, mod) if x else 0 for x in a]
+    # from_mont: Montgomery limbs -> canonical limbs ; to_mont is its inverse
+    assert o.unpack(run(5, False)) == a
+    can = o.pack(a)
+    rc = gpu.lib.h2mi_dbg_field_op(field, 6, can.ctypes.data, None, out.ctypes.data, n)
+    assert rc == 0
+    assert np.array_equal(out, A)
+    # outputs are fully reduced
+    assert all(v < mod for v in o.unpack(run(0)))
+
+
+def _points(n, seed):
+    rng = np.random.default_rng(seed)
+    return [o.g1_mul(int(rng.integers(1, 1 << 62)), o.G1_GEN) for _ in range(n)]
+
+
+def test_g1_ops(gpu):
+    P = _points(40, 3)
+    Qs = _points(40, 4)
+    # special cases: identity operands, P + P, P + (-P)
+    P += [None, P[0], P[1], None, P[2]]
+    Qs += [Qs[0], None, P[1], None, o.g1_neg(P[2])]
+    n = len(P)
+    A, B = o.pack_points(P), o.pack_points(Qs)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    for op, ref in [(0, lambda p, q: o.g1_add(p, q)), (1, lambda p, q: o.g1_double(p)), (2, lambda p, q: o.g1_add(p, q))]:
+        rc = gpu.lib.h2mi_dbg_g1_op(op, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+        assert rc == 0, gpu.lib.h2mi_strerror(rc)
+        got = [o.unpack_jacobian(out[i]) for i in range(n)]
+        want = [ref(p, q) for p, q in zip(P, Qs)]
+        assert got == want, op
+    # batch_normalize and the multi-GPU fold
+    aff = np.zeros((n, 8), dtype=np.uint64)
+    assert gpu.lib.h2mi_g1_batch_normalize(out.ctypes.data, n, aff.ctypes.data) == 0
+    assert o.unpack_points(aff) == want
+    s = np.zeros(12, dtype=np.uint64)
+    assert gpu.lib.h2mi_g1_sum_jacobian(out.ctypes.data, n, s.ctypes.data) == 0
+    acc = None
+    for w in want:
+        acc = o.g1_add(acc, w)
+    assert o.unpack_jacobian(s) == acc
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13])
+def test_ntt_matches_oracle(gpu, log_n):
+    n = 1 << log_n
+    a = o.random_field_limbs(n, o.SEED + 1)
+    vals = o.unpack(a, o.R)
+    w = o.omega_for(log_n)
+    wl = o.pack([w], o.R)[0]
+    got = a.copy()
+    gpu.best_fft(got, wl, log_n)
+    assert o.unpack(got, o.R) == o.ntt(vals, w)
+    # inverse with fused n^-1, coset pre-scale
+    winv = o.pack([pow(w, -1, o.R)], o.R)[0]
+    ninv = o.pack([pow(n, -1, o.R)], o.R)[0]
+    back = got.copy()
+    rc = gpu.lib.h2mi_ntt_ext_bn254_fr(back.ctypes.data, log_n, winv.ctypes.data, None, ninv.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(back, a)
+    zeta = o.pack([o.FR_ZETA], o.R)[0]
+    cos = a.copy()
+    rc = gpu.lib.h2mi_ntt_ext_bn254_fr(cos.ctypes.data, log_n, wl.ctypes.data, zeta.ctypes.data, None)
+    assert rc == 0
+    assert o.unpack(cos, o.R) == o.ntt_ext(vals, w, pre_base=o.FR_ZETA)
+
+
+@pytest.mark.parametrize("log_n", [16, 20, 21, 22])
+def test_ntt_large_properties(gpu, log_n):
+    """size-independent properties at BASELINE sizes: delta -> ones, round trip, linearity spot-check."""
+    n = 1 << log_n
+    w = o.omega_for(log_n)
+    wl = o.pack([w], o.R)[0]
+    one = o.pack([1], o.R)[0]
+    delta = np.zeros((n, 4), dtype=np.uint64)
+    delta[0] = one
+    gpu.best_fft(delta, wl, log_n)
+    assert (delta == one).all()
+    # shifted delta: NTT(e_1)[i] = omega^i ; check a few entries
+    e1 = np.zeros((n, 4), dtype=np.uint64)
+    e1[1] = one
+    gpu.best_fft(e1, wl, log_n)
+    for i in [0, 1, 2, 12345 % n, n // 2, n - 1]:
+        assert o.unpack(e1[i : i + 1], o.R)[0] == pow(w, i, o.R)
+    a = o.random_field_limbs(n, o.SEED + 1)
+    b = a.copy()
+    gpu.best_fft(b, wl, log_n)
+    # X[0] = sum a[j]; X[n/2] = sum (-1)^j a[j]
+    vals = o.unpack(a, o.R)
+    assert o.unpack(b[0:1], o.R)[0] == sum(vals) % o.R
+    assert o.unpack(b[n // 2 : n // 2 + 1], o.R)[0] == (sum(vals[0::2]) - sum(vals[1::2])) % o.R
+    winv = o.pack([pow(w, -1, o.R)], o.R)[0]
+    ninv = o.pack([pow(n, -1, o.R)], o.R)[0]
+    rc = gpu.lib.h2mi_ntt_ext_bn254_fr(b.ctypes.data, log_n, winv.ctypes.data, None, ninv.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(a, b)
+
+
+def test_domain_matches_oracle(gpu):
+    k, j = 6, 3
+    d = gpu.EvaluationDomain(j, k)
+    od = o.Domain(k, j)
+    assert d.extended_k == od.extended_k
+    a = o.random_field_limbs(d.n, 7)
+    vals = o.unpack(a, o.R)
+    assert o.unpack(d.lagrange_to_coeff(a), o.R) == od.lagrange_to_coeff(vals)
+    ext = d.coeff_to_extended(a)
+    assert o.unpack(ext, o.R) == od.coeff_to_extended(vals)
+    back = d.extended_to_coeff(ext)
+    assert o.unpack(back, o.R) == od.extended_to_coeff(od.coeff_to_extended(vals))
+    assert o.unpack(back, o.R)[: d.n] == vals
+
+
+def _msm_case(gpu, scalars_limbs, points):
+    got = gpu.best_multiexp(scalars_limbs, o.pack_points(points))
+    want = o.msm_naive(o.unpack(scalars_limbs, o.R), points)
+    assert o.unpack_jacobian(got) == want
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 64, 257, 1024])
+def test_msm_matches_oracle(gpu, n):
+    pts = _points(n, 10 + n)
+    _msm_case(gpu, o.random_field_limbs(n, o.SEED), pts)
+
+
+def test_msm_edge_cases(gpu):
+    n = 96
+    pts = _points(n, 5)
+    one = o.pack([1], o.R)[0]
+    # all-zero scalars -> identity (0, R, 0)
+    z = np.zeros((n, 4), dtype=np.uint64)
+    out = gpu.best_multiexp(z, o.pack_points(pts))
+    assert o.unpack_jacobian(out) is None
+    # all ones -> sum of points ; r-1 -> minus sum
+    ones = np.tile(one, (n, 1))
+    _msm_case(gpu, ones, pts)
+    _msm_case(gpu, np.tile(o.pack([o.R - 1], o.R)[0], (n, 1)), pts)
+    # identity bases, duplicate bases (P + P inside one bucket), P and -P with equal scalars
+    pts2 = list(pts)
+    pts2[3] = None
+    pts2[5] = pts2[4]
+    pts2[7] = o.g1_neg(pts2[6])
+    s = o.random_field_limbs(n, 99)
+    s[5] = s[4]
+    s[7] = s[6]
+    _msm_case(gpu, s, pts2)
+    _msm_case(gpu, ones, [o.G1_GEN] * n)  # n * G: every addition in the hot bucket is a doubling case
+    # witness-like distribution: hot buckets 0/1
+    _msm_case(gpu, o.witness_like_limbs(n, 3), pts)
+    # digit carry chain: scalars with all-ones windows
+    carry = o.pack([(1 << 253) - 1, (1 << 200) - 1, 0x7FFF8000_7FFF8000, 0x8000, 0x8001, 0xFFFF], o.R)
+    _msm_case(gpu, carry, pts[:6])
+
+
+def test_length_mismatch_raises(gpu):
+    with pytest.raises(AssertionError):
+        gpu.best_multiexp(np.zeros((3, 4), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64))
+    with pytest.raises(AssertionError):
+        gpu.best_fft(np.zeros((3, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), 2)
+
+
+@pytest.mark.parametrize("k", [4, 8, 12])
+def test_srs_commit_consistency(gpu, k):
+    """commit(f; g) == commit_lagrange(NTT(f); g_lagrange): cross-checks MSM, NTT, SRS generation."""
+    s = 0x1234567 + k
+    params = gpu.ParamsKZG.setup(k, s)
+    n = 1 << k
+    if k <= 8:
+        g, gl = params.get_g(), params.get_g_lagrange()
+        og = o.unpack_points(g)
+        assert og[0] == o.G1_GEN and og[1] == o.g1_mul(s, o.G1_GEN) and og[n - 1] == o.g1_mul(pow(s, n - 1, o.R), o.G1_GEN)
+        if k <= 4:
+            eg, egl = o.srs(k, s)
+            assert og == eg and o.unpack_points(gl) == egl
+    coeffs = o.random_field_limbs(n, 5)
+    d = gpu.EvaluationDomain(3, k)
+    evals = d.coeff_to_lagrange(coeffs)
+    c1 = o.unpack_jacobian(params.commit(coeffs))
+    c2 = o.unpack_jacobian(params.commit_lagrange(evals))
+    assert c1 == c2 and c1 is not None
+    # f(s) * G, evaluated by Horner on the host for small k
+    if k <= 8:
+        fs = 0
+        for c in reversed(o.unpack(coeffs, o.R)):
+            fs = (fs * s + c) % o.R
+        assert c1 == o.g1_mul(fs, o.G1_GEN)
+    params.release()
