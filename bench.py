@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — prover hot-path replay of a 2^k-row StandardPlonk proof on N MI355X GPUs.
+
+A "step" is one proof's worth of hot-path work: 11 MSM(n) over BN254 G1 +
+6 iNTT(n) + 6 coset-NTT(2n) + 1 coset-iNTT(2n) over the BN254 scalar field, on synthetic vectors that
+are already resident in HBM when the timed region starts.  It is NOT create_proof(): no Rust prover is
+linked (none can be built here), so gate evaluation / transcript / witness generation are not timed.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; the total work is fixed ("strong" scaling): every rank owns a contiguous
+1/N slice of both base sets, runs each MSM on its slice and the 96-byte partial points are combined by
+an RCCL all-gather + fold; NTTs are replayed on every rank (NTT is single-GPU by design).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--k", type=int, default=20, help="log2 rows (BASELINE.json metric is quoted at k=20)")
+    ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 size of the CPU baseline sample MSM/NTT")
+    args = ap.parse_args()
+
+    import torch  # first: the HIP runtime torch loads is the one libh2mi.so then shares
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import _load_pkg
+
+    h2 = _load_pkg.load()
+    from halo2_scaffold_amd import replay as rp
+    from halo2_scaffold_amd.dist import PartialPointCombiner
+
+    h2.init(local_rank)
+    lib = h2.lib
+    combine = PartialPointCombiner(device=torch.device("cuda", local_rank)) if world > 1 else None
+    R = rp.StandardPlonkReplay(args.k, rank=rank, world=world, dist=args.dist, combine=combine)
+    n = R.n
+
+    def sync_all():
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        R.step()
+        R.finish()
+
+    # G1 additions one step performs (bucket insertions + reduction adds), summed over the 11 MSMs
+    import ctypes as C
+
+    adds_local = 0
+    for lagrange, buf in [(True, R.cols[0]), (False, R.random_poly)]:
+        handle = R.params.g_lagrange_handle if lagrange else R.params.g_handle
+        h2._lib.check(lib.h2mi_msm_bn254_g1_dev(handle, buf.ptr + R.lo * 32, R.n_local, R.out.ptr, None), "msm")
+        ba, ra = C.c_uint64(), C.c_uint64()
+        h2._lib.check(lib.h2mi_msm_last_stats(handle, C.byref(ba), C.byref(ra)), "stats")
+        # uniform columns: every MSM of the step has the same expected insertion count
+        adds_local += (ba.value + ra.value) * (6 if lagrange else 5)
+    adds = adds_local
+    if dist is not None:
+        t = torch.tensor([adds_local], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t)
+        adds = int(t.item())
+
+    lib.h2mi_profile_reset()
+    lib.h2mi_profile_filter(b"k_msm_accum")
+    lib.h2mi_profile_enable(1)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        R.step()
+        R.finish()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    lib.h2mi_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tot_ms, cnt = C.c_double(), C.c_uint64()
+    lib.h2mi_profile_query(b"k_msm_accum", C.byref(tot_ms), C.byref(cnt))
+    accum_ms = tot_ms.value / max(cnt.value, 1)
+
+    # per-phase device time (untimed extra pass, all kernels bracketed by events)
+    lib.h2mi_profile_reset()
+    lib.h2mi_profile_filter(b"")
+    lib.h2mi_profile_enable(1)
+    R.step()
+    R.finish()
+    lib.h2mi_profile_enable(0)
+    phases = {}
+    for name in ["k_msm_digits", "hipcub_radix_sort", "k_msm_bounds", "k_msm_scan", "k_msm_accum", "k_msm_fold", "k_msm_rowcol", "k_msm_weighted", "k_msm_final",
+                 "k_ntt_pass_col", "k_ntt_pass_row", "k_scale_powers"]:
+        lib.h2mi_profile_query(name.encode(), C.byref(tot_ms), C.byref(cnt))
+        phases[name] = {"ms": round(tot_ms.value, 4), "launches": cnt.value}
+    lib.h2mi_profile_reset()
+    msm_ms = sum(v["ms"] for k, v in phases.items() if k.startswith("k_msm") or k.startswith("hipcub"))
+    ntt_ms = sum(v["ms"] for k, v in phases.items() if k.startswith("k_ntt") or k.startswith("k_scale"))
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = adds / (ms_per_step * 1e-3)
+    c, W, nb, nreg = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    lib.h2mi_bases_info(R.params.g_handle, C.byref(c), C.byref(W), C.byref(nb), C.byref(nreg))
+
+    algo_bytes = 96 * R.n_local  # 32 B scalar + 64 B affine base per pair, read once
+    achieved = algo_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and world == 1 and args.k == 20:
+        try:
+            traffic = json.load(open(tpath)).get("k_msm_accum_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "kernel": "k_msm_accum",
+        "bound": "hbm",
+        "achieved": round(achieved, 3),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "avg_launch_ms": round(accum_ms, 4),
+        "note": "MSM is 254-bit integer-multiply bound (v_mad_u64_u32), not HBM bound; see DESIGN.md",
+    }
+
+    out = {
+        "metric": "create_proof() wall-clock + MSM G1-adds/s at k=20 standard_plonk, 1/2/4/8 GPU",
+        "value": round(value, 1),
+        "unit": "G1-adds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32x8 (254-bit Montgomery integers)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"standard_plonk hot-path replay k={args.k}: 11 MSM(2^{args.k}) + 6 iNTT(2^{args.k}) + 6 coset-NTT(2^{args.k + 1}) + 1 coset-iNTT(2^{args.k + 1})",
+            "k": args.k,
+            "scalar_distribution": args.dist,
+            "msm_window_bits": c.value,
+            "msm_windows": W.value,
+            "msm_buckets": nb.value,
+            "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
+            "what_is_timed": "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation",
+        },
+        "g1_adds_per_step": adds,
+        "msm_pairs_per_s": round(rp.MSM_PER_PROOF * n / (ms_per_step * 1e-3), 1),
+        "device_ms_per_step": {"msm": round(msm_ms, 3), "ntt": round(ntt_ms, 3)},
+        "kernels": phases,
+        "roofline": roofline,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(R, args, n)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def host_threads():
+    """threads this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box hands
+    each job a share of the host, e.g. 16 of 256 hardware threads)."""
+    t = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            t = min(t, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(t, 64))
+
+
+def cpu_baseline(R, args, n):
+    """the C restatement of best_multiexp / best_fft (oracle/h2ref.c) timed on this host's cores."""
+    import math
+
+    import numpy as np
+
+    from oracle import cref
+
+    threads = host_threads()
+    ls = args.cpu_sample_log if args.cpu_sample_log is not None else min(args.k, 20)
+    ns = 1 << ls
+    scal = R.cols[0].to_numpy(shape=(n, 4))[:ns].copy()
+    bases = R.params.get_g_lagrange()[:ns].copy()
+    cref.msm(scal[:1024], bases[:1024], threads)  # warm the thread pool / page in
+    t0 = time.perf_counter()
+    cref.msm(scal, bases, threads)
+    t_msm = time.perf_counter() - t0
+    # G1 additions of the reference algorithm on this sample (per thread chunk: window c = ceil(ln chunk))
+    chunk = max(ns // threads, 1) if ns > threads else ns
+    cc = 1 if chunk < 4 else 3 if chunk < 32 else math.ceil(math.log(chunk))
+    segments = 256 // cc + 1
+    nchunks = math.ceil(ns / chunk)
+    used_segments = math.ceil(254 / cc)
+    cpu_adds = ns * used_segments * (1 - 2.0 ** -cc) + nchunks * segments * 2 * ((1 << cc) - 1)
+    from halo2_scaffold_amd import field as F
+
+    w = F.fr_to_mont_limbs(F.omega_for(ls))
+    a = scal.copy()
+    t0 = time.perf_counter()
+    cref.ntt(a, w, ls, threads)
+    t_ntt = time.perf_counter() - t0
+    with open("/proc/cpuinfo") as f:
+        model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    return {
+        "value": round(cpu_adds / t_msm, 1),
+        "unit": "G1-adds/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"1 MSM(2^{ls}) + 1 NTT(2^{ls}) of the same synthetic vectors, C restatement of best_multiexp/best_fft "
+                  f"(oracle/h2ref.c), {threads} threads, window c={cc}",
+        "cpu_model": model,
+        "msm_seconds": round(t_msm, 4),
+        "msm_pairs_per_s": round(ns / t_msm, 1),
+        "ntt_seconds": round(t_ntt, 4),
+        "projected_step_seconds": round(11 * t_msm * (n / ns) + (6 + 2 * 7) * t_ntt * (n / ns), 3),
+        "label": "restated CPU baseline (C), not the Rust binary",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ def _load():
         "h2mi_memcpy_h2d": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_d2h": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_d2d": ([vp, vp, sz], C.c_int),
+        "h2mi_memset_zero": ([vp, sz], C.c_int),
         "h2mi_sync": ([], C.c_int),
         "h2mi_bases_register": ([vp, sz, u64p], C.c_int),
         "h2mi_bases_register_dev": ([vp, sz, u64p], C.c_int),
@@ -54,6 +55,7 @@ def _load():
         "h2mi_g1_fixed_base_mul_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_fr_powers_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_profile_enable": ([C.c_int], C.c_int),
+        "h2mi_profile_filter": ([C.c_char_p], C.c_int),
         "h2mi_profile_reset": ([], C.c_int),
         "h2mi_profile_query": ([C.c_char_p, C.POINTER(C.c_double), u64p], C.c_int),
         "h2mi_dbg_field_op": ([C.c_int, C.c_int, vp, vp, vp, sz], C.c_int),

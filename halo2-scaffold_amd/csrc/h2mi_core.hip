@@ -205,6 +205,11 @@ int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
   H2_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
   return H2MI_OK;
 }
+int h2mi_memset_zero(void* d_ptr, size_t bytes) {
+  H2_REQUIRE_INIT();
+  H2_HIP(hipMemsetAsync(d_ptr, 0, bytes, ctx().stream));
+  return H2MI_OK;
+}
 int h2mi_sync(void) {
   H2_REQUIRE_INIT();
   H2_HIP(hipStreamSynchronize(ctx().stream));
@@ -214,6 +219,11 @@ int h2mi_sync(void) {
 int h2mi_profile_enable(int on) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   ctx().profiling = on != 0;
+  return H2MI_OK;
+}
+int h2mi_profile_filter(const char* prefix) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  ctx().prof_filter = prefix ? prefix : "";
   return H2MI_OK;
 }
 int h2mi_profile_reset(void) {

@@ -24,6 +24,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   std::recursive_mutex mu;
   bool profiling = false;
+  std::string prof_filter;
   std::vector<ProfRec> prof;
   char last_err[256] = {0};
 };
@@ -52,12 +53,17 @@ void note_hip_error(hipError_t e, const char* file, int line);
 // stream it is launched on (device time of exactly this launch); otherwise a plain launch.
 void prof_begin(const char* name, hipStream_t s);
 void prof_end(hipStream_t s);
+inline bool prof_on(const char* name) {
+  Ctx& c = ctx();
+  return c.profiling && (c.prof_filter.empty() || strncmp(name, c.prof_filter.c_str(), c.prof_filter.size()) == 0);
+}
 
 #define H2_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                       \
   do {                                                                                 \
-    if (::h2::ctx().profiling) ::h2::prof_begin(name, stream);                         \
+    const bool prof_ = ::h2::prof_on(name);                                            \
+    if (prof_) ::h2::prof_begin(name, stream);                                         \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__);   \
-    if (::h2::ctx().profiling) ::h2::prof_end(stream);                                 \
+    if (prof_) ::h2::prof_end(stream);                                                 \
     H2_HIP(hipGetLastError());                                                         \
   } while (0)
 

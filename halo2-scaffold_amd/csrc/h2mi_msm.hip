@@ -9,7 +9,9 @@
 //    w (W x n x 64 B; 1 GiB at n = 2^20, c = 16 — HBM is 288 GB).  All windows then feed ONE set of
 //    2^(c-1) buckets, so there is no per-window reduction and no c-doubling Horner chain;
 //  * scalars: Montgomery -> canonical, signed c-bit digits (halves the bucket count), zero digits skipped;
-//  * (digit, point) pairs are counting-sorted by bucket (histogram, scan, scatter);
+//  * (bucket, point) pairs are radix-sorted by bucket id (stable, so the addition order — and with it
+//    every output bit — is reproducible); global atomics are avoided: on gfx950 a device-scope atomic is a
+//    64-B memory-side transaction (~24 G/s measured), 10x slower than sorting;
 //  * bucket accumulation is load-balanced: a bucket's sorted run is cut into tasks of <= 64 points, one
 //    thread per task, mixed additions in XYZZ coordinates on 64-B gathered table points, so a hot
 //    bucket (witness columns full of 0/1) never serialises a wavefront; partial sums are folded by
@@ -17,6 +19,8 @@
 //  * the weighted bucket sum  sum_b (b+1) B_b  is done without long serial chains: row/column sums of
 //    the bucket matrix (LDS tree reductions), bit-decomposed weights, then <= 15 doublings.
 // All arithmetic is 254-bit integer work on v_mad_u64_u32; no MFMA (not a dense contraction).
+#include <hipcub/hipcub.hpp>
+
 #include <map>
 
 #include "g1.cuh"
@@ -31,11 +35,12 @@ struct Bases {
   size_t n = 0;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each
-  uint16_t* digits = nullptr;   // [W][n]
-  uint32_t* entries = nullptr;  // sorted (sign<<31 | w*n+i)
+  uint16_t* keys[2] = {nullptr, nullptr};     // [W][n] bucket id per (window, scalar); 0xFFFF = zero digit
+  uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i ; [1] holds the sorted order
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
-  uint32_t* cursor = nullptr;   // nb
   uint32_t* np[3] = {nullptr, nullptr, nullptr};    // partial counts per bucket after level 0,1,2
   uint32_t* toff[3] = {nullptr, nullptr, nullptr};  // task offsets (nb+1)
   uint8_t* part[2] = {nullptr, nullptr};            // XYZZ partial buffers (ping-pong)
@@ -63,9 +68,10 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
 }
 
 // ---- per call -------------------------------------------------------------------------------------
-// signed-digit recoding: digit d_w in [-2^(c-1)+1, 2^(c-1)], stored as u16 two's complement
-// (0 = skip, v <= 0x8000 positive, v > 0x8000 negative with |d| = 0x10000 - v).
-__global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n, uint16_t* digits, uint32_t* hist, uint32_t c, uint32_t W) {
+// signed-digit recoding: digit d_w in [-2^(c-1)+1, 2^(c-1)]; emits the sort key (bucket |d|-1, or 0xFFFF
+// for a zero digit, which sorts behind every bucket) and the payload sign<<31 | table index.
+__global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n, size_t n_reg, uint16_t* keys, uint32_t* vals, uint32_t c,
+                                                     uint32_t W) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
@@ -81,33 +87,63 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n,
       raw = (uint32_t)(two >> sh) & ((1u << c) - 1);
     }
     uint32_t d = raw + carry;  // 0 .. 2^c
-    uint32_t v;
-    if (d > half) {            // negative digit d - 2^c, carry 1
-      uint32_t mag = (1u << c) - d;  // 0 .. 2^(c-1)-1
+    uint32_t mag, neg;
+    if (d > half) {  // negative digit d - 2^c, carry 1
+      mag = (1u << c) - d;  // 0 .. 2^(c-1)-1
+      neg = 1;
       carry = 1;
-      v = mag ? (0x10000u - mag) : 0;
-      if (mag) atomicAdd(&hist[mag - 1], 1u);
     } else {
+      mag = d;
+      neg = 0;
       carry = 0;
-      v = d;
-      if (d) atomicAdd(&hist[d - 1], 1u);
     }
-    digits[(size_t)w * n + i] = (uint16_t)v;
+    keys[(size_t)w * n + i] = mag ? (uint16_t)(mag - 1) : (uint16_t)0xFFFFu;
+    vals[(size_t)w * n + i] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
   }
 }
 
-// single-block exclusive scan of f(count) = ceil(count / chunk) over nb entries (nb multiple of 1024 or
-// smaller); writes np[b] = f(count[b]) and off[0..nb] (off[nb] = total).
+// bucket boundaries in the sorted key array: off[b] = first index with key >= b, hist[b] = run length
+__global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32_t total, uint32_t nb, uint32_t* off, uint32_t* hist) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb) return;
+  uint32_t lo = 0, hi = total;  // first index with key >= b
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < b) lo = mid + 1;
+    else hi = mid;
+  }
+  off[b] = lo;
+  if (b < nb) {
+    uint32_t lo2 = lo, hi2 = total;
+    while (lo2 < hi2) {
+      uint32_t mid = (lo2 + hi2) >> 1;
+      if (keys[mid] < b + 1) lo2 = mid + 1;
+      else hi2 = mid;
+    }
+    hist[b] = lo2 - lo;
+  }
+}
+
+// single-block exclusive scan of f(count) = ceil(count / chunk) over nb entries, staged through LDS
+// (coalesced global access, padded so that a thread's contiguous run is bank-conflict free);
+// writes np[b] = f(count[b]) and off[0..nb] (off[nb] = total).
+extern __shared__ uint32_t h2_scan_smem[];
 __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* counts, uint32_t nb, uint32_t chunk, uint32_t* np, uint32_t* off) {
   __shared__ uint32_t sums[1024];
+  uint32_t* s = h2_scan_smem;
   const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < nb; i += 1024) {
+    uint32_t f = (counts[i] + chunk - 1) / chunk;
+    if (np) np[i] = f;
+    s[i + (i >> 5)] = f;
+  }
+  __syncthreads();
   const uint32_t per = (nb + 1023) / 1024;
   uint32_t b0 = tid * per, b1 = min(b0 + per, nb);
   uint32_t local = 0;
-  for (uint32_t b = b0; b < b1; b++) local += (counts[b] + chunk - 1) / chunk;
+  for (uint32_t b = b0; b < b1; b++) local += s[b + (b >> 5)];
   sums[tid] = local;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 values
   for (uint32_t d = 1; d < 1024; d <<= 1) {
     uint32_t v = (tid >= d) ? sums[tid - d] : 0;
     __syncthreads();
@@ -116,27 +152,13 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* counts, uint3
   }
   uint32_t run = sums[tid] - local;
   for (uint32_t b = b0; b < b1; b++) {
-    uint32_t f = (counts[b] + chunk - 1) / chunk;
-    if (np) np[b] = f;
-    off[b] = run;
+    uint32_t f = s[b + (b >> 5)];
+    s[b + (b >> 5)] = run;
     run += f;
   }
+  __syncthreads();
+  for (uint32_t i = tid; i < nb; i += 1024) off[i] = s[i + (i >> 5)];
   if (tid == 1023) off[nb] = sums[1023];
-}
-
-__global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* digits, size_t n, size_t n_reg, uint32_t W, const uint32_t* off,
-                                                      uint32_t* cursor, uint32_t* entries) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * W) return;
-  uint32_t w = (uint32_t)(t / n);
-  size_t i = t - (size_t)w * n;
-  uint32_t v = digits[t];
-  if (v == 0) return;
-  uint32_t neg = v > 0x8000u;
-  uint32_t mag = neg ? (0x10000u - v) : v;
-  uint32_t b = mag - 1;
-  uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
-  entries[pos] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
 }
 
 // largest b with toff[b] <= t (toff has nb+1 monotone entries, toff[nb] = total > t)
@@ -298,7 +320,8 @@ static uint32_t pick_window(size_t n) {
 }
 
 static void free_bases(Bases* B) {
-  hipFree(B->table); hipFree(B->digits); hipFree(B->entries); hipFree(B->hist); hipFree(B->off); hipFree(B->cursor);
+  hipFree(B->table); hipFree(B->keys[0]); hipFree(B->keys[1]); hipFree(B->vals[0]); hipFree(B->vals[1]); hipFree(B->sort_tmp);
+  hipFree(B->hist); hipFree(B->off);
   for (int i = 0; i < 3; i++) { hipFree(B->np[i]); hipFree(B->toff[i]); }
   hipFree(B->part[0]); hipFree(B->part[1]); hipFree(B->rc); hipFree(B->g); hipFree(B->stats);
   delete B;
@@ -329,11 +352,18 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   B->max_tasks2 = B->max_tasks1 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
-  H2_ALLOC(B->digits, nW * 2);
-  H2_ALLOC(B->entries, nW * 4);
+  for (int i = 0; i < 2; i++) {
+    H2_ALLOC(B->keys[i], nW * 2);
+    H2_ALLOC(B->vals[i], nW * 4);
+  }
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, B->keys[0], B->keys[1], B->vals[0], B->vals[1], (unsigned int)nW, 0,
+                                         16, s) != hipSuccess) {
+    free_bases(B);
+    return H2MI_EHIP;
+  }
+  H2_ALLOC(B->sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
   H2_ALLOC(B->hist, (size_t)B->nb * 4);
   H2_ALLOC(B->off, (size_t)(B->nb + 1) * 4);
-  H2_ALLOC(B->cursor, (size_t)B->nb * 4);
   for (int i = 0; i < 3; i++) {
     H2_ALLOC(B->np[i], (size_t)B->nb * 4);
     H2_ALLOC(B->toff[i], (size_t)(B->nb + 1) * 4);
@@ -345,10 +375,11 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   H2_ALLOC(B->stats, 64);
   if (hipMemcpyAsync(B->table, d_bases, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
   for (uint32_t w = 1; w < B->W; w++) {
-    if (ctx().profiling) prof_begin("k_msm_table_next", s);
+    const bool prof_ = prof_on("k_msm_table_next");
+    if (prof_) prof_begin("k_msm_table_next", s);
     hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * n * 64),
                        B->table + (size_t)w * n * 64, n, B->c);
-    if (ctx().profiling) prof_end(s);
+    if (prof_) prof_end(s);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
   uint64_t h = g_next_handle++;
@@ -359,23 +390,34 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
 
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   const uint32_t nb = B->nb, W = B->W;
-  H2_HIP(hipMemsetAsync(B->hist, 0, (size_t)nb * 4, s));
-  H2_HIP(hipMemsetAsync(B->cursor, 0, (size_t)nb * 4, s));
-  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->digits, B->hist, B->c, W);
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->hist, nb, 1u, (uint32_t*)nullptr, B->off);
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->hist, nb, S0, B->np[0], B->toff[0]);
-  H2_LAUNCH("k_msm_scatter", k_msm_scatter, ceil_div_u32(n * W, 256), 256, 0, s, (const uint16_t*)B->digits, n, B->n, W,
-            (const uint32_t*)B->off, B->cursor, B->entries);
+  const uint32_t total = (uint32_t)(n * W);
+  static bool scan_attr_set = false;
+  if (!scan_attr_set) {
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    scan_attr_set = true;
+  }
+  const size_t scan_lds = (size_t)(nb + (nb >> 5) + 32) * 4;
+  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, B->keys[0], B->vals[0], B->c, W);
+  {
+    const bool prof_ = prof_on("hipcub_radix_sort");
+    if (prof_) prof_begin("hipcub_radix_sort", s);
+    // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(B->sort_tmp, B->sort_tmp_bytes, B->keys[0], B->keys[1], B->vals[0], B->vals[1], total, 0, 16, s);
+    if (prof_) prof_end(s);
+    H2_HIP(e);
+  }
+  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)B->keys[1], total, nb, B->off, B->hist);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->hist, nb, S0, B->np[0], B->toff[0]);
   uint32_t tasks0 = (uint32_t)(n * W / S0 + nb);
-  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)B->entries, (const uint32_t*)B->off,
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)B->vals[1], (const uint32_t*)B->off,
             (const uint32_t*)B->hist, (const uint32_t*)B->toff[0], nb, (const uint8_t*)B->table, B->part[0]);
   // fold level 1: part[0] -> part[1]
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->np[0], nb, S1, B->np[1], B->toff[1]);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->np[0], nb, S1, B->np[1], B->toff[1]);
   uint32_t tasks1 = tasks0 / S1 + nb;
   H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, s, (const uint8_t*)B->part[0], (const uint32_t*)B->toff[0],
             (const uint32_t*)B->np[0], (const uint32_t*)B->toff[1], nb, B->part[1]);
   // fold level 2: part[1] -> part[0] (part[0] holds max_tasks0 >= max_tasks2 slots)
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, 0, s, (const uint32_t*)B->np[1], nb, S1, B->np[2], B->toff[2]);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->np[1], nb, S1, B->np[2], B->toff[2]);
   uint32_t tasks2 = tasks1 / S1 + nb;
   H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks2, 256), 256, 0, s, (const uint8_t*)B->part[1], (const uint32_t*)B->toff[1],
             (const uint32_t*)B->np[1], (const uint32_t*)B->toff[2], nb, B->part[0]);

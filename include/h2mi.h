@@ -56,6 +56,7 @@ int h2mi_free(void* d_ptr);
 int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
+int h2mi_memset_zero(void* d_ptr, size_t bytes); /* asynchronous on the library's stream */
 int h2mi_sync(void); /* wait for all work queued on the library's stream */
 
 /* ---- bases (the KZG SRS): ParamsKZG::{g, g_lagrange}, SURVEY.md 8a row a5 ------------------------
@@ -116,6 +117,8 @@ int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_strea
 
 /* ---- profiling: per-kernel device time measured with HIP events on the launching stream ---------- */
 int h2mi_profile_enable(int on);         /* 1 = record events around every kernel launch */
+/* restrict event recording to kernels whose name starts with `prefix` (NULL or "" = all kernels) */
+int h2mi_profile_filter(const char* prefix);
 int h2mi_profile_reset(void);
 /* total milliseconds and launch count for kernels whose name starts with `prefix`; synchronises */
 int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches);
