@@ -160,17 +160,64 @@ __device__ __forceinline__ fe fe_neg(const fe& a) {
 
 // ---- Montgomery multiplication ------------------------------------------------------------------
 // Product-scanning (column-wise) Montgomery: column k sums a[j]*b[k-j] and m[j]*MOD[k-j] into a
-// 64-bit accumulator (v_mad_u64_u32 with the running sum as its 64-bit addend) plus a carry word.
-// MOD < 2^254, so the result of the loop is < 2*MOD and one conditional subtract finishes.
-__device__ __forceinline__ void mac(uint64_t& acc, uint32_t& ov, uint32_t a, uint32_t b) {
-  // acc += a*b ; ov += carry-out
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc), "+v"(ov)
-      : "v"(a), "v"(b)
-      : "vcc");
+// 64-bit accumulator (v_mad_u64_u32 with the running sum as its 64-bit addend) plus a carry word
+// (v_addc_co_u32 on the mad's carry-out).  MOD < 2^254, so the loop result is < 2*MOD and one
+// conditional subtract finishes.  Each column's chain is ONE asm statement (fp_mac.inc).
+#include "fp_mac.inc"
+
+template <int N>
+__device__ __forceinline__ void mac_col_vv(uint64_t& acc, uint32_t& ov, const uint32_t* x, const uint32_t* y) {
+  // sum_{i<N} x[i] * y[-i]   (y walks downwards)
+  if constexpr (N == 1) mac_vv_1(acc, ov, x[0], y[0]);
+  if constexpr (N == 2) mac_vv_2(acc, ov, x[0], y[0], x[1], y[-1]);
+  if constexpr (N == 3) mac_vv_3(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2]);
+  if constexpr (N == 4) mac_vv_4(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3]);
+  if constexpr (N == 5) mac_vv_5(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4]);
+  if constexpr (N == 6) mac_vv_6(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5]);
+  if constexpr (N == 7) mac_vv_7(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6]);
+  if constexpr (N == 8)
+    mac_vv_8(acc, ov, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6], x[7], y[-7]);
 }
-__device__ __forceinline__ void mac_nc(uint64_t& acc, uint32_t a, uint32_t b) {  // no carry possible
-  acc = (uint64_t)a * b + acc;
+// sum_{i<N} m[J0+i] * MOD[K-J0-i]
+template <class F, int N, int J0, int K>
+__device__ __forceinline__ void mac_col_mod(uint64_t& acc, uint32_t& ov, const uint32_t* m) {
+  if constexpr (N == 1) mac_vs_1(acc, ov, m[J0], F::MOD[K - J0]);
+  if constexpr (N == 2) mac_vs_2(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1]);
+  if constexpr (N == 3) mac_vs_3(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2]);
+  if constexpr (N == 4)
+    mac_vs_4(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2], m[J0 + 3], F::MOD[K - J0 - 3]);
+  if constexpr (N == 5)
+    mac_vs_5(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2], m[J0 + 3], F::MOD[K - J0 - 3],
+             m[J0 + 4], F::MOD[K - J0 - 4]);
+  if constexpr (N == 6)
+    mac_vs_6(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2], m[J0 + 3], F::MOD[K - J0 - 3],
+             m[J0 + 4], F::MOD[K - J0 - 4], m[J0 + 5], F::MOD[K - J0 - 5]);
+  if constexpr (N == 7)
+    mac_vs_7(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2], m[J0 + 3], F::MOD[K - J0 - 3],
+             m[J0 + 4], F::MOD[K - J0 - 4], m[J0 + 5], F::MOD[K - J0 - 5], m[J0 + 6], F::MOD[K - J0 - 6]);
+  if constexpr (N == 8)
+    mac_vs_8(acc, ov, m[J0], F::MOD[K - J0], m[J0 + 1], F::MOD[K - J0 - 1], m[J0 + 2], F::MOD[K - J0 - 2], m[J0 + 3], F::MOD[K - J0 - 3],
+             m[J0 + 4], F::MOD[K - J0 - 4], m[J0 + 5], F::MOD[K - J0 - 5], m[J0 + 6], F::MOD[K - J0 - 6], m[J0 + 7], F::MOD[K - J0 - 7]);
+}
+
+template <class F, int K>
+__device__ __forceinline__ void mont_col_lo(uint64_t& acc, uint32_t& ov, const fe& a, const fe& b, uint32_t* m) {
+  // column K < 8: a[0..K]*b[K..0], m[0..K-1]*MOD[K..1], then m[K] and m[K]*MOD[0]
+  mac_col_vv<K + 1>(acc, ov, &a.v[0], &b.v[K]);
+  if constexpr (K > 0) mac_col_mod<F, K, 0, K>(acc, ov, m);
+  m[K] = (uint32_t)acc * F::INV;
+  mac_col_mod<F, 1, K, K>(acc, ov, m);  // low word becomes 0
+  acc = (acc >> 32) | ((uint64_t)ov << 32);
+  ov = 0;
+}
+template <class F, int K>
+__device__ __forceinline__ void mont_col_hi(uint64_t& acc, uint32_t& ov, const fe& a, const fe& b, const uint32_t* m, uint32_t* t) {
+  // column K in 8..14: a[K-7..7]*b[7..K-7], m[K-7..7]*MOD[7..K-7]
+  mac_col_vv<15 - K>(acc, ov, &a.v[K - 7], &b.v[7]);
+  mac_col_mod<F, 15 - K, K - 7, K>(acc, ov, m);
+  t[K - 8] = (uint32_t)acc;
+  acc = (acc >> 32) | ((uint64_t)ov << 32);
+  ov = 0;
 }
 
 template <class F>
@@ -179,27 +226,22 @@ __device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) {
   uint32_t t[8];
   uint64_t acc = 0;
   uint32_t ov = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-#pragma unroll
-    for (int j = 0; j <= k; j++) mac(acc, ov, a.v[j], b.v[k - j]);
-#pragma unroll
-    for (int j = 0; j < k; j++) mac(acc, ov, m[j], F::MOD[k - j]);
-    m[k] = (uint32_t)acc * F::INV;
-    mac(acc, ov, m[k], F::MOD[0]);  // low word becomes 0
-    acc = (acc >> 32) | ((uint64_t)ov << 32);
-    ov = 0;
-  }
-#pragma unroll
-  for (int k = 8; k < 16; k++) {
-#pragma unroll
-    for (int j = k - 7; j < 8; j++) mac(acc, ov, a.v[j], b.v[k - j]);
-#pragma unroll
-    for (int j = k - 7; j < 8; j++) mac(acc, ov, m[j], F::MOD[k - j]);
-    t[k - 8] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)ov << 32);
-    ov = 0;
-  }
+  mont_col_lo<F, 0>(acc, ov, a, b, m);
+  mont_col_lo<F, 1>(acc, ov, a, b, m);
+  mont_col_lo<F, 2>(acc, ov, a, b, m);
+  mont_col_lo<F, 3>(acc, ov, a, b, m);
+  mont_col_lo<F, 4>(acc, ov, a, b, m);
+  mont_col_lo<F, 5>(acc, ov, a, b, m);
+  mont_col_lo<F, 6>(acc, ov, a, b, m);
+  mont_col_lo<F, 7>(acc, ov, a, b, m);
+  mont_col_hi<F, 8>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 9>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 10>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 11>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 12>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 13>(acc, ov, a, b, m, t);
+  mont_col_hi<F, 14>(acc, ov, a, b, m, t);
+  t[7] = (uint32_t)acc;  // column 15 has no products
   fe r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];

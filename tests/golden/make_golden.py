@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/bn254_vectors.json from the pure-Python oracle (oracle/bn254.py).
+
+The reference (/root/reference) ships no vectors for this path and cannot be run here,
+so these are SELF-DERIVED known answers: every value below is computed by big-integer arithmetic from
+the published definitions (sum s_i P_i; out[i] = sum a[j] w^(ij); g[i] = s^i G), with inputs taken
+from the seeded generator.  They pin the oracle, the C restatement and the HIP path to each other.
+Usage: python tests/golden/make_golden.py   (rewrites the JSON next to this script)
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import bn254 as o  # noqa: E402
+
+
+def hx(v):
+    return "0x%064x" % v
+
+
+def pt(p):
+    return None if p is None else [hx(p[0]), hx(p[1])]
+
+
+def main():
+    out = {"comment": "self-derived known answers (oracle/bn254.py); canonical (non-Montgomery) integers", "seed": o.SEED}
+    out["constants"] = {
+        "q": hx(o.Q), "r": hx(o.R), "fr_root_of_unity": hx(o.FR_ROOT_OF_UNITY), "fr_zeta": hx(o.FR_ZETA),
+        "fr_mont_R": hx(o.to_mont(1, o.R)), "fr_mont_R2": hx(o.to_mont(o.to_mont(1, o.R), o.R)),
+        "fq_mont_R": hx(o.to_mont(1, o.Q)), "fq_mont_R2": hx(o.to_mont(o.to_mont(1, o.Q), o.Q)),
+        "fr_inv64": hx((-pow(o.R, -1, 1 << 64)) % (1 << 64)), "fq_inv64": hx((-pow(o.Q, -1, 1 << 64)) % (1 << 64)),
+    }
+    G = o.G1_GEN
+    out["g1"] = {
+        "G": pt(G), "2G": pt(o.g1_double(G)), "3G": pt(o.g1_add(o.g1_double(G), G)), "(r-1)G": pt(o.g1_mul(o.R - 1, G)),
+        "12345G": pt(o.g1_mul(12345, G)), "seedG": pt(o.g1_mul(o.SEED, G)),
+    }
+    # NTT: n = 64, seeded input (canonical values), forward / coset / inverse
+    k = 6
+    n = 1 << k
+    a = o.unpack(o.random_field_limbs(n, o.SEED + 1), o.R)
+    w = o.omega_for(k)
+    out["ntt"] = {
+        "log_n": k, "omega": hx(w), "input": [hx(x) for x in a], "forward": [hx(x) for x in o.ntt(a, w)],
+        "coset_zeta": [hx(x) for x in o.ntt_ext(a, w, pre_base=o.FR_ZETA)],
+        "inverse_scaled": [hx(x) for x in o.intt(a, w)],
+    }
+    # MSM: n = 64 bases s_i * G with seeded s_i, seeded scalars
+    m = 64
+    bs = o.unpack(o.random_field_limbs(m, o.SEED + 2), o.R)
+    bases = [o.g1_mul(s, G) for s in bs]
+    sc = o.unpack(o.random_field_limbs(m, o.SEED), o.R)
+    out["msm"] = {
+        "n": m, "base_scalars": [hx(x) for x in bs], "scalars": [hx(x) for x in sc], "result": pt(o.msm_naive(sc, bases)),
+        "result_all_ones": pt(o.msm_naive([1] * m, bases)),
+        "result_witness_like": pt(o.msm_naive(o.unpack(o.witness_like_limbs(m, 3), o.R), bases)),
+    }
+    # SRS k = 3, s = 5 and the commitment of a fixed polynomial both ways
+    g, gl = o.srs(3, 5)
+    coeffs = [3, 1, 4, 1, 5, 9, 2, 6]
+    out["srs"] = {"k": 3, "s": 5, "g": [pt(p) for p in g], "g_lagrange": [pt(p) for p in gl], "coeffs": coeffs,
+                  "commit": pt(o.msm_naive(coeffs, g))}
+    # extended domain (k = 3, cs degree 3)
+    d = o.Domain(3, 3)
+    out["domain"] = {"k": 3, "j": 3, "extended_k": d.extended_k, "coeff_to_extended": [hx(x) for x in d.coeff_to_extended(coeffs)]}
+    with open(os.path.join(HERE, "bn254_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", os.path.join(HERE, "bn254_vectors.json"))
+
+
+if __name__ == "__main__":
+    main()

@@ -228,3 +228,86 @@ def test_srs_commit_consistency(gpu, k):
             fs = (fs * s + c) % o.R
         assert c1 == o.g1_mul(fs, o.G1_GEN)
     params.release()
+
+
+# ---- committed golden vectors (tests/golden/bn254_vectors.json) ------------------------------------
+import json  # noqa: E402
+import os  # noqa: E402
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_vectors.json")))
+
+
+def _gpt(p):
+    return None if p is None else (int(p[0], 16), int(p[1], 16))
+
+
+def test_golden_ntt(gpu):
+    t = GOLD["ntt"]
+    a = o.pack([int(x, 16) for x in t["input"]], o.R)
+    w = o.pack([int(t["omega"], 16)], o.R)[0]
+    x = a.copy()
+    gpu.best_fft(x, w, t["log_n"])
+    assert o.unpack(x, o.R) == [int(v, 16) for v in t["forward"]]
+    zeta = o.pack([o.FR_ZETA], o.R)[0]
+    x = a.copy()
+    assert gpu.lib.h2mi_ntt_ext_bn254_fr(x.ctypes.data, t["log_n"], w.ctypes.data, zeta.ctypes.data, None) == 0
+    assert o.unpack(x, o.R) == [int(v, 16) for v in t["coset_zeta"]]
+    d = gpu.EvaluationDomain(3, t["log_n"])
+    assert o.unpack(d.lagrange_to_coeff(a), o.R) == [int(v, 16) for v in t["inverse_scaled"]]
+
+
+def test_golden_msm_and_srs(gpu):
+    t = GOLD["msm"]
+    bases = o.pack_points([o.g1_mul(int(x, 16), o.G1_GEN) for x in t["base_scalars"]])
+    sc = o.pack([int(x, 16) for x in t["scalars"]], o.R)
+    assert o.unpack_jacobian(gpu.best_multiexp(sc, bases)) == _gpt(t["result"])
+    assert o.unpack_jacobian(gpu.best_multiexp(o.pack([1] * t["n"], o.R), bases)) == _gpt(t["result_all_ones"])
+    assert o.unpack_jacobian(gpu.best_multiexp(o.witness_like_limbs(t["n"], 3), bases)) == _gpt(t["result_witness_like"])
+    s = GOLD["srs"]
+    params = gpu.ParamsKZG.setup(s["k"], s["s"])
+    assert o.unpack_points(params.get_g()) == [_gpt(p) for p in s["g"]]
+    assert o.unpack_points(params.get_g_lagrange()) == [_gpt(p) for p in s["g_lagrange"]]
+    assert o.unpack_jacobian(params.commit(o.pack(s["coeffs"], o.R))) == _gpt(s["commit"])
+    params.release()
+    d = gpu.EvaluationDomain(GOLD["domain"]["j"], GOLD["domain"]["k"])
+    ext = d.coeff_to_extended(o.pack(s["coeffs"], o.R))
+    assert o.unpack(ext, o.R) == [int(v, 16) for v in GOLD["domain"]["coeff_to_extended"]]
+
+
+def test_msm_vs_c_oracle_large(gpu):
+    """2^16 points: the HIP MSM against the C restatement of best_multiexp (same group element), plus
+    run-to-run bit reproducibility of the Jacobian output (stable sort => fixed addition order)."""
+    from oracle import cref
+
+    n = 1 << 16
+    params = gpu.ParamsKZG.setup(16, 0xC0FFEE)
+    bases = params.get_g()
+    for limbs in (o.random_field_limbs(n, o.SEED), o.witness_like_limbs(n, o.SEED)):
+        got = params.commit(limbs)
+        want = cref.msm(limbs, bases, 8)
+        assert np.array_equal(cref.normalize(got), cref.normalize(want))
+        assert np.array_equal(got, params.commit(limbs))
+    # shorter polynomial than the SRS (SHPLONK quotients): first m bases only
+    m = 40000
+    got = params.commit(o.random_field_limbs(m, 9))
+    assert np.array_equal(cref.normalize(got), cref.normalize(cref.msm(o.random_field_limbs(m, 9), bases[:m], 8)))
+    params.release()
+
+
+def test_msm_linearity_full_size(gpu):
+    """BASELINE size (k = 20): MSM(a + b) == MSM(a) + MSM(b) and MSM(c * 1) == c * MSM(1) as group elements."""
+    from oracle import cref
+
+    k = 20
+    n = 1 << k
+    params = gpu.ParamsKZG.setup(k, 0x5EC2E7)
+    a = o.random_field_limbs(n, 1)
+    b = o.random_field_limbs(n, 2)
+    s = cref.field_op(1, 1, a, b)  # a + b in Fr (Montgomery limbs add like the values)
+    pa, pb, ps = params.commit(a), params.commit(b), params.commit(s)
+    assert np.array_equal(cref.normalize(cref.g1_sum(np.stack([pa, pb]))), cref.normalize(ps))
+    # commit(f; g) == commit_lagrange(NTT f; g_lagrange) at full size
+    d = gpu.EvaluationDomain(3, k)
+    ev = d.coeff_to_lagrange(a)
+    assert np.array_equal(cref.normalize(params.commit_lagrange(ev)), cref.normalize(pa))
+    params.release()
