@@ -39,6 +39,7 @@ def _load():
         "h2mi_memcpy_d2d": ([vp, vp, sz], C.c_int),
         "h2mi_memset_zero": ([vp, sz], C.c_int),
         "h2mi_sync": ([], C.c_int),
+        "h2mi_join": ([], C.c_int),
         "h2mi_bases_register": ([vp, sz, u64p], C.c_int),
         "h2mi_bases_register_dev": ([vp, sz, u64p], C.c_int),
         "h2mi_bases_release": ([C.c_uint64], C.c_int),

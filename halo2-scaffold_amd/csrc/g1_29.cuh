@@ -1,0 +1,94 @@
+// XYZZ mixed addition on the lazy 29-bit-limb representation (f29.cuh) — the inner loop of the MSM
+// bucket accumulation.  Same group law as g1.cuh (madd-2008-s, complete), different field layer.
+//
+// Coordinates are Montgomery-2^261 values, loosely reduced.  Invariants of an accumulator between
+// additions (value bounds in units of p; all limbs normalized):
+//     X < 6, Y < 4, ZZ < 1.1, ZZZ < 1.1          ("acc invariant")
+// Table points (x2, y2): canonical (< 1), normalized; a negated y2 is 2p - y2 (lazy limbs, < 2).
+// With eps = p / 2^261 = 0.0059 and mul(A, B) < 1 + eps*A*B:
+//     U2 = x2*ZZ < 1.007            S2 = y2*ZZZ < 1.014
+//     P  = U2 - X + 6p < 7.007      R  = S2 - Y + 4p < 5.014          (normalized before squaring)
+//     PP = P^2 < 1.29               PPP = P*PP < 1.054                Q = X*PP < 1.046
+//     RR = R^2 < 1.149              X3 = RR - PPP - 2Q + 4p < 5.149   (< 6: invariant holds)
+//     T  = Q - X3 + 6p < 7.05 (lazy operand)   T1 = R*T < 1.209       T2 = Y*PPP < 1.025
+//     Y3 = T1 - T2 + 2p < 3.209    (< 4: invariant holds)             ZZ3, ZZZ3 < 1.01
+#pragma once
+#include "f29.cuh"
+
+namespace h2 {
+
+struct affine29 {
+  f29 x, y;  // canonical Mont261, normalized; (0,0) = identity
+};
+struct xyzz29 {
+  f29 x, y, zz, zzz;  // zz limbs all zero = identity
+};
+
+H2_HD bool affine29_is_identity(const affine29& p) { return f29_limbs_zero(p.x) && f29_limbs_zero(p.y); }
+H2_HD bool xyzz29_is_identity(const xyzz29& p) { return f29_limbs_zero(p.zz); }
+H2_HD xyzz29 xyzz29_identity() {
+  xyzz29 r;
+  r.x = f29_zero(); r.y = f29_zero(); r.zz = f29_zero(); r.zzz = f29_zero();
+  return r;
+}
+
+// 2 * (affine point) — rare path (a bucket receiving the same point twice); everything normalized.
+H2_HD xyzz29 xyzz29_dbl_affine(const f29& x, const f29& y_any) {
+  using F = Fq29;
+  xyzz29 r;
+  f29 y = f29_normalize(y_any);
+  f29 u = f29_normalize(f29_dbl(y));                           // U = 2Y            (< 4)
+  f29 v = f29_sqr<F>(u);                                       // V = U^2           (< 1.1)
+  f29 w = f29_mul<F>(u, v);                                    // W = U*V
+  f29 s = f29_mul<F>(x, v);                                    // S = X*V
+  f29 xx = f29_sqr<F>(x);
+  f29 m = f29_normalize(f29_add(f29_dbl(xx), xx));             // M = 3X^2          (< 3.1)
+  f29 mm = f29_sqr<F>(m);                                      // (< 1.06)
+  r.x = f29_normalize(f29_sub(mm, f29_dbl(s), F::KW4));        // X3 = M^2 - 2S + 4p (< 5.1); 2S limbs < 2^30
+  f29 t = f29_sub(s, r.x, F::K6);                              // S - X3 + 6p  (lazy, < 7.1)
+  f29 t1 = f29_mul<F>(t, m);
+  f29 t2 = f29_mul<F>(w, y);
+  r.y = f29_normalize(f29_sub(t1, t2, F::K2));                 // (< 3.1)
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+
+// acc += (x2, y2);  y2 may be lazy (negated).  Complete: handles acc = identity, P + P, P + (-P).
+// The caller skips identity table points.
+H2_HD void xyzz29_madd(xyzz29& acc, const f29& x2, const f29& y2) {
+  using F = Fq29;
+  if (xyzz29_is_identity(acc)) {
+    acc.x = x2;
+    acc.y = f29_normalize(y2);
+    acc.zz = f29_const<F>(F::ONE);
+    acc.zzz = f29_const<F>(F::ONE);
+    return;
+  }
+  f29 u2 = f29_mul<F>(x2, acc.zz);
+  f29 s2 = f29_mul<F>(y2, acc.zzz);
+  f29 p = f29_normalize(f29_sub(u2, acc.x, F::K6));
+  f29 r = f29_normalize(f29_sub(s2, acc.y, F::K4));
+  f29 pp = f29_sqr<F>(p);
+  if (f29_is_zero_mod<F>(pp)) {  // same x: equal or opposite points (rare)
+    f29 rr = f29_sqr<F>(r);
+    if (f29_is_zero_mod<F>(rr)) acc = xyzz29_dbl_affine(x2, y2);
+    else acc = xyzz29_identity();
+    return;
+  }
+  f29 ppp = f29_mul<F>(p, pp);
+  f29 q = f29_mul<F>(acc.x, pp);
+  f29 rr = f29_sqr<F>(r);
+  // X3 = RR - PPP - 2Q + 4p : subtract (PPP + 2Q) (limbs < 3 * 2^29) with the 2^31-biased 4p
+  f29 sub3 = f29_add(ppp, f29_dbl(q));
+  f29 x3 = f29_normalize(f29_sub(rr, sub3, F::KW4));
+  f29 t = f29_sub(q, x3, F::K6);  // lazy operand (limbs < 1.5 * 2^30)
+  f29 t1 = f29_mul<F>(t, r);
+  f29 t2 = f29_mul<F>(acc.y, ppp);
+  acc.x = x3;
+  acc.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  acc.zz = f29_mul<F>(acc.zz, pp);
+  acc.zzz = f29_mul<F>(acc.zzz, ppp);
+}
+
+}  // namespace h2

@@ -145,6 +145,7 @@ int h2mi_init(int device) {
   if (device < 0 || device >= count) return H2MI_EINVAL;
   H2_HIP(hipSetDevice(device));
   H2_HIP(hipStreamCreateWithFlags(&ctx().stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&ctx().tail_stream, hipStreamNonBlocking));
   ctx().device = device;
   ctx().inited = true;
   return H2MI_OK;
@@ -155,8 +156,11 @@ void h2mi_shutdown(void) {
   if (!ctx().inited) return;
   hipStreamSynchronize(ctx().stream);
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; }
+  hipStreamSynchronize(ctx().tail_stream);
+  hipStreamDestroy(ctx().tail_stream);
   hipStreamDestroy(ctx().stream);
   ctx().stream = nullptr;
+  ctx().tail_stream = nullptr;
   ctx().inited = false;
 }
 
@@ -196,6 +200,11 @@ int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
 }
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
   H2_REQUIRE_INIT();
+  {
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    int rc = msm_join_all(ctx().stream);
+    if (rc) return rc;
+  }
   H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
   H2_HIP(hipStreamSynchronize(ctx().stream));
   return H2MI_OK;
@@ -210,8 +219,18 @@ int h2mi_memset_zero(void* d_ptr, size_t bytes) {
   H2_HIP(hipMemsetAsync(d_ptr, 0, bytes, ctx().stream));
   return H2MI_OK;
 }
+int h2mi_join(void) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return msm_join_all(ctx().stream);
+}
 int h2mi_sync(void) {
   H2_REQUIRE_INIT();
+  {
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    int rc = msm_join_all(ctx().stream);
+    if (rc) return rc;
+  }
   H2_HIP(hipStreamSynchronize(ctx().stream));
   return H2MI_OK;
 }

@@ -22,6 +22,7 @@ struct Ctx {
   bool inited = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t tail_stream = nullptr;  // latency-bound MSM tails overlap the next MSM here
   std::recursive_mutex mu;
   bool profiling = false;
   std::string prof_filter;
@@ -66,6 +67,9 @@ inline bool prof_on(const char* name) {
     if (prof_) ::h2::prof_end(stream);                                                 \
     H2_HIP(hipGetLastError());                                                         \
   } while (0)
+
+// h2mi_msm.hip: make `s` wait for all outstanding MSM tails
+int msm_join_all(hipStream_t s);
 
 inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 

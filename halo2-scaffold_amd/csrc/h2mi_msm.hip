@@ -24,6 +24,7 @@
 #include <map>
 
 #include "g1.cuh"
+#include "g1_29.cuh"
 #include "h2mi_internal.h"
 
 namespace h2 {
@@ -31,14 +32,12 @@ namespace h2 {
 constexpr uint32_t S0 = 64;  // points per accumulation task
 constexpr uint32_t S1 = 32;  // partials per fold task
 
-struct Bases {
-  size_t n = 0;
-  uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
-  uint8_t* table = nullptr;     // [W][n] affine, 64 B each
+// per-call workspace; two slots per handle so that the latency-bound tail of one MSM (fold, bucket
+// reduction) runs on the tail stream while the next MSM's sort and accumulation already run.
+struct Slot {
   uint16_t* keys[2] = {nullptr, nullptr};     // [W][n] bucket id per (window, scalar); 0xFFFF = zero digit
   uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i ; [1] holds the sorted order
   void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
   uint32_t* np[3] = {nullptr, nullptr, nullptr};    // partial counts per bucket after level 0,1,2
@@ -47,6 +46,18 @@ struct Bases {
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
   uint8_t* g = nullptr;                             // weighted partials (<= 32)
   uint64_t* stats = nullptr;                        // [0] = insertions
+  hipEvent_t accum_done = nullptr, tail_done = nullptr;
+  bool tail_pending = false;
+};
+constexpr int NSLOT = 2;
+
+struct Bases {
+  size_t n = 0;
+  uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
+  uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
+  size_t sort_tmp_bytes = 0;
+  Slot slot[NSLOT];
+  int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0, max_tasks2 = 0;
 };
 
@@ -172,8 +183,23 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
   return lo;
 }
 
+// registration epilogue: the table is consumed only by k_msm_accum, which works in the lazy 29-bit-limb
+// representation (f29.cuh); store the points as canonical Montgomery-2^261 integers (still 8 x 32-bit
+// words per coordinate) so the inner loop only unpacks.
+__global__ void __launch_bounds__(256) k_msm_table_to261(uint8_t* table, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  affine p = affine_load(table + i * 64);
+  if (affine_is_identity(p)) return;
+  affine q;
+  f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.x.v)), q.x.v);
+  f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.y.v)), q.y.v);
+  affine_store(table + i * 64, q);
+}
+
 // level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
-// accumulates with mixed additions.
+// accumulates with mixed additions in the lazy 29-bit-limb representation (g1_29.cuh).  The partial
+// sum is written back in the standard XYZZ / Montgomery-2^256 format the later kernels use.
 __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* hist, const uint32_t* toff,
                                                     uint32_t nb, const uint8_t* table, uint8_t* part) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,7 +208,7 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
   uint32_t j = t - toff[b];
   uint32_t start = off[b] + j * S0;
   uint32_t len = min(S0, hist[b] - j * S0);
-  xyzz acc = xyzz_identity();
+  xyzz29 acc = xyzz29_identity();
   uint32_t e = entries[start];
   affine nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
   uint32_t nneg = e >> 31;
@@ -194,10 +220,22 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
       nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
       nneg = e >> 31;
     }
-    if (neg) p.y = fe_neg<Fq>(p.y);
-    xyzz_madd(acc, p);
+    if (affine_is_identity(p)) continue;
+    f29 x2 = f29_unpack(p.x.v);
+    f29 y2 = f29_unpack(p.y.v);
+    if (neg) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
+    xyzz29_madd(acc, x2, y2);
   }
-  xyzz_store(part + (size_t)t * 128, acc);
+  xyzz out;
+  if (xyzz29_is_identity(acc)) {
+    out = xyzz_identity();
+  } else {
+    f29_to_mont256<Fq29>(acc.x, out.x.v);
+    f29_to_mont256<Fq29>(acc.y, out.y.v);
+    f29_to_mont256<Fq29>(acc.zz, out.zz.v);
+    f29_to_mont256<Fq29>(acc.zzz, out.zzz.v);
+  }
+  xyzz_store(part + (size_t)t * 128, out);
 }
 
 // fold level: one thread per task of <= S1 partials of one bucket
@@ -320,10 +358,15 @@ static uint32_t pick_window(size_t n) {
 }
 
 static void free_bases(Bases* B) {
-  hipFree(B->table); hipFree(B->keys[0]); hipFree(B->keys[1]); hipFree(B->vals[0]); hipFree(B->vals[1]); hipFree(B->sort_tmp);
-  hipFree(B->hist); hipFree(B->off);
-  for (int i = 0; i < 3; i++) { hipFree(B->np[i]); hipFree(B->toff[i]); }
-  hipFree(B->part[0]); hipFree(B->part[1]); hipFree(B->rc); hipFree(B->g); hipFree(B->stats);
+  hipFree(B->table);
+  for (Slot& S : B->slot) {
+    hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
+    hipFree(S.hist); hipFree(S.off);
+    for (int i = 0; i < 3; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
+    hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
+    if (S.accum_done) hipEventDestroy(S.accum_done);
+    if (S.tail_done) hipEventDestroy(S.tail_done);
+  }
   delete B;
 }
 
@@ -352,33 +395,46 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   B->max_tasks2 = B->max_tasks1 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
-  for (int i = 0; i < 2; i++) {
-    H2_ALLOC(B->keys[i], nW * 2);
-    H2_ALLOC(B->vals[i], nW * 4);
-  }
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, B->keys[0], B->keys[1], B->vals[0], B->vals[1], (unsigned int)nW, 0,
-                                         16, s) != hipSuccess) {
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
+                                         (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
     free_bases(B);
     return H2MI_EHIP;
   }
-  H2_ALLOC(B->sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
-  H2_ALLOC(B->hist, (size_t)B->nb * 4);
-  H2_ALLOC(B->off, (size_t)(B->nb + 1) * 4);
-  for (int i = 0; i < 3; i++) {
-    H2_ALLOC(B->np[i], (size_t)B->nb * 4);
-    H2_ALLOC(B->toff[i], (size_t)(B->nb + 1) * 4);
+  for (Slot& S : B->slot) {
+    for (int i = 0; i < 2; i++) {
+      H2_ALLOC(S.keys[i], nW * 2);
+      H2_ALLOC(S.vals[i], nW * 4);
+    }
+    H2_ALLOC(S.sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
+    H2_ALLOC(S.hist, (size_t)B->nb * 4);
+    H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
+    for (int i = 0; i < 3; i++) {
+      H2_ALLOC(S.np[i], (size_t)B->nb * 4);
+      H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
+    }
+    H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * 128);
+    H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * 128);
+    H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * 128);
+    H2_ALLOC(S.g, (size_t)64 * 128);
+    H2_ALLOC(S.stats, 64);
+    if (hipEventCreateWithFlags(&S.accum_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming) != hipSuccess) {
+      free_bases(B);
+      return H2MI_EHIP;
+    }
   }
-  H2_ALLOC(B->part[0], (size_t)B->max_tasks0 * 128);
-  H2_ALLOC(B->part[1], (size_t)B->max_tasks1 * 128);
-  H2_ALLOC(B->rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * 128);
-  H2_ALLOC(B->g, (size_t)64 * 128);
-  H2_ALLOC(B->stats, 64);
   if (hipMemcpyAsync(B->table, d_bases, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
   for (uint32_t w = 1; w < B->W; w++) {
     const bool prof_ = prof_on("k_msm_table_next");
     if (prof_) prof_begin("k_msm_table_next", s);
     hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * n * 64),
                        B->table + (size_t)w * n * 64, n, B->c);
+    if (prof_) prof_end(s);
+  }
+  {
+    const bool prof_ = prof_on("k_msm_table_to261");
+    if (prof_) prof_begin("k_msm_table_to261", s);
+    hipLaunchKernelGGL(k_msm_table_to261, dim3(ceil_div_u32(nW, 256)), dim3(256), 0, s, B->table, nW);
     if (prof_) prof_end(s);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
@@ -388,6 +444,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   return H2MI_OK;
 }
 
+// One MSM.  On the library's own stream the call is split: sort + accumulation on `s`, the
+// latency-bound tail on the tail stream (joined by msm_join_all / h2mi_sync / the next use of the slot).
+// On a caller-provided stream everything stays on that stream.
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   const uint32_t nb = B->nb, W = B->W;
   const uint32_t total = (uint32_t)(n * W);
@@ -396,38 +455,65 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     scan_attr_set = true;
   }
+  const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
+  Slot& S = B->slot[B->next_slot];
+  B->last_slot = B->next_slot;
+  B->next_slot = (B->next_slot + 1) % NSLOT;
+  if (S.tail_pending) {  // the slot's previous tail must be finished before its buffers are reused
+    H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+    S.tail_pending = false;
+  }
   const size_t scan_lds = (size_t)(nb + (nb >> 5) + 32) * 4;
-  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, B->keys[0], B->vals[0], B->c, W);
+  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
   {
     const bool prof_ = prof_on("hipcub_radix_sort");
     if (prof_) prof_begin("hipcub_radix_sort", s);
     // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(B->sort_tmp, B->sort_tmp_bytes, B->keys[0], B->keys[1], B->vals[0], B->vals[1], total, 0, 16, s);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, s);
     if (prof_) prof_end(s);
     H2_HIP(e);
   }
-  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)B->keys[1], total, nb, B->off, B->hist);
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->hist, nb, S0, B->np[0], B->toff[0]);
+  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)S.keys[1], total, nb, S.off, S.hist);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)S.hist, nb, S0, S.np[0], S.toff[0]);
   uint32_t tasks0 = (uint32_t)(n * W / S0 + nb);
-  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)B->vals[1], (const uint32_t*)B->off,
-            (const uint32_t*)B->hist, (const uint32_t*)B->toff[0], nb, (const uint8_t*)B->table, B->part[0]);
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
+            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, (const uint8_t*)B->table, S.part[0]);
+  hipStream_t t = s;
+  if (pipelined) {
+    t = ctx().tail_stream;
+    H2_HIP(hipEventRecord(S.accum_done, s));
+    H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
+  }
   // fold level 1: part[0] -> part[1]
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->np[0], nb, S1, B->np[1], B->toff[1]);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, t, (const uint32_t*)S.np[0], nb, S1, S.np[1], S.toff[1]);
   uint32_t tasks1 = tasks0 / S1 + nb;
-  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, s, (const uint8_t*)B->part[0], (const uint32_t*)B->toff[0],
-            (const uint32_t*)B->np[0], (const uint32_t*)B->toff[1], nb, B->part[1]);
+  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[0],
+            (const uint32_t*)S.np[0], (const uint32_t*)S.toff[1], nb, S.part[1]);
   // fold level 2: part[1] -> part[0] (part[0] holds max_tasks0 >= max_tasks2 slots)
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)B->np[1], nb, S1, B->np[2], B->toff[2]);
+  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, t, (const uint32_t*)S.np[1], nb, S1, S.np[2], S.toff[2]);
   uint32_t tasks2 = tasks1 / S1 + nb;
-  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks2, 256), 256, 0, s, (const uint8_t*)B->part[1], (const uint32_t*)B->toff[1],
-            (const uint32_t*)B->np[1], (const uint32_t*)B->toff[2], nb, B->part[0]);
+  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks2, 256), 256, 0, t, (const uint8_t*)S.part[1], (const uint32_t*)S.toff[1],
+            (const uint32_t*)S.np[1], (const uint32_t*)S.toff[2], nb, S.part[0]);
   // weighted bucket sum
   const uint32_t Nh = 1u << B->logNh, Nl = 1u << B->logNl;
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * 128, s, (const uint8_t*)B->part[0], (const uint32_t*)B->toff[2],
-            (const uint32_t*)B->np[2], B->logNh, B->logNl, B->rc);
-  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * 128, s, (const uint8_t*)B->rc, B->logNh, B->logNl, B->g);
-  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * 128, s, (const uint8_t*)B->g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)B->off,
-            nb, B->stats);
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * 128, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[2],
+            (const uint32_t*)S.np[2], B->logNh, B->logNl, S.rc);
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * 128, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
+  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * 128, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
+            nb, S.stats);
+  H2_HIP(hipEventRecord(S.tail_done, t));
+  S.tail_pending = true;
+  return H2MI_OK;
+}
+
+// make stream `s` wait for every outstanding MSM tail (device-side join, no host synchronisation)
+int msm_join_all(hipStream_t s) {
+  for (auto& kv : g_bases)
+    for (Slot& S : kv.second->slot)
+      if (S.tail_pending) {
+        H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+        S.tail_pending = false;
+      }
   return H2MI_OK;
 }
 
@@ -511,6 +597,7 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   if (hipMalloc(&d, n * 32 + 96) != hipSuccess) rc = H2MI_ENOMEM;
   if (!rc && hipMemcpyAsync(d + 96, scalars, n * 32, hipMemcpyHostToDevice, s) != hipSuccess) rc = H2MI_EHIP;
   if (!rc) rc = msm_dev(it->second, d + 96, n, d, s);
+  if (!rc) rc = msm_join_all(s);
   if (!rc && hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
   if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
   if (d) hipFree(d);
@@ -526,7 +613,7 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   Bases* B = it->second;
   H2_HIP(hipDeviceSynchronize());
   uint64_t st = 0;
-  H2_HIP(hipMemcpy(&st, B->stats, 8, hipMemcpyDeviceToHost));
+  H2_HIP(hipMemcpy(&st, B->slot[B->last_slot].stats, 8, hipMemcpyDeviceToHost));
   if (bucket_adds) *bucket_adds = st;
   if (reduce_adds) {
     // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))

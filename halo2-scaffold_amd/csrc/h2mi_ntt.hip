@@ -8,23 +8,32 @@
 //   pass p < last : inside every segment of length SEG (n, n/N1, ...) run the size-N_p DFT down each
 //                   column (stride S = SEG/N_p), multiply element (k, j) by w_seg^(j*k), store in place;
 //   last pass     : size-N_P DFT of every contiguous row, scattered to the digit-reversed output slot.
-// Every size-2^m DFT runs in LDS: the tile (2^m x C columns, 32 B elements) and the 2^(m-1) local
-// twiddles are staged in LDS once; m radix-2 DIF stages exchange through LDS; the tile is read back
-// bit-reversed on the way out.  HBM sees each element once per pass (read + write, C*32 B segments).
+// Every size-2^m DFT runs in LDS: the tile (2^m x C columns, nine 29-bit limb planes) and the 2^(m-1)
+// local twiddles are staged in LDS once, the tile written bit-reversed; m radix-2 DIT stages exchange
+// through LDS.  HBM sees each element once per pass (read + write, C*32 B segments).
 // The coset pre-scale (a[i] *= g^i) is fused into the first pass's load and the n^-1 post-scale into
 // the last pass's store, so EvaluationDomain's extra sweeps over memory disappear.
 // Twiddles: w^e for the inter-pass factors comes from two small tables (e = hi*2^h + lo, one extra
 // field mul) instead of an n-entry table, so all twiddle data stays L2/LDS resident.
 #include <map>
 
+#include "f29.cuh"
 #include "fp.cuh"
 #include "h2mi_internal.h"
 
 namespace h2 {
 
 using Fr = FrP;
+using F9 = Fr29;
 
-// out[i] = (base^(2^log_stride))^i
+// Arithmetic: the lazy 29-bit-limb layer (f29.cuh).  Data stays in the ABI's Montgomery-2^256 form
+// (only unpacked to 9 limbs); every twiddle / scale table is kept in Montgomery-2^261 form, so
+// f29_mul(data, twiddle) = data * twiddle * 2^-261 lands back in the data's own domain.
+// Butterflies are decimation-in-time: t = v*w is freshly reduced by the multiplication and u +- t grow
+// by at most 2p per stage (< 25p after 10 stages, capacity 2^261 = 169p), so stages need no modular
+// correction at all — one carry normalisation per output.
+
+// out[i] = (base^(2^log_stride))^i, written as canonical Montgomery-2^261 words
 __global__ void __launch_bounds__(256) k_pow_table(fe* out, uint32_t count, fe base, uint32_t log_stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -35,22 +44,24 @@ __global__ void __launch_bounds__(256) k_pow_table(fe* out, uint32_t count, fe b
     r = fe_sqr<Fr>(r);
     if ((i >> bit) & 1u) r = fe_mul<Fr>(r, b);
   }
-  fe_store(&out[i], r);
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(f29_from_mont256<F9>(r.v)), o.v);
+  fe_store(&out[i], o);
 }
 
 struct PassParams {
   const fe* in;
   fe* out;
   uint32_t log_n, log_seg, m, logC;
-  const fe* loc;  // local twiddles w_loc^e, e < 2^(m-1)
-  const fe* tlo;  // omega^i, i < 2^h
+  const fe* loc;  // local twiddles w_loc^e, e < 2^(m-1)            (Mont261)
+  const fe* tlo;  // omega^i, i < 2^h                                (Mont261)
   const fe* thi;  // omega^(i << h)
   uint32_t h;
-  const fe* plo;  // pre-scale tables (first pass only) or null
+  const fe* plo;  // pre-scale tables (first pass only) or null      (Mont261)
   const fe* phi;
   uint32_t ph;
   int has_post;
-  fe post;
+  fe post;        // Mont256 (as passed by the caller)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
   uint32_t remap;         // XCD-aware block remap on/off
 };
@@ -64,41 +75,65 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nb, uint3
   return (b & 7u) * (nb >> 3) + (b >> 3);
 }
 
-// m radix-2 DIF stages over C tiles of 2^m elements resident in LDS; result is bit-reversed per tile.
-__device__ __forceinline__ void local_ntt(fe* lds, const fe* tw, uint32_t m, uint32_t logC) {
+// LDS image: structure-of-arrays, limb plane l of element i at lds[l * stride + i] (conflict-free
+// 4-byte accesses for consecutive lanes).
+__device__ __forceinline__ f29 lds_get(const uint32_t* lds, uint32_t stride, uint32_t i) {
+  f29 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) r.v[l] = lds[l * stride + i];
+  return r;
+}
+__device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t stride, uint32_t i, const f29& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) lds[l * stride + i] = a.v[l];
+}
+__device__ __forceinline__ f29 load_unpack(const fe* p) {
+  fe x = fe_load(p);
+  return f29_unpack(x.v);
+}
+__device__ __forceinline__ void pack_store(fe* p, const f29& a_lt2p) {
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(a_lt2p), o.v);
+  fe_store(p, o);
+}
+
+// m radix-2 DIT stages over C tiles of 2^m elements (bit-reversed order in, natural order out)
+__device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const fe* tw, uint32_t m, uint32_t logC) {
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   if (m == 0) return;
   const uint32_t nbf = 1u << (m - 1 + logC);
   for (uint32_t s = 0; s < m; s++) {
-    const uint32_t lh = m - 1 - s;  // log2(half)
-    const uint32_t half = 1u << lh;
+    const uint32_t half = 1u << s;
     for (uint32_t b = tid; b < nbf; b += T) {
       uint32_t c = b >> (m - 1);
       uint32_t i_ = b & ((1u << (m - 1)) - 1);
       uint32_t pos = i_ & (half - 1);
-      uint32_t grp = i_ >> lh;
-      uint32_t i = (c << m) | (grp << (lh + 1)) | pos;
-      fe u = lds[i], v = lds[i + half];
-      lds[i] = fe_add<Fr>(u, v);
-      fe d = fe_sub<Fr>(u, v);
-      if (s != m - 1) d = fe_mul<Fr>(d, tw[pos << s]);
-      lds[i + half] = d;
+      uint32_t grp = i_ >> s;
+      uint32_t i = (c << m) | (grp << (s + 1)) | pos;
+      f29 u = lds_get(lds, dstride, i), v = lds_get(lds, dstride, i + half);
+      f29 t = v;
+      if (s != 0) t = f29_mul<F9>(v, f29_unpack(tw[pos << (m - 1 - s)].v));
+      else t = f29_normalize(v);
+      // u + t and u - t + 2p  (t < 1.2p by the multiplication bound; stage 0: t is an input < 1.2p)
+      lds_put(lds, dstride, i, f29_normalize(f29_add(u, t)));
+      lds_put(lds, dstride, i + half, f29_normalize(f29_sub(u, t, F9::K2)));
     }
     __syncthreads();
   }
 }
 
-__device__ __forceinline__ fe pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {
-  return fe_mul<Fr>(fe_load(&hi[e >> h]), fe_load(&lo[e & ((1u << h) - 1)]));
+__device__ __forceinline__ f29 pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {  // Mont261
+  return f29_mul<F9>(load_unpack(&hi[e >> h]), load_unpack(&lo[e & ((1u << h) - 1)]));
 }
 
-extern __shared__ uint4 h2_smem[];
+extern __shared__ uint32_t h2_smem[];
 
 // non-final pass: column DFTs inside segments, in-place layout
-__global__ void __launch_bounds__(256) k_ntt_pass_col(PassParams p) {
-  fe* lds = reinterpret_cast<fe*>(h2_smem);
+__global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  fe* tw = lds + (C << m);
+  const uint32_t dstride = C << m, tstride = 1u << (m - 1);
+  uint32_t* lds = h2_smem;
+  fe* tw = reinterpret_cast<fe*>(lds + 9 * dstride);  // packed (32 B) twiddles: keeps a 2^10 tile at 52 KiB = 3 blocks/CU
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t logS = p.log_seg - m;
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
@@ -110,28 +145,29 @@ __global__ void __launch_bounds__(256) k_ntt_pass_col(PassParams p) {
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), e = o >> logC;
     size_t idx = base + ((size_t)e << logS) + jl0 + c;
-    fe x = fe_load(&p.in[idx]);
-    if (p.plo) x = fe_mul<Fr>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
-    lds[(c << m) | e] = x;
+    f29 x = load_unpack(&p.in[idx]);
+    if (p.plo) x = f29_mul<F9>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
-  for (uint32_t i = tid; i < (1u << (m - 1)); i += T) tw[i] = fe_load(&p.loc[i]);
+  for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
   __syncthreads();
-  local_ntt(lds, tw, m, logC);
+  local_ntt(lds, dstride, tw, m, logC);
   const uint32_t sh = p.log_n - p.log_seg;
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
-    fe x = lds[(c << m) | bitrev(k, m)];
+    f29 x = lds_get(lds, dstride, (c << m) | k);
     uint32_t ex = ((jl0 + c) * k) << sh;  // < n
-    x = fe_mul<Fr>(x, pow2tab(p.tlo, p.thi, p.h, ex));
-    fe_store(&p.out[base + ((size_t)k << logS) + jl0 + c], x);
+    x = f29_mul<F9>(x, pow2tab(p.tlo, p.thi, p.h, ex));
+    pack_store(&p.out[base + ((size_t)k << logS) + jl0 + c], x);
   }
 }
 
 // final pass: row DFTs, digit-reversed scatter
-__global__ void __launch_bounds__(256) k_ntt_pass_row(PassParams p) {
-  fe* lds = reinterpret_cast<fe*>(h2_smem);
+__global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  fe* tw = lds + (C << m);
+  const uint32_t dstride = C << m, tstride = m ? (1u << (m - 1)) : 1u;
+  uint32_t* lds = h2_smem;
+  fe* tw = reinterpret_cast<fe*>(lds + 9 * dstride);
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
   const uint32_t k2 = tile & ((1u << p.logN2) - 1);
@@ -141,19 +177,21 @@ __global__ void __launch_bounds__(256) k_ntt_pass_row(PassParams p) {
     uint32_t c = o >> m, e = o & ((1u << m) - 1);
     size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
     size_t idx = (rho << m) + e;
-    fe x = fe_load(&p.in[idx]);
-    if (p.plo) x = fe_mul<Fr>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
-    lds[(c << m) | e] = x;
+    f29 x = load_unpack(&p.in[idx]);
+    if (p.plo) x = f29_mul<F9>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
-  if (m) for (uint32_t i = tid; i < (1u << (m - 1)); i += T) tw[i] = fe_load(&p.loc[i]);
+  if (m) for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
   __syncthreads();
-  local_ntt(lds, tw, m, logC);
+  local_ntt(lds, dstride, tw, m, logC);
+  // the closing multiplication also brings the lazily accumulated value back below 2p:
+  // by the caller's post-scale (Mont256 -> Mont261 first) or by the Montgomery one
+  f29 fin = p.has_post ? f29_from_mont256<F9>(p.post.v) : f29_const<F9>(F9::ONE);
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
-    fe x = lds[(c << m) | bitrev(k, m)];
-    if (p.has_post) x = fe_mul<Fr>(x, p.post);
+    f29 x = f29_mul<F9>(lds_get(lds, dstride, (c << m) | k), fin);
     size_t oidx = (size_t)(k1_0 + c) + ((size_t)k2 << p.logN1) + ((size_t)k << (p.logN1 + p.logN2));
-    fe_store(&p.out[oidx], x);
+    pack_store(&p.out[oidx], x);
   }
 }
 
@@ -161,15 +199,18 @@ __global__ void __launch_bounds__(256) k_ntt_pass_row(PassParams p) {
 __global__ void __launch_bounds__(256) k_scale_powers(fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, int has_post, fe post) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe x = fe_load(&a[i]);
-  x = fe_mul<Fr>(x, pow2tab(lo, hi, h, (uint32_t)i));
-  if (has_post) x = fe_mul<Fr>(x, post);
-  fe_store(&a[i], x);
+  f29 x = load_unpack(&a[i]);
+  x = f29_mul<F9>(x, pow2tab(lo, hi, h, (uint32_t)i));
+  if (has_post) x = f29_mul<F9>(x, f29_from_mont256<F9>(post.v));
+  pack_store(&a[i], x);
 }
+// out[i] = base^i in the ABI's Montgomery-2^256 form
 __global__ void __launch_bounds__(256) k_powers(fe* out, size_t n, const fe* lo, const fe* hi, uint32_t h) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe_store(&out[i], pow2tab(lo, hi, h, (uint32_t)i));
+  fe o;
+  f29_to_mont256<F9>(pow2tab(lo, hi, h, (uint32_t)i), o.v);
+  fe_store(&out[i], o);
 }
 
 // ---- host side: plans and table caches -----------------------------------------------------------
@@ -323,6 +364,14 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
   }
   const uint32_t tile_elems_log = env_u32("H2MI_NTT_TILE_LOG", 10);  // elements staged per block
   const uint32_t remap = env_u32("H2MI_NTT_XCD_REMAP", 1);
+  uint32_t nthreads = env_u32("H2MI_NTT_THREADS", 512);
+  if (nthreads != 64 && nthreads != 128 && nthreads != 256 && nthreads != 512) nthreads = 256;
+  static bool attr_set = false;
+  if (!attr_set) {  // tiles above 64 KiB of LDS need the opt-in
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_col), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_row), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
   // buffer schedule: P=1: a->a ; P=2: a->tmp, tmp->a ; P=3: a->tmp, tmp->tmp, tmp->a
   uint32_t log_seg = log_n;
   for (int p = 0; p < pl.P; p++) {
@@ -350,8 +399,8 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       if (logC > logS) logC = logS;
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
-      size_t shmem = (((size_t)1 << (pp.m + logC)) + ((size_t)1 << (pp.m - 1))) * 32;
-      H2_LAUNCH("k_ntt_pass_col", k_ntt_pass_col, nblocks, 256, shmem, s, pp);
+      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + ((size_t)1 << (pp.m - 1)) * 32;
+      H2_LAUNCH("k_ntt_pass_col", k_ntt_pass_col, nblocks, nthreads, shmem, s, pp);
     } else {
       pp.has_post = post ? 1 : 0;
       if (post) pp.post = host_fe(post);
@@ -368,9 +417,8 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       if (logC > pp.logN1) logC = pp.logN1;
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
-      size_t shmem = (((size_t)1 << (pp.m + logC)) + (pp.m ? ((size_t)1 << (pp.m - 1)) : 1)) * 32;
-      uint32_t threads = 256;
-      H2_LAUNCH("k_ntt_pass_row", k_ntt_pass_row, nblocks, threads, shmem, s, pp);
+      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + (pp.m ? ((size_t)1 << (pp.m - 1)) : 1) * 32;
+      H2_LAUNCH("k_ntt_pass_row", k_ntt_pass_row, nblocks, nthreads, shmem, s, pp);
     }
     log_seg -= pp.m;
   }

@@ -70,34 +70,52 @@ class StandardPlonkReplay:
         src = buf.ptr + (offset_elems + self.lo) * 32
         check(lib.h2mi_msm_bn254_g1_dev(h, src, self.n_local, self.out.ptr + 96 * slot, None), "msm")
 
-    def step(self):
-        """one proof's worth of hot-path work, queued on the library stream (asynchronous)."""
+    def step(self, phase_joins: bool = True):
+        """one proof's worth of hot-path work, queued on the library streams (asynchronous).
+
+        The order follows create_proof.  Where the real prover must hash commitments
+        into the transcript before it can continue (challenges theta/beta/gamma, y, x, u), the replay
+        joins the MSM tails (`h2mi_join`), so no overlap is claimed that a prover could not have."""
         d, n = self.domain, self.n
+        join = (lambda: check(lib.h2mi_join(), "join")) if phase_joins else (lambda: None)
         slot = 0
-        # phase 2/4: advice and permutation-product commitments (Lagrange basis)
-        for c in self.cols:
+        # phase 2: advice commitments (Lagrange basis) -> challenges theta, beta, gamma
+        for c in self.cols[:N_ADVICE]:
             self._msm(slot, c, lagrange=True)
             slot += 1
-        # phase 6: random polynomial commitment (coefficient basis)
-        self._msm(slot, self.random_poly, lagrange=False)
-        slot += 1
-        # phase 4/7: lagrange_to_coeff then coeff_to_extended for every advice / z column
-        for c, w, e in zip(self.cols, self.work, self.ext):
+        join()
+        # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per column
+        for c, w, e in zip(self.cols[N_ADVICE:], self.work[N_ADVICE:], self.ext[N_ADVICE:]):
+            self._msm(slot, c, lagrange=True)
+            slot += 1
             w.copy_from(c, n * 32)
             d.lagrange_to_coeff_dev(w)
-            e.copy_from(w, n * 32)  # upper half of e stays zero: coset NTT output overwrites it, so re-zero
+            e.copy_from(w, n * 32)
             d.coeff_to_extended_dev(e)
-        # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each
+        # phase 6: random polynomial commitment (coefficient basis) -> challenge y
+        self._msm(slot, self.random_poly, lagrange=False)
+        slot += 1
+        join()
+        # phase 7: advice lagrange_to_coeff + coeff_to_extended (evaluate_h inputs)
+        for c, w, e in zip(self.cols[:N_ADVICE], self.work[:N_ADVICE], self.ext[:N_ADVICE]):
+            w.copy_from(c, n * 32)
+            d.lagrange_to_coeff_dev(w)
+            e.copy_from(w, n * 32)
+            d.coeff_to_extended_dev(e)
+        # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each -> challenge x
         self.h.copy_from(self._h_src)
         d.extended_to_coeff_dev(self.h)
         for piece in range(CS_DEGREE - 1):
             self._msm(slot, self.h, lagrange=False, offset_elems=piece * n)
             slot += 1
-        # phase 10: SHPLONK h(X) and L(X)/(X-u) commitments
+        join()
+        # phase 10: SHPLONK h(X) commitment -> challenge u -> L(X)/(X-u) commitment
         self._msm(slot, self.work[0], lagrange=False)
         slot += 1
+        join()
         self._msm(slot, self.work[1], lagrange=False)
         slot += 1
+        join()
         assert slot == MSM_PER_PROOF
         # restore the zero padding of the extended buffers for the next proof
         for e in self.ext:

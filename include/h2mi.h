@@ -57,7 +57,12 @@ int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int h2mi_memset_zero(void* d_ptr, size_t bytes); /* asynchronous on the library's stream */
-int h2mi_sync(void); /* wait for all work queued on the library's stream */
+int h2mi_sync(void); /* wait for all work queued on the library's streams */
+/* device-side join: later work on the library's stream waits for every MSM queued so far to be complete
+ * (MSMs on the library's stream run their bucket-reduction tail concurrently with the next call; results
+ * are complete after h2mi_join / h2mi_sync / h2mi_memcpy_d2h).  A prover calls it where the transcript
+ * needs the commitments of a phase. */
+int h2mi_join(void);
 
 /* ---- bases (the KZG SRS): ParamsKZG::{g, g_lagrange}, SURVEY.md 8a row a5 ------------------------
  * Replaces the `&params.g` / `&params.g_lagrange` slices that ParamsKZG::commit / commit_lagrange pass

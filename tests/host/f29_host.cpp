@@ -1,0 +1,68 @@
+// Host-side harness for the plain-C++ field/curve layer (halo2-scaffold_amd/csrc/f29.cuh, g1_29.cuh):
+// the same code the GPU kernels inline, compiled with g++ so the arithmetic is verified on the CPU
+// against the big-integer oracle before it ever runs on a GPU.  Test infrastructure only.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#include "../../halo2-scaffold_amd/csrc/g1_29.cuh"
+
+using namespace h2;
+
+template <class F>
+static void mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, int mode) {
+  for (size_t i = 0; i < n; i++) {
+    if (mode == 0) {  // Mont256 x Mont256 -> Mont256 through the internal Mont261 domain
+      f29 x = f29_from_mont256<F>(a + 8 * i), y = f29_from_mont256<F>(b + 8 * i);
+      f29_to_mont256<F>(f29_mul<F>(x, y), out + 8 * i);
+    } else if (mode == 1) {  // NTT butterfly style: data stays Mont256, twiddle is Mont261
+      f29 d = f29_unpack(a + 8 * i), w = f29_from_mont256<F>(b + 8 * i);
+      f29 r = f29_reduce_canonical<F>(f29_mul<F>(d, w));
+      f29_pack(r, out + 8 * i);
+    } else if (mode == 2) {  // lazy chain: (a + b) * (a - b + 2p) with un-normalized first operand
+      f29 x = f29_from_mont256<F>(a + 8 * i), y = f29_from_mont256<F>(b + 8 * i);
+      f29 s = f29_normalize(f29_add(x, y));
+      f29 d = f29_sub(x, y, F::K2);
+      f29_to_mont256<F>(f29_mul<F>(d, s), out + 8 * i);
+    } else {  // pack(unpack(x)) round trip
+      f29 x = f29_unpack(a + 8 * i);
+      f29_pack(x, out + 8 * i);
+    }
+  }
+}
+
+extern "C" {
+void f29t_mul(int field, int mode, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  if (field == 0) mul_words<Fq29>(a, b, out, n, mode);
+  else mul_words<Fr29>(a, b, out, n, mode);
+}
+
+// accumulate n affine points (Mont256, 16 words each; (0,0) skipped) with signs[i] != 0 meaning -P_i;
+// writes the XYZZ result as 4 x 8 words Mont256 (canonical)
+void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz) {
+  xyzz29 acc = xyzz29_identity();
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t* p = pts + 16 * i;
+    bool id = true;
+    for (int k = 0; k < 16; k++) id = id && p[k] == 0;
+    if (id) continue;
+    // table format: canonical Mont261 packed words
+    uint32_t xw[8], yw[8];
+    f29 x = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p));
+    f29 y = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p + 8));
+    f29_pack(x, xw);
+    f29_pack(y, yw);
+    f29 x2 = f29_unpack(xw), y2 = f29_unpack(yw);
+    if (signs[i]) y2 = f29_sub(f29_zero(), y2, Fq29::K2);
+    xyzz29_madd(acc, x2, y2);
+  }
+  if (xyzz29_is_identity(acc)) {
+    memset(out_xyzz, 0, 128);
+    return;
+  }
+  f29_to_mont256<Fq29>(acc.x, out_xyzz);
+  f29_to_mont256<Fq29>(acc.y, out_xyzz + 8);
+  f29_to_mont256<Fq29>(acc.zz, out_xyzz + 16);
+  f29_to_mont256<Fq29>(acc.zzz, out_xyzz + 24);
+}
+}

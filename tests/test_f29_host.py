@@ -1,0 +1,92 @@
+"""CPU tests of the lazy 29-bit-limb field / curve layer (csrc/f29.cuh, g1_29.cuh) compiled with g++.
+
+The GPU kernels inline exactly this code; verifying it on the host against the big-integer oracle
+covers limb bounds, the Mont256 <-> Mont261 conversions and every special case of the mixed addition
+without needing a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host", "f29_host.cpp")
+SO = os.path.join(ROOT, "tests", "host", "libf29host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    deps = [SRC] + [os.path.join(ROOT, "halo2-scaffold_amd", "csrc", f) for f in ("f29.cuh", "g1_29.cuh", "f29_consts.inc")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+    L = C.CDLL(SO)
+    L.f29t_mul.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.f29t_madd_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return L
+
+
+def test_generated_constants_are_current():
+    gen = subprocess.check_output(["python", os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "gen_f29_consts.py")], text=True)
+    assert gen == open(os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "f29_consts.inc")).read()
+
+
+def _edge(mod):
+    return [0, 1, 2, mod - 1, mod - 2, (1 << 253) % mod, (1 << 232) - 1, 1 << 232, (1 << 29) - 1, 1 << 29, ((1 << 254) - 1) % mod]
+
+
+@pytest.mark.parametrize("field,mod", [(0, o.Q), (1, o.R)])
+def test_f29_mul_modes(host, field, mod):
+    rng = np.random.default_rng(7 + field)
+    vals_a = _edge(mod) + [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(3000)]
+    vals_b = list(reversed(_edge(mod))) + [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(3000)]
+    n = len(vals_a)
+    A, B = o.pack(vals_a, mod), o.pack(vals_b, mod)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    host.f29t_mul(field, 0, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+    assert o.unpack(out, mod) == [x * y % mod for x, y in zip(vals_a, vals_b)]
+    host.f29t_mul(field, 1, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+    assert o.unpack(out, mod) == [x * y % mod for x, y in zip(vals_a, vals_b)]
+    host.f29t_mul(field, 2, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+    assert o.unpack(out, mod) == [(x + y) * (x - y) % mod for x, y in zip(vals_a, vals_b)]
+    host.f29t_mul(field, 3, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+    assert np.array_equal(out, A)
+    assert all(v < mod for v in o.unpack(out))
+
+
+def _xyzz_to_affine(out):
+    X, Y, ZZ, ZZZ = (o.limbs_to_int(out[4 * i : 4 * i + 4]) * pow(o.MONT_R, -1, o.Q) % o.Q for i in range(4))
+    if ZZ == 0:
+        return None
+    assert pow(ZZ, 3, o.Q) == ZZZ * ZZZ % o.Q
+    return (X * pow(ZZ, -1, o.Q) % o.Q, Y * pow(ZZZ, -1, o.Q) % o.Q)
+
+
+def _chain(host, pts, signs):
+    P = o.pack_points(pts)
+    S = np.array(signs, dtype=np.uint8)
+    out = np.zeros(16, dtype=np.uint64)
+    host.f29t_madd_chain(P.ctypes.data, S.ctypes.data, len(pts), out.ctypes.data)
+    want = None
+    for p, s in zip(pts, signs):
+        want = o.g1_add(want, o.g1_neg(p) if s else p)
+    assert _xyzz_to_affine(out) == want
+
+
+def test_madd_chain_random_and_special_cases(host):
+    rng = np.random.default_rng(3)
+    pts = [o.g1_mul(int(rng.integers(1, 1 << 62)), o.G1_GEN) for _ in range(200)]
+    signs = [int(rng.integers(0, 2)) for _ in pts]
+    _chain(host, pts, signs)                      # long chain: the accumulator invariants must hold
+    _chain(host, pts[:1], [1])                    # single negated point
+    _chain(host, [pts[0], pts[0]], [0, 0])        # P + P  (doubling branch)
+    _chain(host, [pts[0], pts[0]], [1, 1])        # (-P) + (-P)
+    _chain(host, [pts[0], pts[0]], [0, 1])        # P - P = identity
+    _chain(host, [pts[0], pts[0], pts[1]], [0, 1, 0])      # identity then restart
+    _chain(host, [pts[0], pts[0], pts[0], pts[0]], [0, 0, 0, 0])  # 2P then +P then +P
+    _chain(host, [None, pts[2], None, pts[3]], [0, 0, 1, 1])      # identity table entries skipped
+    _chain(host, [o.G1_GEN] * 33, [0] * 33)       # n*G: first addition doubles, rest are generic
+    big = [o.g1_mul(o.R - 1 - i, o.G1_GEN) for i in range(5)]
+    _chain(host, big + pts[:5], [0] * 10)
