@@ -140,9 +140,38 @@ H2_HD f29 f29_mul(const f29& a, const f29& b) {
   t.v[8] = (uint32_t)acc;
   return t;
 }
+// a^2 / 2^261: the 36 cross products are taken once against 2a (limbs < 2^30) instead of twice,
+// 45 + 81 multiply-adds instead of 162.  Requires a normalized (limbs < 2^29).
 template <class F>
 H2_HD f29 f29_sqr(const f29& a) {
-  return f29_mul<F>(a, a);
+  uint32_t m[9], a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) a2[i] = a.v[i] << 1;
+  f29 t;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int j = 0; 2 * j < k; j++) acc += (uint64_t)a.v[j] * a2[k - j];
+    if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+    for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P[k - j];
+    m[k] = ((uint32_t)acc * F::INV) & M29;
+    acc += (uint64_t)m[k] * F::P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int j = k - 8; 2 * j < k; j++) acc += (uint64_t)a.v[j] * a2[k - j];
+    if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+    for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * F::P[k - j];
+    t.v[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  t.v[8] = (uint32_t)acc;
+  return t;
 }
 
 // x (normalized, value < 2p) -> canonical [0, p)

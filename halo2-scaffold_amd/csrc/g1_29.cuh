@@ -91,4 +91,64 @@ H2_HD void xyzz29_madd(xyzz29& acc, const f29& x2, const f29& y2) {
   acc.zzz = f29_mul<F>(acc.zzz, ppp);
 }
 
+// 2 * p (XYZZ, dbl-2008-s-1).  Invariant in / out: X < 6, Y < 4, ZZ, ZZZ < 1.5 (units of p), normalized.
+//   U = 2Y < 8    V = U^2 < 1.38    W = U*V < 1.07    S = X*V < 1.05    M = 3X^2 < 3.64
+//   X3 = M^2 - 2S + 4p < 5.1    T = S - X3 + 6p < 7.1    Y3 = M*T - W*Y + 2p < 3.2    ZZ3, ZZZ3 < 1.02
+H2_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
+  using F = Fq29;
+  if (xyzz29_is_identity(p)) return p;
+  xyzz29 r;
+  f29 u = f29_normalize(f29_dbl(p.y));
+  f29 v = f29_sqr<F>(u);
+  f29 w = f29_mul<F>(u, v);
+  f29 s = f29_mul<F>(p.x, v);
+  f29 xx = f29_sqr<F>(p.x);
+  f29 m = f29_normalize(f29_add(f29_dbl(xx), xx));
+  f29 mm = f29_sqr<F>(m);
+  r.x = f29_normalize(f29_sub(mm, f29_dbl(s), F::KW4));
+  f29 t = f29_sub(s, r.x, F::K6);
+  f29 t1 = f29_mul<F>(t, m);
+  f29 t2 = f29_mul<F>(w, p.y);
+  r.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  r.zz = f29_mul<F>(v, p.zz);
+  r.zzz = f29_mul<F>(w, p.zzz);
+  return r;
+}
+
+// a += b (both XYZZ, add-2008-s, complete).  Same invariant as xyzz29_dbl.
+//   U1, U2 < 1.06   S1, S2 < 1.04   P = U2 - U1 + 2p < 3.1   R = S2 - S1 + 2p < 3.1
+//   PP < 1.06  PPP < 1.02  Q = U1*PP < 1.01  X3 = R^2 - PPP - 2Q + 4p < 5.1
+//   T = Q - X3 + 6p < 7.1   Y3 = R*T - S1*PPP + 2p < 3.2
+H2_HD void xyzz29_add(xyzz29& a, const xyzz29& b) {
+  using F = Fq29;
+  if (xyzz29_is_identity(b)) return;
+  if (xyzz29_is_identity(a)) { a = b; return; }
+  f29 u1 = f29_mul<F>(a.x, b.zz);
+  f29 u2 = f29_mul<F>(b.x, a.zz);
+  f29 s1 = f29_mul<F>(a.y, b.zzz);
+  f29 s2 = f29_mul<F>(b.y, a.zzz);
+  f29 p = f29_normalize(f29_sub(u2, u1, F::K2));
+  f29 r = f29_normalize(f29_sub(s2, s1, F::K2));
+  f29 pp = f29_sqr<F>(p);
+  if (f29_is_zero_mod<F>(pp)) {
+    f29 rr0 = f29_sqr<F>(r);
+    if (f29_is_zero_mod<F>(rr0)) a = xyzz29_dbl(a);
+    else a = xyzz29_identity();
+    return;
+  }
+  f29 ppp = f29_mul<F>(p, pp);
+  f29 q = f29_mul<F>(u1, pp);
+  f29 rr = f29_sqr<F>(r);
+  f29 x3 = f29_normalize(f29_sub(rr, f29_add(ppp, f29_dbl(q)), F::KW4));
+  f29 t = f29_sub(q, x3, F::K6);
+  f29 t1 = f29_mul<F>(t, r);
+  f29 t2 = f29_mul<F>(s1, ppp);
+  f29 zz = f29_mul<F>(f29_mul<F>(a.zz, b.zz), pp);
+  f29 zzz = f29_mul<F>(f29_mul<F>(a.zzz, b.zzz), ppp);
+  a.x = x3;
+  a.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  a.zz = zz;
+  a.zzz = zzz;
+}
+
 }  // namespace h2

@@ -172,6 +172,31 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* counts, uint3
   if (tid == 1023) off[nb] = sums[1023];
 }
 
+// Partial bucket sums travel between the MSM kernels as raw xyzz29 values (4 x 9 normalized limbs =
+// 144 B, Montgomery-2^261, loosely reduced): no conversion until the final result.
+constexpr uint32_t PART_BYTES = 144;
+__device__ __forceinline__ xyzz29 part_load(const uint8_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  xyzz29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { r.x.v[i] = w[i]; r.y.v[i] = w[9 + i]; r.zz.v[i] = w[18 + i]; r.zzz.v[i] = w[27 + i]; }
+  return r;
+}
+__device__ __forceinline__ void part_store(uint8_t* p, const xyzz29& a) {
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { w[i] = a.x.v[i]; w[9 + i] = a.y.v[i]; w[18 + i] = a.zz.v[i]; w[27 + i] = a.zzz.v[i]; }
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 // largest b with toff[b] <= t (toff has nb+1 monotone entries, toff[nb] = total > t)
 __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t nb, uint32_t t) {
   uint32_t lo = 0, hi = nb;  // invariant: toff[lo] <= t < toff[hi]
@@ -198,8 +223,7 @@ __global__ void __launch_bounds__(256) k_msm_table_to261(uint8_t* table, size_t 
 }
 
 // level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
-// accumulates with mixed additions in the lazy 29-bit-limb representation (g1_29.cuh).  The partial
-// sum is written back in the standard XYZZ / Montgomery-2^256 format the later kernels use.
+// accumulates with mixed additions in the lazy 29-bit-limb representation (g1_29.cuh).
 __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* hist, const uint32_t* toff,
                                                     uint32_t nb, const uint8_t* table, uint8_t* part) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,16 +250,7 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
     if (neg) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
     xyzz29_madd(acc, x2, y2);
   }
-  xyzz out;
-  if (xyzz29_is_identity(acc)) {
-    out = xyzz_identity();
-  } else {
-    f29_to_mont256<Fq29>(acc.x, out.x.v);
-    f29_to_mont256<Fq29>(acc.y, out.y.v);
-    f29_to_mont256<Fq29>(acc.zz, out.zz.v);
-    f29_to_mont256<Fq29>(acc.zzz, out.zzz.v);
-  }
-  xyzz_store(part + (size_t)t * 128, out);
+  part_store(part + (size_t)t * PART_BYTES, acc);
 }
 
 // fold level: one thread per task of <= S1 partials of one bucket
@@ -247,34 +262,34 @@ __global__ void __launch_bounds__(256) k_msm_fold(const uint8_t* pin, const uint
   uint32_t j = t - toff_out[b];
   uint32_t start = toff_in[b] + j * S1;
   uint32_t len = min(S1, np_in[b] - j * S1);
-  xyzz acc = xyzz_load(pin + (size_t)start * 128);
+  xyzz29 acc = part_load(pin + (size_t)start * PART_BYTES);
   for (uint32_t k = 1; k < len; k++) {
-    xyzz p = xyzz_load(pin + (size_t)(start + k) * 128);
-    xyzz_add(acc, p);
+    xyzz29 p = part_load(pin + (size_t)(start + k) * PART_BYTES);
+    xyzz29_add(acc, p);
   }
-  xyzz_store(pout + (size_t)t * 128, acc);
+  part_store(pout + (size_t)t * PART_BYTES, acc);
 }
 
-__device__ __forceinline__ xyzz load_bucket(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t b) {
+__device__ __forceinline__ xyzz29 load_bucket(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t b) {
   uint32_t cnt = np[b];
-  if (cnt == 0) return xyzz_identity();
+  if (cnt == 0) return xyzz29_identity();
   uint32_t s = toff[b];
-  xyzz acc = xyzz_load(part + (size_t)s * 128);
+  xyzz29 acc = part_load(part + (size_t)s * PART_BYTES);
   for (uint32_t k = 1; k < cnt; k++) {  // only adversarial inputs (one bucket > S0*S1*S1 points) get here
-    xyzz p = xyzz_load(part + (size_t)(s + k) * 128);
-    xyzz_add(acc, p);
+    xyzz29 p = part_load(part + (size_t)(s + k) * PART_BYTES);
+    xyzz29_add(acc, p);
   }
   return acc;
 }
 
 // block-wide tree sum of up to 256 XYZZ values held in LDS
-__device__ __forceinline__ void block_tree_sum(xyzz* lds, uint32_t count_pow2) {
+__device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2) {
   const uint32_t tid = threadIdx.x;
   for (uint32_t s = count_pow2 >> 1; s > 0; s >>= 1) {
     if (tid < s) {
-      xyzz a = lds[tid];
-      xyzz b = lds[tid + s];
-      xyzz_add(a, b);
+      xyzz29 a = lds[tid];
+      xyzz29 b = lds[tid + s];
+      xyzz29_add(a, b);
       lds[tid] = a;
     }
     __syncthreads();
@@ -286,10 +301,10 @@ extern __shared__ uint4 h2_msm_smem[];
 // bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
 __global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t logNh, uint32_t logNl,
                                                      uint8_t* rc) {
-  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
-  xyzz v = xyzz_identity();
+  xyzz29 v = xyzz29_identity();
   if (blk < Nh) {
     if (tid < Nl) v = load_bucket(part, toff, np, (blk << logNl) + tid);
   } else {
@@ -298,45 +313,55 @@ __global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* part, const u
   lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, 256);
-  if (tid == 0) xyzz_store(rc + (size_t)blk * 128, lds[0]);
+  if (tid == 0) part_store(rc + (size_t)blk * PART_BYTES, lds[0]);
 }
 
 // bit-decomposed weights: block beta < logNh sums rows with bit beta of hi set; block logNh + beta sums
 // columns with bit beta of (lo+1) set (beta <= logNl).
 __global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_t logNh, uint32_t logNl, uint8_t* g) {
-  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
-  xyzz v = xyzz_identity();
+  xyzz29 v = xyzz29_identity();
   if (blk < logNh) {
-    if (tid < Nh && ((tid >> blk) & 1u)) v = xyzz_load(rc + (size_t)tid * 128);
+    if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(rc + (size_t)tid * PART_BYTES);
   } else {
     uint32_t beta = blk - logNh;
-    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = xyzz_load(rc + (size_t)(Nh + tid) * 128);
+    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(rc + (size_t)(Nh + tid) * PART_BYTES);
   }
   lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, 256);
-  if (tid == 0) xyzz_store(g + (size_t)blk * 128, lds[0]);
+  if (tid == 0) part_store(g + (size_t)blk * PART_BYTES, lds[0]);
 }
 
-// result = sum_beta 2^(beta + logNl) G_row[beta] + sum_beta 2^beta G_col[beta]
+// result = sum_beta 2^(beta + logNl) G_row[beta] + sum_beta 2^beta G_col[beta], returned as a Jacobian
+// point in the ABI's Montgomery-2^256 form: (X*ZZ, Y*ZZZ, ZZ) since ZZ^3 = ZZZ^2; identity = (0, R, 0).
 __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t logNh, uint32_t logNl, uint8_t* out_jac, const uint32_t* off,
                                                    uint32_t nb, uint64_t* stats) {
-  xyzz* lds = reinterpret_cast<xyzz*>(h2_msm_smem);
+  xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t tid = threadIdx.x;
   const uint32_t terms = logNh + logNl + 1;
-  xyzz v = xyzz_identity();
+  xyzz29 v = xyzz29_identity();
   if (tid < terms) {
-    v = xyzz_load(g + (size_t)tid * 128);
+    v = part_load(g + (size_t)tid * PART_BYTES);
     uint32_t shift = tid < logNh ? tid + logNl : tid - logNh;
-    for (uint32_t k = 0; k < shift; k++) v = xyzz_dbl(v);
+    for (uint32_t k = 0; k < shift; k++) v = xyzz29_dbl(v);
   }
   lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, 64);
   if (tid == 0) {
-    jac_store(out_jac, xyzz_to_jac(lds[0]));
+    xyzz29 r = lds[0];
+    jac j;
+    if (xyzz29_is_identity(r)) {
+      j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
+    } else {
+      f29_to_mont256<Fq29>(f29_mul<Fq29>(r.x, r.zz), j.x.v);
+      f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
+      f29_to_mont256<Fq29>(r.zz, j.z.v);
+    }
+    jac_store(out_jac, j);
     if (stats) stats[0] = off[nb];
   }
 }
@@ -412,10 +437,10 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
       H2_ALLOC(S.np[i], (size_t)B->nb * 4);
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
     }
-    H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * 128);
-    H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * 128);
-    H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * 128);
-    H2_ALLOC(S.g, (size_t)64 * 128);
+    H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * PART_BYTES);
+    H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * PART_BYTES);
+    H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * PART_BYTES);
+    H2_ALLOC(S.g, (size_t)64 * PART_BYTES);
     H2_ALLOC(S.stats, 64);
     if (hipEventCreateWithFlags(&S.accum_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming) != hipSuccess) {
@@ -496,10 +521,10 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
             (const uint32_t*)S.np[1], (const uint32_t*)S.toff[2], nb, S.part[0]);
   // weighted bucket sum
   const uint32_t Nh = 1u << B->logNh, Nl = 1u << B->logNl;
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * 128, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[2],
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * PART_BYTES, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[2],
             (const uint32_t*)S.np[2], B->logNh, B->logNl, S.rc);
-  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * 128, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
-  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * 128, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * PART_BYTES, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
+  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * PART_BYTES, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
             nb, S.stats);
   H2_HIP(hipEventRecord(S.tail_done, t));
   S.tail_pending = true;

@@ -24,6 +24,9 @@ static void mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out, size_
       f29 s = f29_normalize(f29_add(x, y));
       f29 d = f29_sub(x, y, F::K2);
       f29_to_mont256<F>(f29_mul<F>(d, s), out + 8 * i);
+    } else if (mode == 4) {  // dedicated squaring of a normalized input
+      f29 x = f29_from_mont256<F>(a + 8 * i);
+      f29_to_mont256<F>(f29_sqr<F>(x), out + 8 * i);
     } else {  // pack(unpack(x)) round trip
       f29 x = f29_unpack(a + 8 * i);
       f29_pack(x, out + 8 * i);
@@ -39,9 +42,9 @@ void f29t_mul(int field, int mode, const uint32_t* a, const uint32_t* b, uint32_
 
 // accumulate n affine points (Mont256, 16 words each; (0,0) skipped) with signs[i] != 0 meaning -P_i;
 // writes the XYZZ result as 4 x 8 words Mont256 (canonical)
-void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz) {
+void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz, int tree) {
   xyzz29 acc = xyzz29_identity();
-  for (size_t i = 0; i < n; i++) {
+  for (size_t i = 0; i < (tree ? 0 : n); i++) {
     const uint32_t* p = pts + 16 * i;
     bool id = true;
     for (int k = 0; k < 16; k++) id = id && p[k] == 0;
@@ -55,6 +58,36 @@ void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32
     f29 x2 = f29_unpack(xw), y2 = f29_unpack(yw);
     if (signs[i]) y2 = f29_sub(f29_zero(), y2, Fq29::K2);
     xyzz29_madd(acc, x2, y2);
+  }
+  if (tree) {
+    // exercise the full XYZZ addition / doubling: split the points into `tree` groups, accumulate each
+    // with mixed additions, then fold the group sums pairwise (and double-check 2S = S + S)
+    xyzz29 groups[16];
+    for (int g = 0; g < tree; g++) groups[g] = xyzz29_identity();
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t* p = pts + 16 * i;
+      bool id = true;
+      for (int k = 0; k < 16; k++) id = id && p[k] == 0;
+      if (id) continue;
+      uint32_t xw[8], yw[8];
+      f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p)), xw);
+      f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p + 8)), yw);
+      f29 x2 = f29_unpack(xw), y2 = f29_unpack(yw);
+      if (signs[i]) y2 = f29_sub(f29_zero(), y2, Fq29::K2);
+      xyzz29_madd(groups[i % tree], x2, y2);
+    }
+    for (int stride = 1; stride < tree; stride *= 2)
+      for (int g = 0; g + stride < tree; g += 2 * stride) xyzz29_add(groups[g], groups[g + stride]);
+    acc = groups[0];
+    if (tree == 16) {  // (S + S) - via add's doubling branch - then + (-2S) computed by dbl ... keep S: S + S - S - S + S
+      xyzz29 s2 = acc;
+      xyzz29_add(s2, acc);              // doubling branch of add
+      xyzz29 d = xyzz29_dbl(acc);       // explicit doubling
+      d.y = f29_normalize(f29_sub(f29_zero(), d.y, Fq29::K4));  // -2S
+      xyzz29_add(s2, d);                // 2S + (-2S) = identity
+      xyzz29_add(s2, acc);              // identity + S = S
+      acc = s2;
+    }
   }
   if (xyzz29_is_identity(acc)) {
     memset(out_xyzz, 0, 128);

@@ -24,7 +24,7 @@ def host():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     L = C.CDLL(SO)
     L.f29t_mul.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-    L.f29t_madd_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.f29t_madd_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     return L
 
 
@@ -51,6 +51,8 @@ def test_f29_mul_modes(host, field, mod):
     assert o.unpack(out, mod) == [x * y % mod for x, y in zip(vals_a, vals_b)]
     host.f29t_mul(field, 2, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
     assert o.unpack(out, mod) == [(x + y) * (x - y) % mod for x, y in zip(vals_a, vals_b)]
+    host.f29t_mul(field, 4, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+    assert o.unpack(out, mod) == [x * x % mod for x in vals_a]
     host.f29t_mul(field, 3, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
     assert np.array_equal(out, A)
     assert all(v < mod for v in o.unpack(out))
@@ -64,11 +66,11 @@ def _xyzz_to_affine(out):
     return (X * pow(ZZ, -1, o.Q) % o.Q, Y * pow(ZZZ, -1, o.Q) % o.Q)
 
 
-def _chain(host, pts, signs):
+def _chain(host, pts, signs, tree=0):
     P = o.pack_points(pts)
     S = np.array(signs, dtype=np.uint8)
     out = np.zeros(16, dtype=np.uint64)
-    host.f29t_madd_chain(P.ctypes.data, S.ctypes.data, len(pts), out.ctypes.data)
+    host.f29t_madd_chain(P.ctypes.data, S.ctypes.data, len(pts), out.ctypes.data, tree)
     want = None
     for p, s in zip(pts, signs):
         want = o.g1_add(want, o.g1_neg(p) if s else p)
@@ -90,3 +92,16 @@ def test_madd_chain_random_and_special_cases(host):
     _chain(host, [o.G1_GEN] * 33, [0] * 33)       # n*G: first addition doubles, rest are generic
     big = [o.g1_mul(o.R - 1 - i, o.G1_GEN) for i in range(5)]
     _chain(host, big + pts[:5], [0] * 10)
+
+
+def test_full_add_and_double_trees(host):
+    """XYZZ + XYZZ additions (the fold / bucket-reduction kernels) incl. doubling and cancellation branches."""
+    rng = np.random.default_rng(11)
+    pts = [o.g1_mul(int(rng.integers(1, 1 << 62)), o.G1_GEN) for _ in range(300)]
+    signs = [int(rng.integers(0, 2)) for _ in pts]
+    for tree in (2, 4, 8, 16):
+        _chain(host, pts, signs, tree)
+        _chain(host, pts[:tree], signs[:tree], tree)          # one point per group
+        _chain(host, pts[:3], signs[:3], tree)                # mostly empty groups (identity operands)
+    _chain(host, [pts[0]] * 16, [0] * 16, 16)                 # all groups equal: every fold step doubles
+    _chain(host, [pts[0], pts[0]], [0, 1], 2)                 # groups cancel
