@@ -82,6 +82,18 @@ __global__ void k_g1_sum_jac(const uint8_t* pts, size_t k, uint8_t* out) {
   jac_store(out, xyzz_to_jac(acc));
 }
 
+// out[j] = sum over r < world of pts[r*k + j]  (rank-major partial results of k MSMs)
+__global__ void __launch_bounds__(64) k_g1_fold_groups(const uint8_t* pts, size_t world, size_t k, uint8_t* out) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  xyzz acc = xyzz_identity();
+  for (size_t r = 0; r < world; r++) {
+    xyzz p = jac_to_xyzz(jac_load(pts + (r * k + j) * 96));
+    xyzz_add(acc, p);
+  }
+  jac_store(out + j * 96, xyzz_to_jac(acc));
+}
+
 __global__ void __launch_bounds__(256) k_g1_normalize(const uint8_t* pts, size_t k, uint8_t* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
@@ -335,6 +347,23 @@ int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian
   H2_HIP(hipMemcpyAsync(dp, points, k * 96, hipMemcpyHostToDevice, s));
   H2_LAUNCH("k_g1_sum_jac", k_g1_sum_jac, 1, 64, 0, s, dp, k, dout);
   H2_HIP(hipMemcpyAsync(out_jacobian, dout, 96, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  hipFree(dp);
+  hipFree(dout);
+  return H2MI_OK;
+}
+
+int h2mi_g1_fold_groups(const uint64_t* points, size_t world, size_t k, uint64_t* out) {
+  H2_REQUIRE_INIT();
+  if (!points || !out || world == 0 || k == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  uint8_t *dp = nullptr, *dout = nullptr;
+  H2_HIP(hipMalloc(&dp, world * k * 96));
+  H2_HIP(hipMalloc(&dout, k * 96));
+  H2_HIP(hipMemcpyAsync(dp, points, world * k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_fold_groups", k_g1_fold_groups, ceil_div_u32(k, 64), 64, 0, s, dp, world, k, dout);
+  H2_HIP(hipMemcpyAsync(out, dout, k * 96, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
   hipFree(dp);
   hipFree(dout);

@@ -29,8 +29,9 @@
 
 namespace h2 {
 
-constexpr uint32_t S0 = 64;  // points per accumulation task
-constexpr uint32_t S1 = 32;  // partials per fold task
+constexpr uint32_t S0_MAX = 64;  // points per accumulation task (smaller for small problems: see pick_chunk)
+constexpr uint32_t S1 = 8;       // partials per fold task
+constexpr uint32_t FG = 8;       // lanes that cooperate on one bucket in k_msm_finish
 
 // per-call workspace; two slots per handle so that the latency-bound tail of one MSM (fold, bucket
 // reduction) runs on the tail stream while the next MSM's sort and accumulation already run.
@@ -40,9 +41,11 @@ struct Slot {
   void* sort_tmp = nullptr;
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
-  uint32_t* np[3] = {nullptr, nullptr, nullptr};    // partial counts per bucket after level 0,1,2
-  uint32_t* toff[3] = {nullptr, nullptr, nullptr};  // task offsets (nb+1)
-  uint8_t* part[2] = {nullptr, nullptr};            // XYZZ partial buffers (ping-pong)
+  uint32_t* np[3] = {nullptr, nullptr, nullptr};    // tasks per bucket: accumulation, fold 1, fold 2 (nb+1 entries, last = 0)
+  uint32_t* toff[3] = {nullptr, nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
+  void* scan_tmp = nullptr;
+  uint8_t* part[2] = {nullptr, nullptr};   // XYZZ partial buffers: accumulation output, fold output
+  uint8_t* dense = nullptr;                // one XYZZ sum per bucket
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
   uint8_t* g = nullptr;                             // weighted partials (<= 32)
   uint64_t* stats = nullptr;                        // [0] = insertions
@@ -55,7 +58,7 @@ struct Bases {
   size_t n = 0;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
-  size_t sort_tmp_bytes = 0;
+  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
   Slot slot[NSLOT];
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0, max_tasks2 = 0;
@@ -113,8 +116,10 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n,
   }
 }
 
-// bucket boundaries in the sorted key array: off[b] = first index with key >= b, hist[b] = run length
-__global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32_t total, uint32_t nb, uint32_t* off, uint32_t* hist) {
+// bucket boundaries in the sorted key array: off[b] = first index with key >= b, hist[b] = run length;
+// also the task counts of the accumulation (chunks of 2^ls0 entries) and of the fold (chunks of S1 partials)
+__global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32_t total, uint32_t nb, uint32_t ls0, uint32_t* off, uint32_t* hist,
+                                                     uint32_t* np0, uint32_t* np1, uint32_t* np2) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > nb) return;
   uint32_t lo = 0, hi = total;  // first index with key >= b
@@ -124,6 +129,7 @@ __global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32
     else hi = mid;
   }
   off[b] = lo;
+  uint32_t cnt = 0;
   if (b < nb) {
     uint32_t lo2 = lo, hi2 = total;
     while (lo2 < hi2) {
@@ -131,45 +137,14 @@ __global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32
       if (keys[mid] < b + 1) lo2 = mid + 1;
       else hi2 = mid;
     }
-    hist[b] = lo2 - lo;
+    cnt = lo2 - lo;
+    hist[b] = cnt;
   }
-}
-
-// single-block exclusive scan of f(count) = ceil(count / chunk) over nb entries, staged through LDS
-// (coalesced global access, padded so that a thread's contiguous run is bank-conflict free);
-// writes np[b] = f(count[b]) and off[0..nb] (off[nb] = total).
-extern __shared__ uint32_t h2_scan_smem[];
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* counts, uint32_t nb, uint32_t chunk, uint32_t* np, uint32_t* off) {
-  __shared__ uint32_t sums[1024];
-  uint32_t* s = h2_scan_smem;
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < nb; i += 1024) {
-    uint32_t f = (counts[i] + chunk - 1) / chunk;
-    if (np) np[i] = f;
-    s[i + (i >> 5)] = f;
-  }
-  __syncthreads();
-  const uint32_t per = (nb + 1023) / 1024;
-  uint32_t b0 = tid * per, b1 = min(b0 + per, nb);
-  uint32_t local = 0;
-  for (uint32_t b = b0; b < b1; b++) local += s[b + (b >> 5)];
-  sums[tid] = local;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t v = (tid >= d) ? sums[tid - d] : 0;
-    __syncthreads();
-    sums[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = sums[tid] - local;
-  for (uint32_t b = b0; b < b1; b++) {
-    uint32_t f = s[b + (b >> 5)];
-    s[b + (b >> 5)] = run;
-    run += f;
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < nb; i += 1024) off[i] = s[i + (i >> 5)];
-  if (tid == 1023) off[nb] = sums[1023];
+  uint32_t f0 = (cnt + (1u << ls0) - 1) >> ls0;
+  np0[b] = f0;                    // entry nb = 0: the scans then leave the totals in toff[nb]
+  uint32_t f1 = (f0 + S1 - 1) / S1;
+  np1[b] = f1;
+  np2[b] = (f1 + S1 - 1) / S1;
 }
 
 // Partial bucket sums travel between the MSM kernels as raw xyzz29 values (4 x 9 normalized limbs =
@@ -225,7 +200,7 @@ __global__ void __launch_bounds__(256) k_msm_table_to261(uint8_t* table, size_t 
 // level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
 // accumulates with mixed additions in the lazy 29-bit-limb representation (g1_29.cuh).
 __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* hist, const uint32_t* toff,
-                                                    uint32_t nb, const uint8_t* table, uint8_t* part) {
+                                                    uint32_t nb, uint32_t S0, const uint8_t* table, uint8_t* part) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= toff[nb]) return;
   uint32_t b = find_bucket(toff, nb, t);
@@ -270,16 +245,35 @@ __global__ void __launch_bounds__(256) k_msm_fold(const uint8_t* pin, const uint
   part_store(pout + (size_t)t * PART_BYTES, acc);
 }
 
-__device__ __forceinline__ xyzz29 load_bucket(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t b) {
-  uint32_t cnt = np[b];
-  if (cnt == 0) return xyzz29_identity();
-  uint32_t s = toff[b];
-  xyzz29 acc = part_load(part + (size_t)s * PART_BYTES);
-  for (uint32_t k = 1; k < cnt; k++) {  // only adversarial inputs (one bucket > S0*S1*S1 points) get here
-    xyzz29 p = part_load(part + (size_t)(s + k) * PART_BYTES);
-    xyzz29_add(acc, p);
+// bucket finish: FG lanes cooperate on one bucket: lane l sums partials l, l+FG, ... (one partial each in
+// the common case), then a log2(FG)-level shuffle tree; writes one dense XYZZ value per bucket.
+__device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta) {
+  xyzz29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.v[i] = __shfl_down(a.x.v[i], delta);
+    r.y.v[i] = __shfl_down(a.y.v[i], delta);
+    r.zz.v[i] = __shfl_down(a.zz.v[i], delta);
+    r.zzz.v[i] = __shfl_down(a.zzz.v[i], delta);
   }
-  return acc;
+  return r;
+}
+__global__ void __launch_bounds__(256) k_msm_finish(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t nb, uint8_t* dense) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t b = t / FG, l = t % FG;
+  xyzz29 acc = xyzz29_identity();
+  if (b < nb) {
+    uint32_t cnt = np[b], s = toff[b];
+    for (uint32_t k = l; k < cnt; k += FG) {
+      xyzz29 p = part_load(part + (size_t)(s + k) * PART_BYTES);
+      xyzz29_add(acc, p);
+    }
+  }
+  for (uint32_t d = FG / 2; d > 0; d >>= 1) {
+    xyzz29 o = shfl_down_xyzz(acc, d);
+    if (l < d) xyzz29_add(acc, o);
+  }
+  if (b < nb && l == 0) part_store(dense + (size_t)b * PART_BYTES, acc);
 }
 
 // block-wide tree sum of up to 256 XYZZ values held in LDS
@@ -299,20 +293,19 @@ __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2)
 extern __shared__ uint4 h2_msm_smem[];
 
 // bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
-__global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t logNh, uint32_t logNl,
-                                                     uint8_t* rc) {
+__global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* dense, uint32_t logNh, uint32_t logNl, uint8_t* rc) {
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
   xyzz29 v = xyzz29_identity();
   if (blk < Nh) {
-    if (tid < Nl) v = load_bucket(part, toff, np, (blk << logNl) + tid);
+    if (tid < Nl) v = part_load(dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
   } else {
-    if (tid < Nh) v = load_bucket(part, toff, np, (tid << logNl) + (blk - Nh));
+    if (tid < Nh) v = part_load(dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
   }
   lds[tid] = v;
   __syncthreads();
-  block_tree_sum(lds, 256);
+  block_tree_sum(lds, max(Nh, Nl));
   if (tid == 0) part_store(rc + (size_t)blk * PART_BYTES, lds[0]);
 }
 
@@ -331,7 +324,7 @@ __global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_
   }
   lds[tid] = v;
   __syncthreads();
-  block_tree_sum(lds, 256);
+  block_tree_sum(lds, max(Nh, Nl));
   if (tid == 0) part_store(g + (size_t)blk * PART_BYTES, lds[0]);
 }
 
@@ -350,7 +343,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t log
   }
   lds[tid] = v;
   __syncthreads();
-  block_tree_sum(lds, 64);
+  block_tree_sum(lds, 32);  // terms <= 17
   if (tid == 0) {
     xyzz29 r = lds[0];
     jac j;
@@ -375,11 +368,23 @@ static uint32_t pick_window(size_t n) {
   }
   uint32_t lg = 0;
   while (((size_t)1 << lg) < n) lg++;
-  // buckets 2^(c-1) ~ n/32 keeps the bucket phase small against n*W point additions
-  int c = (int)lg - 4;
-  if (c < 6) c = 6;
-  if (c > 16) c = 16;
+  // Larger windows mean fewer point additions (n * ceil(256/c)); the bucket phase is latency-bound and
+  // nearly independent of the bucket count.  Only windows whose TOP window still holds many scalar bits
+  // are used (254 mod c large): c = 12 or 14 leave 2 bits there, i.e. four buckets that each receive n/4
+  // points.
+  int c = lg >= 20 ? 16 : lg >= 18 ? 15 : 13;
   return (uint32_t)c;
+}
+
+// points per accumulation task: large problems use 64 (few partials per bucket); small ones (a GPU's
+// slice of a multi-GPU MSM) shorter chains so that the task count still fills the 1024 SIMDs.
+static uint32_t pick_chunk(size_t entries) {
+  const char* ev = getenv("H2MI_MSM_S0");
+  if (ev && atoi(ev) >= 1 && atoi(ev) <= 64) return (uint32_t)atoi(ev);
+  size_t want = entries / 196608;
+  uint32_t s0 = 8;
+  while (s0 < want && s0 < S0_MAX) s0 <<= 1;
+  return s0;
 }
 
 static void free_bases(Bases* B) {
@@ -388,6 +393,7 @@ static void free_bases(Bases* B) {
     hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
     hipFree(S.hist); hipFree(S.off);
     for (int i = 0; i < 3; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
+    hipFree(S.scan_tmp); hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
     if (S.accum_done) hipEventDestroy(S.accum_done);
     if (S.tail_done) hipEventDestroy(S.tail_done);
@@ -416,12 +422,16 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->logNh = (B->c - 1) - B->logNl;
   if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = n * B->W;
-  B->max_tasks0 = (uint32_t)(nW / S0 + B->nb);
+  B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb);  // pick_chunk keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
-  B->max_tasks2 = B->max_tasks1 / S1 + B->nb;
+  B->max_tasks2 = 0;
   H2_ALLOC(B->table, nW * 64);
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
                                          (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
+    free_bases(B);
+    return H2MI_EHIP;
+  }
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, B->scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(B->nb + 1), s) != hipSuccess) {
     free_bases(B);
     return H2MI_EHIP;
   }
@@ -434,9 +444,11 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.hist, (size_t)B->nb * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     for (int i = 0; i < 3; i++) {
-      H2_ALLOC(S.np[i], (size_t)B->nb * 4);
+      H2_ALLOC(S.np[i], (size_t)(B->nb + 1) * 4);
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
     }
+    H2_ALLOC(S.scan_tmp, B->scan_tmp_bytes ? B->scan_tmp_bytes : 16);
+    H2_ALLOC(S.dense, (size_t)B->nb * PART_BYTES);
     H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * PART_BYTES);
     H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * PART_BYTES);
     H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * PART_BYTES);
@@ -475,11 +487,6 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   const uint32_t nb = B->nb, W = B->W;
   const uint32_t total = (uint32_t)(n * W);
-  static bool scan_attr_set = false;
-  if (!scan_attr_set) {
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    scan_attr_set = true;
-  }
   const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
@@ -488,7 +495,9 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
     S.tail_pending = false;
   }
-  const size_t scan_lds = (size_t)(nb + (nb >> 5) + 32) * 4;
+  const uint32_t s0 = pick_chunk(total);
+  uint32_t ls0 = 0;
+  while ((1u << ls0) < s0) ls0++;
   H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
   {
     const bool prof_ = prof_on("hipcub_radix_sort");
@@ -498,31 +507,40 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     if (prof_) prof_end(s);
     H2_HIP(e);
   }
-  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)S.keys[1], total, nb, S.off, S.hist);
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, s, (const uint32_t*)S.hist, nb, S0, S.np[0], S.toff[0]);
-  uint32_t tasks0 = (uint32_t)(n * W / S0 + nb);
+  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist, S.np[0],
+            S.np[1], S.np[2]);
+  {
+    const bool prof_ = prof_on("hipcub_scan");
+    if (prof_) prof_begin("hipcub_scan", s);
+    hipError_t e0 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), s);
+    hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), s);
+    hipError_t e2 = hipSuccess;
+    if (prof_) prof_end(s);
+    H2_HIP(e0);
+    H2_HIP(e1);
+    H2_HIP(e2);
+  }
+  uint32_t tasks0 = (uint32_t)((n * W >> ls0) + nb);
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, (const uint8_t*)B->table, S.part[0]);
+            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
   hipStream_t t = s;
   if (pipelined) {
     t = ctx().tail_stream;
     H2_HIP(hipEventRecord(S.accum_done, s));
     H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
   }
-  // fold level 1: part[0] -> part[1]
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, t, (const uint32_t*)S.np[0], nb, S1, S.np[1], S.toff[1]);
+  // one fold level (<= S1 partials per task: part[0] -> part[1]), then FG lanes per bucket finish into the
+  // dense array.  A bucket holding m points leaves ceil(m / (s0 * S1)) partials for the finish kernel: 1 in
+  // the uniform case at k = 20, <= ~50 for the hot 0/1 buckets of witness-like columns (7 serial additions
+  // per lane), n / (s0 * S1) if every scalar is the same (slow but correct).
   uint32_t tasks1 = tasks0 / S1 + nb;
   H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[0],
             (const uint32_t*)S.np[0], (const uint32_t*)S.toff[1], nb, S.part[1]);
-  // fold level 2: part[1] -> part[0] (part[0] holds max_tasks0 >= max_tasks2 slots)
-  H2_LAUNCH("k_msm_scan", k_msm_scan, 1, 1024, scan_lds, t, (const uint32_t*)S.np[1], nb, S1, S.np[2], S.toff[2]);
-  uint32_t tasks2 = tasks1 / S1 + nb;
-  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks2, 256), 256, 0, t, (const uint8_t*)S.part[1], (const uint32_t*)S.toff[1],
-            (const uint32_t*)S.np[1], (const uint32_t*)S.toff[2], nb, S.part[0]);
+  H2_LAUNCH("k_msm_finish", k_msm_finish, ceil_div_u32((uint64_t)nb * FG, 256), 256, 0, t, (const uint8_t*)S.part[1], (const uint32_t*)S.toff[1],
+            (const uint32_t*)S.np[1], nb, S.dense);
   // weighted bucket sum
   const uint32_t Nh = 1u << B->logNh, Nl = 1u << B->logNl;
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * PART_BYTES, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[2],
-            (const uint32_t*)S.np[2], B->logNh, B->logNl, S.rc);
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * PART_BYTES, t, (const uint8_t*)S.dense, B->logNh, B->logNl, S.rc);
   H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * PART_BYTES, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
   H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * PART_BYTES, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
             nb, S.stats);

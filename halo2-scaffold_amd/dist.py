@@ -5,8 +5,8 @@ This is the partition halo2_proofs::arithmetic::best_multiexp applies per CPU th
 chunks, partial results folded by addition) lifted to GPUs.  RCCL has no user-defined reduction, so
 the "all-reduce of EC points" is an all-gather of world x 96 B over xGMI followed by world-1 point
 additions on every rank (latency-bound: < 1 KB payload).
-`fold` defaults to the device kernel (h2mi_g1_sum_jacobian); tests inject a CPU fold to exercise the
-collective plumbing over gloo without a GPU.
+`fold` ((world, k, 12) -> (k, 12)) defaults to the device kernel (h2mi_g1_fold_groups); tests inject a
+CPU fold to exercise the collective plumbing over gloo without a GPU.
 """
 import numpy as np
 
@@ -18,12 +18,14 @@ def slice_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def device_fold(points: np.ndarray) -> np.ndarray:
+def device_fold(allp: np.ndarray) -> np.ndarray:
+    """(world, k, 12) partial Jacobian points -> (k, 12): one device launch folds all k MSMs."""
     from ._lib import check, lib
 
-    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
-    out = np.zeros(12, dtype=np.uint64)
-    check(lib.h2mi_g1_sum_jacobian(points.ctypes.data, len(points), out.ctypes.data), "fold")
+    allp = np.ascontiguousarray(allp, dtype=np.uint64)
+    world, k = allp.shape[0], allp.shape[1]
+    out = np.zeros((k, 12), dtype=np.uint64)
+    check(lib.h2mi_g1_fold_groups(allp.ctypes.data, world, k, out.ctypes.data), "fold")
     return out
 
 
@@ -51,4 +53,4 @@ class PartialPointCombiner:
         gathered = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(gathered, t, group=self.group)
         allp = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])  # (world, k, 12)
-        return np.stack([self.fold(allp[:, i, :]) for i in range(k)])
+        return self.fold(allp)

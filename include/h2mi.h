@@ -92,6 +92,8 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
 /* sum of k Jacobian points (k*12 limbs, host) -> one Jacobian point: the combine step of the sliced
  * multi-GPU MSM (the fold `results.iter().fold(identity, |a, b| a + b)` of best_multiexp). */
 int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]);
+/* the same fold for k MSMs at once: points[r*k + j] is rank r's partial result of MSM j -> out[j] */
+int h2mi_g1_fold_groups(const uint64_t* points /* world*k*12 */, size_t world, size_t k, uint64_t* out /* k*12 */);
 /* batch Jacobian -> affine (G1::batch_normalize, used by create_proof before transcript writes) */
 int h2mi_g1_batch_normalize(const uint64_t* jac /* k*12 */, size_t k, uint64_t* affine_out /* k*8 */);
 

@@ -311,3 +311,31 @@ def test_msm_linearity_full_size(gpu):
     ev = d.coeff_to_lagrange(a)
     assert np.array_equal(cref.normalize(params.commit_lagrange(ev)), cref.normalize(pa))
     params.release()
+
+
+def test_fold_groups_and_small_slice_msm(gpu):
+    """multi-GPU building blocks on one GPU: 4 'ranks' each commit their slice; fold_groups == full commit."""
+    from oracle import cref
+    from halo2_scaffold_amd.dist import device_fold, slice_bounds
+
+    k = 14
+    n = 1 << k
+    full = gpu.ParamsKZG.setup(k, 0xBEEF)
+    g = full.get_g()
+    sc = [o.random_field_limbs(n, 40 + j) for j in range(3)]
+    want = [cref.normalize(full.commit(s)) for s in sc]
+    world = 4
+    parts = np.zeros((world, 3, 12), dtype=np.uint64)
+    for r in range(world):
+        lo, hi = slice_bounds(n, r, world)
+        p = gpu.ParamsKZG.from_bases(k, g[lo:hi]) if False else None
+        h = C.c_uint64()
+        gs = np.ascontiguousarray(g[lo:hi])
+        assert gpu.lib.h2mi_bases_register(gs.ctypes.data, hi - lo, C.byref(h)) == 0
+        for j in range(3):
+            parts[r, j] = gpu.best_multiexp(np.ascontiguousarray(sc[j][lo:hi]), h.value)
+        assert gpu.lib.h2mi_bases_release(h.value) == 0
+    got = device_fold(parts)
+    for j in range(3):
+        assert np.array_equal(cref.normalize(got[j]), want[j])
+    full.release()

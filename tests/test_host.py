@@ -104,7 +104,7 @@ n, slots = 96, 3
 bases = cref.g1_mul_gen(o.random_field_limbs(n, 5), 1)
 lo, hi = slice_bounds(n, rank, world)
 part = np.stack([cref.msm(o.random_field_limbs(n, 100 + s)[lo:hi], bases[lo:hi], 1) for s in range(slots)])
-comb = PartialPointCombiner(fold=cref.g1_sum)        # CPU fold injected: exercises the collective plumbing
+comb = PartialPointCombiner(fold=lambda allp: np.stack([cref.g1_sum(allp[:, i]) for i in range(allp.shape[1])]))        # CPU fold injected: exercises the collective plumbing
 total = comb(part)
 for s in range(slots):
     want = o.unpack_jacobian(cref.msm(o.random_field_limbs(n, 100 + s), bases, 1))
