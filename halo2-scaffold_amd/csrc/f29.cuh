@@ -112,6 +112,17 @@ H2_HD f29 f29_dbl(const f29& a) {  // lazy
   return r;
 }
 
+// acc += x * y as ONE v_mad_u64_u32 whose 64-bit addend is the running column accumulator.  Written
+// as inline asm for the first product of every column: left to itself hipcc starts each column's chain
+// from zero and merges the carried-in accumulator with an extra v_lshl_add_u64 (17 per multiplication).
+H2_HD void f29_mac_first(uint64_t& acc, uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+#else
+  acc += (uint64_t)x * y;
+#endif
+}
+
 // Montgomery product a * b / 2^261 mod p (loosely reduced), output normalized.
 template <class F>
 H2_HD f29 f29_mul(const f29& a, const f29& b) {
@@ -120,8 +131,9 @@ H2_HD f29 f29_mul(const f29& a, const f29& b) {
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
+    f29_mac_first(acc, a.v[0], b.v[k]);
 #pragma unroll
-    for (int j = 0; j <= k; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+    for (int j = 1; j <= k; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
 #pragma unroll
     for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P[k - j];
     m[k] = ((uint32_t)acc * F::INV) & M29;
@@ -130,8 +142,9 @@ H2_HD f29 f29_mul(const f29& a, const f29& b) {
   }
 #pragma unroll
   for (int k = 9; k < 17; k++) {
+    f29_mac_first(acc, a.v[k - 8], b.v[8]);
 #pragma unroll
-    for (int j = k - 8; j < 9; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+    for (int j = k - 7; j < 9; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
 #pragma unroll
     for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * F::P[k - j];
     t.v[k - 9] = (uint32_t)acc & M29;
@@ -151,9 +164,11 @@ H2_HD f29 f29_sqr(const f29& a) {
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
+    if (k == 0) f29_mac_first(acc, a.v[0], a.v[0]);
+    else f29_mac_first(acc, a.v[0], a2[k]);
 #pragma unroll
-    for (int j = 0; 2 * j < k; j++) acc += (uint64_t)a.v[j] * a2[k - j];
-    if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+    for (int j = 1; 2 * j < k; j++) acc += (uint64_t)a.v[j] * a2[k - j];
+    if ((k & 1) == 0 && k > 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
 #pragma unroll
     for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P[k - j];
     m[k] = ((uint32_t)acc * F::INV) & M29;
@@ -162,11 +177,12 @@ H2_HD f29 f29_sqr(const f29& a) {
   }
 #pragma unroll
   for (int k = 9; k < 17; k++) {
+    f29_mac_first(acc, m[k - 8], F::P[8]);
 #pragma unroll
     for (int j = k - 8; 2 * j < k; j++) acc += (uint64_t)a.v[j] * a2[k - j];
     if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
 #pragma unroll
-    for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * F::P[k - j];
+    for (int j = k - 7; j < 9; j++) acc += (uint64_t)m[j] * F::P[k - j];
     t.v[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
   }
