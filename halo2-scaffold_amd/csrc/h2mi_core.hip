@@ -158,6 +158,8 @@ int h2mi_init(int device) {
   H2_HIP(hipSetDevice(device));
   H2_HIP(hipStreamCreateWithFlags(&ctx().stream, hipStreamNonBlocking));
   H2_HIP(hipStreamCreateWithFlags(&ctx().tail_stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&ctx().head_stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&ctx().accum_stream, hipStreamNonBlocking));
   ctx().device = device;
   ctx().inited = true;
   return H2MI_OK;
@@ -168,8 +170,11 @@ void h2mi_shutdown(void) {
   if (!ctx().inited) return;
   hipStreamSynchronize(ctx().stream);
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; }
-  hipStreamSynchronize(ctx().tail_stream);
+  hipDeviceSynchronize();
+  hipStreamDestroy(ctx().head_stream);
+  hipStreamDestroy(ctx().accum_stream);
   hipStreamDestroy(ctx().tail_stream);
+  ctx().head_stream = ctx().accum_stream = nullptr;
   hipStreamDestroy(ctx().stream);
   ctx().stream = nullptr;
   ctx().tail_stream = nullptr;

@@ -22,7 +22,9 @@ struct Ctx {
   bool inited = false;
   int device = -1;
   hipStream_t stream = nullptr;
-  hipStream_t tail_stream = nullptr;  // latency-bound MSM tails overlap the next MSM here
+  // MSM pipeline on the library's own stream: sort (memory-bound) | accumulation (VALU-bound) | bucket
+  // reduction (latency-bound) of consecutive MSMs run on three internal streams and overlap.
+  hipStream_t head_stream = nullptr, accum_stream = nullptr, tail_stream = nullptr;
   std::recursive_mutex mu;
   bool profiling = false;
   std::string prof_filter;

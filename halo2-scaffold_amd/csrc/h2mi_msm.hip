@@ -49,8 +49,8 @@ struct Slot {
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
   uint8_t* g = nullptr;                             // weighted partials (<= 32)
   uint64_t* stats = nullptr;                        // [0] = insertions
-  hipEvent_t accum_done = nullptr, tail_done = nullptr;
-  bool tail_pending = false;
+  hipEvent_t input_ready = nullptr, head_done = nullptr, accum_done = nullptr, tail_done = nullptr;
+  bool tail_pending = false, accum_pending = false, head_pending = false;
 };
 constexpr int NSLOT = 2;
 
@@ -395,6 +395,8 @@ static void free_bases(Bases* B) {
     for (int i = 0; i < 3; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
+    if (S.input_ready) hipEventDestroy(S.input_ready);
+    if (S.head_done) hipEventDestroy(S.head_done);
     if (S.accum_done) hipEventDestroy(S.accum_done);
     if (S.tail_done) hipEventDestroy(S.tail_done);
   }
@@ -454,7 +456,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * PART_BYTES);
     H2_ALLOC(S.g, (size_t)64 * PART_BYTES);
     H2_ALLOC(S.stats, 64);
-    if (hipEventCreateWithFlags(&S.accum_done, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&S.input_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S.head_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S.accum_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming) != hipSuccess) {
       free_bases(B);
       return H2MI_EHIP;
@@ -491,43 +495,72 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
   B->next_slot = (B->next_slot + 1) % NSLOT;
-  if (S.tail_pending) {  // the slot's previous tail must be finished before its buffers are reused
-    H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
-    S.tail_pending = false;
-  }
+  // streams: caller-provided stream => everything in order on it.  Library stream => three stages:
+  //   s : digit extraction (the only reader of the caller's scalars)
+  //   hs: sort, bounds, scans
+  //   as: accumulation                   (never blocks s: NTTs queued on s meanwhile run beside it)
+  //   ts: fold ... final                 (joined into s by h2mi_join / h2mi_sync / h2mi_memcpy_d2h)
+  hipStream_t hs = s, as = s, ts = s;
   const uint32_t s0 = pick_chunk(total);
   uint32_t ls0 = 0;
   while ((1u << ls0) < s0) ls0++;
+  if (pipelined) {
+    hs = ctx().head_stream;
+    as = ctx().accum_stream;
+    ts = ctx().tail_stream;
+    // the digit kernel is the only reader of the caller's scalars: it stays on s, so work queued on s after
+    // this call may overwrite them.  It writes keys[0]/vals[0], last read by this slot's previous sort.
+    if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+  } else {
+    if (S.tail_pending) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+    if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
+  }
   H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
+  if (pipelined) {
+    H2_HIP(hipEventRecord(S.input_ready, s));
+    H2_HIP(hipStreamWaitEvent(hs, S.input_ready, 0));
+    // slot reuse: the sorted buffers are read by this slot's previous accumulation, the partial buffers and
+    // bucket offsets by its previous tail
+    if (S.accum_pending) H2_HIP(hipStreamWaitEvent(hs, S.accum_done, 0));
+    if (S.tail_pending) H2_HIP(hipStreamWaitEvent(hs, S.tail_done, 0));
+  }
+  S.tail_pending = false;
+  S.accum_pending = false;
+  S.head_pending = false;
   {
     const bool prof_ = prof_on("hipcub_radix_sort");
-    if (prof_) prof_begin("hipcub_radix_sort", s);
+    if (prof_) prof_begin("hipcub_radix_sort", hs);
     // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, s);
-    if (prof_) prof_end(s);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, hs);
+    if (prof_) prof_end(hs);
     H2_HIP(e);
   }
-  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, s, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist, S.np[0],
+  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, hs, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist, S.np[0],
             S.np[1], S.np[2]);
   {
     const bool prof_ = prof_on("hipcub_scan");
-    if (prof_) prof_begin("hipcub_scan", s);
-    hipError_t e0 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), s);
-    hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), s);
+    if (prof_) prof_begin("hipcub_scan", hs);
+    hipError_t e0 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs);
+    hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs);
     hipError_t e2 = hipSuccess;
-    if (prof_) prof_end(s);
+    if (prof_) prof_end(hs);
     H2_HIP(e0);
     H2_HIP(e1);
     H2_HIP(e2);
   }
   uint32_t tasks0 = (uint32_t)((n * W >> ls0) + nb);
-  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, s, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
-  hipStream_t t = s;
   if (pipelined) {
-    t = ctx().tail_stream;
-    H2_HIP(hipEventRecord(S.accum_done, s));
+    H2_HIP(hipEventRecord(S.head_done, hs));
+    H2_HIP(hipStreamWaitEvent(as, S.head_done, 0));
+    S.head_pending = true;
+  }
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
+            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
+  hipStream_t t = ts;
+  if (pipelined) {
+    H2_HIP(hipEventRecord(S.accum_done, as));
     H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
+    S.accum_pending = true;
   }
   // one fold level (<= S1 partials per task: part[0] -> part[1]), then FG lanes per bucket finish into the
   // dense array.  A bucket holding m points leaves ceil(m / (s0 * S1)) partials for the finish kernel: 1 in
