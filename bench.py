@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=20, help="log2 rows (BASELINE.json metric is quoted at k=20)")
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--shape", choices=["standard_plonk", "halo2_lib_gate", "range_lookup"], default="standard_plonk",
+                    help="proof shape to replay (BASELINE.json metric is quoted on standard_plonk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 size of the CPU baseline sample MSM/NTT")
     args = ap.parse_args()
@@ -62,7 +64,8 @@ def main():
     h2.init(local_rank)
     lib = h2.lib
     combine = PartialPointCombiner(device=torch.device("cuda", local_rank)) if world > 1 else None
-    R = rp.StandardPlonkReplay(args.k, rank=rank, world=world, dist=args.dist, combine=combine)
+    shape = rp.SHAPES[args.shape]
+    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine)
     n = R.n
 
     def sync_all():
@@ -86,7 +89,8 @@ def main():
         ba, ra = C.c_uint64(), C.c_uint64()
         h2._lib.check(lib.h2mi_msm_last_stats(handle, C.byref(ba), C.byref(ra)), "stats")
         # uniform columns: every MSM of the step has the same expected insertion count
-        adds_local += (ba.value + ra.value) * (6 if lagrange else 5)
+        n_lagr = shape.n_advice + 3 * shape.n_lookups + shape.n_perm_z
+        adds_local += (ba.value + ra.value) * (n_lagr if lagrange else shape.msm_per_proof - n_lagr)
     adds = adds_local
     if dist is not None:
         t = torch.tensor([adds_local], dtype=torch.int64, device=f"cuda:{local_rank}")
@@ -175,7 +179,8 @@ def main():
         "dtype": "u32x8 (254-bit Montgomery integers)",
         "data": "synthetic",
         "config": {
-            "workload": f"standard_plonk hot-path replay k={args.k}: 11 MSM(2^{args.k}) + 6 iNTT(2^{args.k}) + 6 coset-NTT(2^{args.k + 1}) + 1 coset-iNTT(2^{args.k + 1})",
+            "workload": f"{shape.name} hot-path replay k={args.k}: {shape.msm_per_proof} MSM(2^{args.k}) + {shape.ntt_per_proof['intt_n']} iNTT(2^{args.k}) + "
+                        f"{shape.ntt_per_proof['coset_ntt_ext']} coset-NTT(2^{R.domain.extended_k}) + 1 coset-iNTT(2^{R.domain.extended_k})",
             "k": args.k,
             "scalar_distribution": args.dist,
             "msm_window_bits": c.value,
@@ -185,7 +190,7 @@ def main():
             "what_is_timed": "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation",
         },
         "g1_adds_per_step": adds,
-        "msm_pairs_per_s": round(rp.MSM_PER_PROOF * n / (ms_per_step * 1e-3), 1),
+        "msm_pairs_per_s": round(shape.msm_per_proof * n / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": {"msm": round(msm_ms, 3), "ntt": round(ntt_ms, 3)},
         "kernels": phases,
         "roofline": roofline,
@@ -255,7 +260,8 @@ def cpu_baseline(R, args, n):
         "msm_seconds": round(t_msm, 4),
         "msm_pairs_per_s": round(ns / t_msm, 1),
         "ntt_seconds": round(t_ntt, 4),
-        "projected_step_seconds": round(11 * t_msm * (n / ns) + (6 + 2 * 7) * t_ntt * (n / ns), 3),
+        "projected_step_seconds": round(R.shape.msm_per_proof * t_msm * (n / ns)
+                                        + (R.shape.ntt_per_proof["intt_n"] + (R.domain.extended_len() // n) * (R.shape.ntt_per_proof["coset_ntt_ext"] + 1)) * t_ntt * (n / ns), 3),
         "label": "restated CPU baseline (C), not the Rust binary",
     }
 

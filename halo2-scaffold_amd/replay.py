@@ -1,15 +1,25 @@
-"""The MSM/NTT sequence one StandardPlonk proof issues — "prover hot-path replay".
+"""The MSM/NTT sequence one Halo2/KZG proof issues — "prover hot-path replay".
 
-Shape from the reference circuit (src/circuits/standard_plonk.rs:29-48: 3 advice + 5 fixed columns, one
-degree-3 gate, equality on a, b, c; examples/standard_plonk.rs:41-49 calls create_proof on it) and the
-create_proof call stack of SURVEY.md 3.3: per proof 11 MSM(n) + 6 iNTT(n) + 6 coset-NTT(2n) +
-1 coset-iNTT(2n).  This is NOT create_proof(): gate evaluation, transcript hashing and witness
-generation are out of scope; vectors are synthetic and stay resident in HBM.
+The shape of a proof (how many commitments and transforms of which size) is fixed by the circuit's
+constraint system; `ProofShape` carries it and `ProofReplay` issues exactly that sequence, in
+create_proof's order, on synthetic vectors resident in HBM.  This is NOT create_proof():
+gate evaluation, transcript hashing and witness generation are out of scope.
+
+Shapes:
+  STANDARD_PLONK  reference src/circuits/standard_plonk.rs:29-48 (3 advice + 5 fixed columns, one
+                  degree-3 gate, equality on a, b, c), proved by examples/standard_plonk.rs:41-49.
+  HALO2_LIB_GATE  reference src/scaffold.rs:379-421 GateWithInstanceCircuitBuilder (halo2_lib.rs /
+                  poseidon.rs closures): one FlexGate advice column at these sizes, one instance column,
+                  degree-3 basic gate  [column counts restated from memory of halo2-base: SURVEY 3.3].
+  RANGE_LOOKUP    reference src/scaffold.rs:434-485 RangeWithInstanceCircuitBuilder (range.rs): adds one
+                  lookup-advice column and one lookup argument => constraint degree 4, extended domain 4n.
 
 Multi-GPU: every rank replays the NTTs on its own GPU (NTT is single-GPU by design) and owns one
 contiguous slice of every base set; each MSM runs on the slice and the 96-byte partial points are
-combined by `combine` (all-gather + fold, see dist.py).
+combined once per proof by `combine` (all-gather + fold, see dist.py).
 """
+from dataclasses import dataclass
+
 import numpy as np
 
 from . import synth
@@ -18,19 +28,51 @@ from .device import DevBuf
 from .domain import EvaluationDomain
 from .params import ParamsKZG
 
-N_ADVICE = 3       # reference src/circuits/standard_plonk.rs:13-15
-N_PERM_Z = 3       # equality enabled on a, b, c (standard_plonk.rs:34), chunk length 1
-CS_DEGREE = 3      # q_ab * a * b (standard_plonk.rs:47)
-MSM_PER_PROOF = N_ADVICE + N_PERM_Z + 1 + (CS_DEGREE - 1) + 2
-NTT_PER_PROOF = {"intt_n": N_ADVICE + N_PERM_Z, "coset_ntt_ext": N_ADVICE + N_PERM_Z, "coset_intt_ext": 1}
+
+@dataclass(frozen=True)
+class ProofShape:
+    name: str
+    n_advice: int
+    n_instance: int
+    n_perm_columns: int  # columns with equality enabled
+    n_lookups: int
+    cs_degree: int       # max(gate degree, 3, lookup => 4)
+
+    @property
+    def n_perm_z(self) -> int:  # permutation columns are chunked by (degree - 2)
+        chunk = self.cs_degree - 2
+        return -(-self.n_perm_columns // chunk)
+
+    @property
+    def msm_per_proof(self) -> int:
+        # advice + (A', S') per lookup + z per chunk + z per lookup + random poly + h pieces + 2 SHPLONK
+        return self.n_advice + 2 * self.n_lookups + self.n_perm_z + self.n_lookups + 1 + (self.cs_degree - 1) + 2
+
+    @property
+    def ntt_per_proof(self) -> dict:
+        polys = self.n_advice + self.n_perm_z + 3 * self.n_lookups
+        return {"intt_n": self.n_instance + polys, "coset_ntt_ext": self.n_instance + polys, "coset_intt_ext": 1}
 
 
-class StandardPlonkReplay:
-    def __init__(self, k: int, rank: int = 0, world: int = 1, srs_secret: int = 0x5EC2E7 + 0x48324D49, dist="uniform", combine=None):
+STANDARD_PLONK = ProofShape("standard_plonk", n_advice=3, n_instance=0, n_perm_columns=3, n_lookups=0, cs_degree=3)
+HALO2_LIB_GATE = ProofShape("halo2_lib_gate", n_advice=1, n_instance=1, n_perm_columns=3, n_lookups=0, cs_degree=3)
+RANGE_LOOKUP = ProofShape("range_lookup", n_advice=2, n_instance=1, n_perm_columns=4, n_lookups=1, cs_degree=4)
+SHAPES = {s.name: s for s in (STANDARD_PLONK, HALO2_LIB_GATE, RANGE_LOOKUP)}
+
+# StandardPlonk constants kept for callers / tests that name them
+N_ADVICE, N_PERM_Z, CS_DEGREE = STANDARD_PLONK.n_advice, STANDARD_PLONK.n_perm_z, STANDARD_PLONK.cs_degree
+MSM_PER_PROOF = STANDARD_PLONK.msm_per_proof
+NTT_PER_PROOF = STANDARD_PLONK.ntt_per_proof
+
+
+class ProofReplay:
+    def __init__(self, shape: ProofShape, k: int, rank: int = 0, world: int = 1, srs_secret: int = 0x5EC2E7 + 0x48324D49, dist="uniform",
+                 combine=None):
+        self.shape = shape
         self.k, self.n = k, 1 << k
         self.rank, self.world = rank, world
         self.combine = combine
-        self.domain = EvaluationDomain(CS_DEGREE, k)
+        self.domain = EvaluationDomain(shape.cs_degree, k)
         n = self.n
         assert n % world == 0
         self.lo, self.hi = rank * n // world, (rank + 1) * n // world
@@ -49,82 +91,119 @@ class StandardPlonkReplay:
             self.params._gl_dev = DevBuf.from_numpy(gl)
             self.params._register()
         gen = synth.witness_like_fr if dist == "witness" else synth.uniform_fr
-        # Lagrange-basis columns: 3 advice, 3 permutation products, 1 random (vanishing) polynomial
-        self.cols = [DevBuf.from_numpy(gen(n, synth.SEED + 10 + i)) for i in range(N_ADVICE + N_PERM_Z)]
+        sh = shape
+        # Lagrange-basis vectors: advice, lookup (A', S', z) triples, permutation products, instance
+        self.advice = [DevBuf.from_numpy(gen(n, synth.SEED + 10 + i)) for i in range(sh.n_advice)]
+        self.lookup = [DevBuf.from_numpy(synth.uniform_fr(n, synth.SEED + 40 + i)) for i in range(3 * sh.n_lookups)]
+        self.perm_z = [DevBuf.from_numpy(synth.uniform_fr(n, synth.SEED + 60 + i)) for i in range(sh.n_perm_z)]
+        self.instance = [DevBuf.from_numpy(gen(n, synth.SEED + 80 + i)) for i in range(sh.n_instance)]
+        self.cols = self.advice + self.perm_z  # kept for bench.py's stats probe
         self.random_poly = DevBuf.from_numpy(synth.uniform_fr(n, synth.SEED + 20))
-        self.work = [DevBuf(n * 32) for _ in range(N_ADVICE + N_PERM_Z)]
+        npoly = sh.n_advice + sh.n_perm_z + 3 * sh.n_lookups + sh.n_instance
+        self.work = [DevBuf(n * 32) for _ in range(npoly)]
         ext = self.domain.extended_len()
-        self.ext = [DevBuf(ext * 32) for _ in range(N_ADVICE + N_PERM_Z)]
+        self.ext = [DevBuf(ext * 32) for _ in range(npoly)]
         self.h = DevBuf(ext * 32)
-        self.out = DevBuf(96 * MSM_PER_PROOF)
-        self._zeros = np.zeros(((ext - n), 4), dtype=np.uint64)
+        self.out = DevBuf(96 * sh.msm_per_proof)
         for e in self.ext:
-            e.upload(self._zeros, offset=n * 32)
+            check(lib.h2mi_memset_zero(e.ptr, ext * 32), "zero")
         self.h.upload(synth.uniform_fr(ext, synth.SEED + 30))
         self._h_src = DevBuf(ext * 32)
         self._h_src.copy_from(self.h)
+        self.counts = {"msm": 0, "intt_n": 0, "coset_ntt_ext": 0, "coset_intt_ext": 0}
         check(lib.h2mi_sync(), "sync")
 
-    def _msm(self, slot: int, buf: DevBuf, lagrange: bool, offset_elems: int = 0):
+    # ---- primitives ----
+    def _msm(self, buf: DevBuf, lagrange: bool, offset_elems: int = 0):
         h = self.params.g_lagrange_handle if lagrange else self.params.g_handle
         src = buf.ptr + (offset_elems + self.lo) * 32
-        check(lib.h2mi_msm_bn254_g1_dev(h, src, self.n_local, self.out.ptr + 96 * slot, None), "msm")
+        check(lib.h2mi_msm_bn254_g1_dev(h, src, self.n_local, self.out.ptr + 96 * self._slot, None), "msm")
+        self._slot += 1
+        self.counts["msm"] += 1
+
+    def _to_coeff_and_extended(self, lagr: DevBuf, w: DevBuf, e: DevBuf):
+        """lagrange_to_coeff then coeff_to_extended (zero padding of e restored at the end of step())."""
+        n = self.n
+        w.copy_from(lagr, n * 32)
+        self.domain.lagrange_to_coeff_dev(w)
+        e.copy_from(w, n * 32)
+        self.domain.coeff_to_extended_dev(e)
+        self.counts["intt_n"] += 1
+        self.counts["coset_ntt_ext"] += 1
 
     def step(self, phase_joins: bool = True):
         """one proof's worth of hot-path work, queued on the library streams (asynchronous).
 
-        The order follows create_proof.  Where the real prover must hash commitments
-        into the transcript before it can continue (challenges theta/beta/gamma, y, x, u), the replay
-        joins the MSM tails (`h2mi_join`), so no overlap is claimed that a prover could not have."""
-        d, n = self.domain, self.n
+        The order follows create_proof.  Where the real prover must hash commitments into
+        the transcript before it can continue (challenges theta, beta/gamma, y, x, u), the replay joins the
+        MSM pipeline (`h2mi_join`), so no overlap is claimed that a prover could not have."""
+        sh, d, n = self.shape, self.domain, self.n
         join = (lambda: check(lib.h2mi_join(), "join")) if phase_joins else (lambda: None)
-        slot = 0
-        # phase 2: advice commitments (Lagrange basis) -> challenges theta, beta, gamma
-        for c in self.cols[:N_ADVICE]:
-            self._msm(slot, c, lagrange=True)
-            slot += 1
+        self._slot = 0
+        w_it, e_it = iter(self.work), iter(self.ext)
+        # phase 1: instance columns (KZG: hashed, not committed): lagrange_to_coeff (+ extended below)
+        inst_we = [(c, next(w_it), next(e_it)) for c in self.instance]
+        # phase 2: advice commitments (Lagrange basis) -> challenge theta
+        for c in self.advice:
+            self._msm(c, lagrange=True)
         join()
-        # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per column
-        for c, w, e in zip(self.cols[N_ADVICE:], self.work[N_ADVICE:], self.ext[N_ADVICE:]):
-            self._msm(slot, c, lagrange=True)
-            slot += 1
-            w.copy_from(c, n * 32)
-            d.lagrange_to_coeff_dev(w)
-            e.copy_from(w, n * 32)
-            d.coeff_to_extended_dev(e)
+        # phase 3: lookups: commit permuted input / table columns -> challenges beta, gamma
+        for i in range(sh.n_lookups):
+            self._msm(self.lookup[3 * i], lagrange=True)
+            self._msm(self.lookup[3 * i + 1], lagrange=True)
+        if sh.n_lookups:
+            join()
+        # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per chunk
+        for c in self.perm_z:
+            self._msm(c, lagrange=True)
+            self._to_coeff_and_extended(c, next(w_it), next(e_it))
+        # phase 5: lookup products
+        for i in range(sh.n_lookups):
+            self._msm(self.lookup[3 * i + 2], lagrange=True)
         # phase 6: random polynomial commitment (coefficient basis) -> challenge y
-        self._msm(slot, self.random_poly, lagrange=False)
-        slot += 1
+        self._msm(self.random_poly, lagrange=False)
         join()
-        # phase 7: advice lagrange_to_coeff + coeff_to_extended (evaluate_h inputs)
-        for c, w, e in zip(self.cols[:N_ADVICE], self.work[:N_ADVICE], self.ext[:N_ADVICE]):
-            w.copy_from(c, n * 32)
-            d.lagrange_to_coeff_dev(w)
-            e.copy_from(w, n * 32)
-            d.coeff_to_extended_dev(e)
+        # phase 7: advice / instance / lookup polynomials to coefficient and extended form (evaluate_h inputs)
+        first_adv_w = None
+        for c in self.advice:
+            w = next(w_it)
+            first_adv_w = first_adv_w or w
+            self._to_coeff_and_extended(c, w, next(e_it))
+        for c, w, e in inst_we:
+            self._to_coeff_and_extended(c, w, e)
+        for c in self.lookup:
+            self._to_coeff_and_extended(c, next(w_it), next(e_it))
         # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each -> challenge x
         self.h.copy_from(self._h_src)
         d.extended_to_coeff_dev(self.h)
-        for piece in range(CS_DEGREE - 1):
-            self._msm(slot, self.h, lagrange=False, offset_elems=piece * n)
-            slot += 1
+        self.counts["coset_intt_ext"] += 1
+        for piece in range(sh.cs_degree - 1):
+            self._msm(self.h, lagrange=False, offset_elems=piece * n)
         join()
         # phase 10: SHPLONK h(X) commitment -> challenge u -> L(X)/(X-u) commitment
-        self._msm(slot, self.work[0], lagrange=False)
-        slot += 1
+        self._msm(first_adv_w, lagrange=False)
         join()
-        self._msm(slot, self.work[1], lagrange=False)
-        slot += 1
+        self._msm(self.work[0], lagrange=False)
         join()
-        assert slot == MSM_PER_PROOF
+        assert self._slot == sh.msm_per_proof
         # restore the zero padding of the extended buffers for the next proof
         for e in self.ext:
             check(lib.h2mi_memset_zero(e.ptr + n * 32, (self.domain.extended_len() - n) * 32), "zero")
 
     def finish(self) -> np.ndarray:
-        """wait, fetch the MSM_PER_PROOF partial results, combine across ranks -> (MSM_PER_PROOF, 12)."""
+        """wait, fetch the partial results, combine across ranks -> (msm_per_proof, 12)."""
         check(lib.h2mi_sync(), "sync")
-        part = self.out.to_numpy(shape=(MSM_PER_PROOF, 12))
+        part = self.out.to_numpy(shape=(self.shape.msm_per_proof, 12))
         if self.world > 1 and self.combine is not None:
             return self.combine(part)
         return part
+
+    def release(self):
+        self.params.release()
+        for b in self.advice + self.lookup + self.perm_z + self.instance + self.work + self.ext + [self.h, self._h_src, self.out, self.random_poly]:
+            b.free()
+
+
+class StandardPlonkReplay(ProofReplay):
+    def __init__(self, k: int, **kw):
+        super().__init__(STANDARD_PLONK, k, **kw)

@@ -77,6 +77,14 @@ def test_replay_shape_matches_reference_circuit(h2):
 
     assert replay.MSM_PER_PROOF == 11
     assert replay.NTT_PER_PROOF == {"intt_n": 6, "coset_ntt_ext": 6, "coset_intt_ext": 1}
+    sp = replay.STANDARD_PLONK
+    assert (sp.n_advice, sp.n_perm_z, sp.cs_degree, sp.n_lookups) == (3, 3, 3, 0)
+    # halo2-lib gate circuit: 1 advice + 1 instance, 3 equality columns in chunks of 1, no lookups
+    g = replay.HALO2_LIB_GATE
+    assert g.msm_per_proof == 1 + 3 + 1 + 2 + 2 and g.ntt_per_proof["intt_n"] == 1 + 1 + 3
+    # range circuit: one lookup => degree 4: permutation chunks of 2, 3 h pieces, 3 extra commitments
+    r = replay.RANGE_LOOKUP
+    assert r.n_perm_z == 2 and r.msm_per_proof == 2 + 2 + 2 + 1 + 1 + 3 + 2
 
 
 def test_slice_bounds(h2):
