@@ -16,6 +16,6 @@ The directory name contains a hyphen (it mirrors the reference's name); load it 
 from . import field  # noqa: F401
 from ._lib import H2miError, lib, init, lib_path  # noqa: F401
 from .device import DevBuf  # noqa: F401
-from .arithmetic import best_fft, best_multiexp  # noqa: F401
+from .arithmetic import best_fft, best_multiexp, eval_polynomial, kate_division, lincomb  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .params import ParamsKZG  # noqa: F401

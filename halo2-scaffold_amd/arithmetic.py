@@ -43,3 +43,60 @@ def best_fft(a: np.ndarray, omega, log_n: int) -> None:
         raise AssertionError("a.len() != 1 << log_n")
     omega = np.ascontiguousarray(omega, dtype=np.uint64)
     check(lib.h2mi_ntt_bn254_fr(a.ctypes.data, omega.ctypes.data, int(log_n)), "best_fft")
+
+
+def eval_polynomial(poly: np.ndarray, point) -> np.ndarray:
+    """halo2_proofs::arithmetic::eval_polynomial: sum_i poly[i] * point^i -> (4,) u64 Fr."""
+    from .device import DevBuf
+
+    poly = _fr_array(poly)
+    point = np.ascontiguousarray(point, dtype=np.uint64)
+    d = DevBuf.from_numpy(poly)
+    o = DevBuf(32)
+    check(lib.h2mi_fr_eval_poly_dev(d.ptr, len(poly), point.ctypes.data, o.ptr, None), "eval_polynomial")
+    out = o.to_numpy(shape=(4,))
+    d.free()
+    o.free()
+    return out
+
+
+def kate_division(a: np.ndarray, b) -> np.ndarray:
+    """halo2_proofs::arithmetic::kate_division: coefficients of a(X) / (X - b), remainder dropped."""
+    from . import field as F
+    from .device import DevBuf
+
+    a = _fr_array(a)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    bv = F.fr_from_mont_limbs(b)
+    if len(a) < 2:
+        return np.zeros((0, 4), dtype=np.uint64)
+    if bv == 0:  # division by X: shift
+        return a[1:].copy()
+    binv = F.fr_to_mont_limbs(F.fr_inv(bv))
+    d = DevBuf.from_numpy(a)
+    o = DevBuf((len(a) - 1) * 32)
+    check(lib.h2mi_fr_kate_division_dev(d.ptr, len(a), b.ctypes.data, binv.ctypes.data, o.ptr, None), "kate_division")
+    out = o.to_numpy(shape=(len(a) - 1, 4))
+    d.free()
+    o.free()
+    return out
+
+
+def lincomb(polys, scalars) -> np.ndarray:
+    """sum_k scalars[k] * polys[k] (the challenge-weighted polynomial sums of the SHPLONK prover)."""
+    import ctypes as C
+
+    from .device import DevBuf
+
+    polys = [_fr_array(p) for p in polys]
+    n = len(polys[0])
+    assert all(len(p) == n for p in polys) and 1 <= len(polys) <= 16
+    sc = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.uint64) for s in scalars]))
+    bufs = [DevBuf.from_numpy(p) for p in polys]
+    ptrs = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])
+    o = DevBuf(n * 32)
+    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, len(bufs), n, o.ptr, None), "lincomb")
+    out = o.to_numpy(shape=(n, 4))
+    for b in bufs + [o]:
+        b.free()
+    return out

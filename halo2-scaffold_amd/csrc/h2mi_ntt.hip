@@ -213,6 +213,136 @@ __global__ void __launch_bounds__(256) k_powers(fe* out, size_t n, const fe* lo,
   fe_store(&out[i], o);
 }
 
+// ---- polynomial helpers of the opening argument: eval_polynomial, kate_division,
+// linear combinations.  Bandwidth-leaning vector kernels over HBM-resident coefficient vectors. ----------
+
+// Horner in y = x^T over the interleaved coefficient classes i = t (mod T): coalesced loads, one
+// multiplication per coefficient; thread t contributes x^t * P_t(y); block sums go to `partial`.
+__global__ void __launch_bounds__(256) k_eval_poly(const fe* poly, size_t n, uint32_t logT, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
+  __shared__ fe red[256];
+  const uint32_t T = 1u << logT, t = blockIdx.x * blockDim.x + threadIdx.x;
+  f29 y = f29_mul<F9>(pow2tab(lo, hi, h, T - 1), pow2tab(lo, hi, h, 1));  // x^T (Mont261)
+  f29 acc = f29_zero();
+  const size_t m = t < n ? (n - 1 - t) / T + 1 : 0;  // coefficients t, t+T, ... < n
+  for (size_t j = m; j-- > 0;) acc = f29_add(f29_mul<F9>(acc, y), load_unpack(&poly[t + j * T]));
+  f29 term = f29_mul<F9>(acc, pow2tab(lo, hi, h, t));
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(term), o.v);
+  red[threadIdx.x] = o;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fe_add<Fr>(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fe_store(&partial[blockIdx.x], red[0]);
+}
+// out = sum of `count` field elements (single block)
+__global__ void __launch_bounds__(256) k_sum_fe(const fe* in, uint32_t count, fe* out) {
+  __shared__ fe red[256];
+  fe acc = fe_zero();
+  for (uint32_t i = threadIdx.x; i < count; i += 256) acc = fe_add<Fr>(acc, fe_load(&in[i]));
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fe_add<Fr>(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fe_store(out, red[0]);
+}
+
+// kate_division: q_i = sum_{j > i} a_j b^(j-i-1) = b^-(i+1) * SUFFIX(i+1), SUFFIX(j) = sum_{l >= j} a_l b^l.
+// pass 1: s_j = a_j b^j and the inclusive suffix sums inside blocks of 1024 elements (+ block totals)
+constexpr uint32_t KATE_TILE = 1024;
+__global__ void __launch_bounds__(256) k_kate_local(const fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, fe* local, fe* totals) {
+  __shared__ fe tile[KATE_TILE + 8];
+  __shared__ fe tsum[256];
+  const uint32_t tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * KATE_TILE;
+  for (uint32_t r = 0; r < 4; r++) {  // coalesced: element base + tid + 256 r
+    size_t i = base + tid + 256 * r;
+    fe o = fe_zero();
+    if (i < n) {
+      f29 x = f29_mul<F9>(load_unpack(&a[i]), pow2tab(lo, hi, h, (uint32_t)i));
+      f29_pack(f29_reduce_canonical<F9>(x), o.v);
+    }
+    tile[tid + 256 * r] = o;
+  }
+  __syncthreads();
+  // thread owns 4 consecutive elements: local suffix, then a suffix scan over the 256 thread totals
+  fe e3 = tile[4 * tid + 3], e2 = fe_add<Fr>(tile[4 * tid + 2], e3), e1 = fe_add<Fr>(tile[4 * tid + 1], e2), e0 = fe_add<Fr>(tile[4 * tid], e1);
+  tsum[tid] = e0;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive suffix scan (Hillis-Steele)
+    fe v = fe_zero();
+    if (tid + d < 256) v = tsum[tid + d];
+    __syncthreads();
+    tsum[tid] = fe_add<Fr>(tsum[tid], v);
+    __syncthreads();
+  }
+  fe right = tid + 1 < 256 ? tsum[tid + 1] : fe_zero();  // sum of everything to the right of this thread's 4
+  __syncthreads();
+  tile[4 * tid] = fe_add<Fr>(e0, right);
+  tile[4 * tid + 1] = fe_add<Fr>(e1, right);
+  tile[4 * tid + 2] = fe_add<Fr>(e2, right);
+  tile[4 * tid + 3] = fe_add<Fr>(e3, right);
+  __syncthreads();
+  for (uint32_t r = 0; r < 4; r++) {
+    size_t i = base + tid + 256 * r;
+    if (i < n) fe_store(&local[i], tile[tid + 256 * r]);
+  }
+  if (tid == 0) fe_store(&totals[blockIdx.x], tile[0]);
+}
+// pass 2: offsets[b] = sum of totals[b'] for b' > b (single block, sequential over chunks of 256)
+__global__ void __launch_bounds__(256) k_kate_offsets(const fe* totals, uint32_t nblocks, fe* offsets) {
+  __shared__ fe tsum[256];
+  const uint32_t tid = threadIdx.x;
+  fe carry = fe_zero();  // sum of all totals to the right of the current chunk
+  for (int64_t c0 = (int64_t)((nblocks + 255) / 256 - 1) * 256; c0 >= 0; c0 -= 256) {
+    uint32_t b = (uint32_t)c0 + tid;
+    tsum[tid] = b < nblocks ? fe_load(&totals[b]) : fe_zero();
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      fe v = fe_zero();
+      if (tid + d < 256) v = tsum[tid + d];
+      __syncthreads();
+      tsum[tid] = fe_add<Fr>(tsum[tid], v);
+      __syncthreads();
+    }
+    fe excl = fe_add<Fr>(tid + 1 < 256 ? tsum[tid + 1] : fe_zero(), carry);
+    if (b < nblocks) fe_store(&offsets[b], excl);
+    fe chunk_total = tsum[0];
+    __syncthreads();
+    carry = fe_add<Fr>(carry, chunk_total);
+  }
+}
+// pass 3: q_i = (local[i+1] + offsets[block(i+1)]) * binv^(i+1), i < n-1
+__global__ void __launch_bounds__(256) k_kate_finish(const fe* local, const fe* offsets, size_t n, const fe* ilo, const fe* ihi, uint32_t ih, fe* q) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  fe s = fe_add<Fr>(fe_load(&local[i + 1]), fe_load(&offsets[(i + 1) / KATE_TILE]));
+  f29 x = f29_mul<F9>(f29_unpack(s.v), pow2tab(ilo, ihi, ih, (uint32_t)(i + 1)));
+  pack_store(&q[i], x);
+}
+
+// out[i] = sum_k scalar_k * poly_k[i]
+struct LincombArgs {
+  const fe* poly[16];
+  fe scalar[16];  // Mont256
+  uint32_t count;
+};
+__global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f29 acc = f29_zero();
+  for (uint32_t k = 0; k < args.count; k++) {
+    f29 s = f29_from_mont256<F9>(args.scalar[k].v);  // uniform: evaluated on the scalar unit
+    f29 t = f29_mul<F9>(load_unpack(&args.poly[k][i]), s);
+    acc = f29_normalize(f29_add(acc, t));            // < 16 * 1.01p, far below the 169p capacity
+  }
+  f29 r = f29_mul<F9>(acc, f29_const<F9>(F9::ONE));  // back below 2p
+  pack_store(&out[i], r);
+}
+
 // ---- host side: plans and table caches -----------------------------------------------------------
 struct Key {
   uint64_t w[4];
@@ -262,8 +392,13 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
     }
     g_powtabs.clear();
     for (auto& kv : g_plans)
-      for (int i = 0; i < 3; i++)
-        if (kv.second.loc[i]) hipFree(kv.second.loc[i]);
+      for (int i = 0; i < 3; i++) {
+        fe* p = kv.second.loc[i];
+        if (!p) continue;
+        for (int j = i + 1; j < 3; j++)  // passes of equal size share one table
+          if (kv.second.loc[j] == p) kv.second.loc[j] = nullptr;
+        hipFree(p);
+      }
     g_plans.clear();
   }
   PowTab t;
@@ -492,6 +627,69 @@ int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_strea
   int rc = get_powtab(base, log_n, s, &pt);
   if (rc) return rc;
   H2_LAUNCH("k_powers", k_powers, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, (const fe*)pt.lo, (const fe*)pt.hi, pt.h);
+  return H2MI_OK;
+}
+
+
+int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_poly || !point || !d_out || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 30) return H2MI_ERANGE;
+  uint32_t logT = log_n > 20 ? 16 : log_n > 12 ? log_n - 4 : 8;  // T threads, >= 256
+  PowTab pt;
+  int rc = get_powtab(point, logT, s, &pt);  // x^i, i < T
+  if (rc) return rc;
+  const uint32_t nblocks = (1u << logT) / 256;
+  rc = ensure_tmp(nblocks + 8, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_eval_poly", k_eval_poly, nblocks, 256, 0, s, (const fe*)d_poly, n, logT, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
+  H2_LAUNCH("k_sum_fe", k_sum_fe, 1, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
+  return H2MI_OK;
+}
+
+int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_poly || !b || !b_inv || !d_out || n < 2) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 30) return H2MI_ERANGE;
+  PowTab pb, pi;
+  int rc = get_powtab(b, log_n, s, &pb);
+  if (!rc) rc = get_powtab(b_inv, log_n, s, &pi);  // exponents i + 1 <= n - 1 < 2^log_n
+  if (rc) return rc;
+  const uint32_t nblocks = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
+  rc = ensure_tmp(n + 2 * (size_t)nblocks + 16, s);
+  if (rc) return rc;
+  fe* local = g_tmp;
+  fe* totals = g_tmp + n;
+  fe* offsets = totals + nblocks;
+  H2_LAUNCH("k_kate_local", k_kate_local, nblocks, 256, 0, s, (const fe*)d_poly, n, (const fe*)pb.lo, (const fe*)pb.hi, pb.h, local, totals);
+  H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
+  H2_LAUNCH("k_kate_finish", k_kate_finish, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, (const fe*)pi.lo,
+            (const fe*)pi.hi, pi.h, (fe*)d_out);
+  return H2MI_OK;
+}
+
+int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, size_t count, size_t n, void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_polys || !scalars || !d_out || n == 0 || count == 0 || count > 16) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  LincombArgs args;
+  memset(&args, 0, sizeof(args));
+  args.count = (uint32_t)count;
+  for (size_t k = 0; k < count; k++) {
+    if (!d_polys[k]) return H2MI_EINVAL;
+    args.poly[k] = (const fe*)d_polys[k];
+    args.scalar[k] = host_fe(scalars + 4 * k);
+  }
+  H2_LAUNCH("k_lincomb", k_lincomb, ceil_div_u32(n, 256), 256, 0, s, args, n, (fe*)d_out);
   return H2MI_OK;
 }
 

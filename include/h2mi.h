@@ -115,6 +115,17 @@ int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4],
 int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const uint64_t* post_scale_or_null,
                              h2mi_stream_t stream);
 
+/* ---- opening-argument helpers on device-resident coefficient vectors ------------------
+ * halo2_proofs::arithmetic::eval_polynomial(poly, point): out = sum_i poly[i] * point^i  (32 B at d_out) */
+int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream);
+/* halo2_proofs::arithmetic::kate_division(a, b): quotient of a(X) by (X - b), n - 1 coefficients at d_out
+ * (the remainder a(b) is dropped, as in the crate).  The caller passes b^-1 (one CPU inversion). */
+int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out,
+                              h2mi_stream_t stream);
+/* out[i] = sum_k scalars[k] * polys[k][i], count <= 16 (the challenge-weighted sums of SHPLONK) */
+int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars /* count*4 */, size_t count, size_t n, void* d_out,
+                        h2mi_stream_t stream);
+
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
  * generator (1, 2) with on-device normalisation. */

@@ -440,3 +440,21 @@ def witness_like_limbs(n: int, seed: int) -> np.ndarray:
     is_uni = sel >= 95
     out[is_uni] = u[is_uni]
     return out
+
+
+# ---- opening-argument helpers (halo2_proofs::arithmetic::{eval_polynomial, kate_division}, restated) ----
+def eval_polynomial(poly, point: int) -> int:
+    acc = 0
+    for c in reversed(poly):
+        acc = (acc * point + c) % R
+    return acc
+
+
+def kate_division(a, b: int):
+    """quotient of a(X) by (X - b), remainder dropped: q[i-1] = a[i] + b*q[i] from the top coefficient down."""
+    q = [0] * (len(a) - 1)
+    tmp = 0
+    for i in range(len(a) - 1, 0, -1):
+        tmp = (a[i] + b * tmp) % R
+        q[i - 1] = tmp
+    return q

@@ -418,3 +418,29 @@ def test_degree22_sizes(gpu, k):
     ext = d.coeff_to_extended(a)
     back = d.extended_to_coeff(ext)
     assert np.array_equal(back[:n], a) and not back[n:].any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 255, 1024, 4097, 70000])
+def test_eval_polynomial_and_kate_division(gpu, n):
+    a = o.random_field_limbs(n, 77 + n)
+    vals = o.unpack(a, o.R)
+    for x in (5, o.R - 1, o.unpack(o.random_field_limbs(1, 3), o.R)[0]):
+        xl = o.pack([x], o.R)[0]
+        assert o.unpack(gpu.eval_polynomial(a, xl).reshape(1, 4), o.R)[0] == o.eval_polynomial(vals, x)
+        if n >= 2:
+            q = gpu.kate_division(a, xl)
+            assert o.unpack(q, o.R) == o.kate_division(vals, x)
+    if n >= 2:  # (X - b) * q(X) + a(b) == a(X): check through a random evaluation on the host
+        b, z = 12345, 987654321
+        q = o.unpack(gpu.kate_division(a, o.pack([b], o.R)[0]), o.R)
+        assert ((z - b) * o.eval_polynomial(q, z) + o.eval_polynomial(vals, b)) % o.R == o.eval_polynomial(vals, z)
+
+
+def test_lincomb(gpu):
+    n, K = 3000, 5
+    polys = [o.random_field_limbs(n, 200 + k) for k in range(K)]
+    sc = o.random_field_limbs(K, 9)
+    got = o.unpack(gpu.lincomb(polys, sc), o.R)
+    pv = [o.unpack(p, o.R) for p in polys]
+    sv = o.unpack(sc, o.R)
+    assert got == [sum(sv[k] * pv[k][i] for k in range(K)) % o.R for i in range(n)]
