@@ -49,11 +49,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    # rehearsal knobs (not used by the driver): H2MI_DIST_BACKEND=gloo runs the N > 1 path with CPU
+    # collectives, H2MI_DEVICE=<i> pins every rank to one GPU so a 1-GPU box can exercise world_size 2
+    backend = os.environ.get("H2MI_DIST_BACKEND", "nccl")
+    if "H2MI_DEVICE" in os.environ:
+        local_rank = int(os.environ["H2MI_DEVICE"])
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     import _load_pkg
 
@@ -63,7 +72,7 @@ def main():
 
     h2.init(local_rank)
     lib = h2.lib
-    combine = PartialPointCombiner(device=torch.device("cuda", local_rank)) if world > 1 else None
+    combine = PartialPointCombiner(device=coll_dev) if world > 1 else None
     shape = rp.SHAPES[args.shape]
     R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine)
     n = R.n
@@ -93,7 +102,7 @@ def main():
         adds_local += (ba.value + ra.value) * (n_lagr if lagrange else shape.msm_per_proof - n_lagr)
     adds = adds_local
     if dist is not None:
-        t = torch.tensor([adds_local], dtype=torch.int64, device=f"cuda:{local_rank}")
+        t = torch.tensor([adds_local], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t)
         adds = int(t.item())
 
@@ -109,7 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.h2mi_profile_enable(0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
