@@ -444,3 +444,17 @@ def test_lincomb(gpu):
     pv = [o.unpack(p, o.R) for p in polys]
     sv = o.unpack(sc, o.R)
     assert got == [sum(sv[k] * pv[k][i] for k in range(K)) % o.R for i in range(n)]
+
+
+@pytest.mark.parametrize("k", [5, 13])
+def test_cpp_host_example(gpu, k):
+    """the C++ host layer (include/h2mi.hpp) end to end: the reference example's flow at its own k = 5 and a
+    larger k; the binary self-checks commit == commit_lagrange == f(s)*G and the kate_division identity."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    r = subprocess.run([os.path.join(root, "examples", "standard_plonk"), str(k)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "self-check passed" in r.stdout and "proof replay: 11 commitments" in r.stdout
+    assert "Creating proof" in r.stdout

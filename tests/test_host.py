@@ -136,3 +136,17 @@ def test_sliced_msm_combine_gloo_world2(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_cpp_host_example_builds_and_fails_loudly_without_gpu(h2):
+    """examples/standard_plonk.cpp (the C++ mirror of the reference example over include/h2mi.hpp) links against
+    libh2mi.so; without a GPU it must exit with the library's error, never compute on the CPU."""
+    import torch
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    exe = os.path.join(ROOT, "examples", "standard_plonk")
+    assert os.path.exists(exe)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the example is run by the -m gpu tests")
+    r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr
