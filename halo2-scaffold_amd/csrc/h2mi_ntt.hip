@@ -97,13 +97,47 @@ __device__ __forceinline__ void pack_store(fe* p, const f29& a_lt2p) {
   fe_store(p, o);
 }
 
-// m radix-2 DIT stages over C tiles of 2^m elements (bit-reversed order in, natural order out)
+// m DIT stages over C tiles of 2^m elements (bit-reversed order in, natural order out), two stages per
+// LDS round trip: a thread takes the four elements {i, i+h, i+2h, i+3h} (h = 2^s), does the two
+// butterflies of stage s and the two of stage s+1 in registers, and normalises only the four results
+// (limb bounds: a = x +- t < 1.5 * 2^30 may feed the next multiplication un-normalised, y < 2.5 * 2^30).
+// Half the barriers, LDS traffic and carry normalisations of a radix-2 schedule; same multiplications.
 __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const fe* tw, uint32_t m, uint32_t logC) {
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   if (m == 0) return;
-  const uint32_t nbf = 1u << (m - 1 + logC);
-  for (uint32_t s = 0; s < m; s++) {
-    const uint32_t half = 1u << s;
+  uint32_t s = 0;
+  if (m >= 2) {
+    const uint32_t nq = 1u << (m - 2 + logC);
+    for (; s + 1 < m; s += 2) {
+      const uint32_t h = 1u << s;
+      for (uint32_t q = tid; q < nq; q += T) {
+        uint32_t c = q >> (m - 2);
+        uint32_t r = q & ((1u << (m - 2)) - 1);
+        uint32_t pos = r & (h - 1);
+        uint32_t grp = r >> s;
+        uint32_t i = (c << m) | (grp << (s + 2)) | pos;
+        f29 x0 = lds_get(lds, dstride, i), x1 = lds_get(lds, dstride, i + h);
+        f29 x2 = lds_get(lds, dstride, i + 2 * h), x3 = lds_get(lds, dstride, i + 3 * h);
+        f29 t1 = x1, t3 = x3;
+        if (s != 0) {
+          f29 wa = f29_unpack(tw[pos << (m - 1 - s)].v);
+          t1 = f29_mul<F9>(x1, wa);
+          t3 = f29_mul<F9>(x3, wa);
+        }
+        f29 a0 = f29_add(x0, t1), a1 = f29_sub(x0, t1, F9::K2);
+        f29 a2 = f29_add(x2, t3), a3 = f29_sub(x2, t3, F9::K2);
+        f29 u2 = f29_mul<F9>(a2, f29_unpack(tw[pos << (m - 2 - s)].v));
+        f29 u3 = f29_mul<F9>(a3, f29_unpack(tw[(pos + h) << (m - 2 - s)].v));
+        lds_put(lds, dstride, i, f29_normalize(f29_add(a0, u2)));
+        lds_put(lds, dstride, i + h, f29_normalize(f29_add(a1, u3)));
+        lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, u2, F9::K2)));
+        lds_put(lds, dstride, i + 3 * h, f29_normalize(f29_sub(a1, u3, F9::K2)));
+      }
+      __syncthreads();
+    }
+  }
+  if (s < m) {  // odd m: one closing radix-2 stage (s = m - 1; for m = 1 it is the multiplication-free stage 0)
+    const uint32_t nbf = 1u << (m - 1 + logC), half = 1u << s;
     for (uint32_t b = tid; b < nbf; b += T) {
       uint32_t c = b >> (m - 1);
       uint32_t i_ = b & ((1u << (m - 1)) - 1);
@@ -113,8 +147,6 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
       f29 u = lds_get(lds, dstride, i), v = lds_get(lds, dstride, i + half);
       f29 t = v;
       if (s != 0) t = f29_mul<F9>(v, f29_unpack(tw[pos << (m - 1 - s)].v));
-      else t = f29_normalize(v);
-      // u + t and u - t + 2p  (t < 1.2p by the multiplication bound; stage 0: t is an input < 1.2p)
       lds_put(lds, dstride, i, f29_normalize(f29_add(u, t)));
       lds_put(lds, dstride, i + half, f29_normalize(f29_sub(u, t, F9::K2)));
     }
@@ -499,7 +531,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
   }
   const uint32_t tile_elems_log = env_u32("H2MI_NTT_TILE_LOG", 10);  // elements staged per block
   const uint32_t remap = env_u32("H2MI_NTT_XCD_REMAP", 1);
-  uint32_t nthreads = env_u32("H2MI_NTT_THREADS", 512);
+  uint32_t nthreads = env_u32("H2MI_NTT_THREADS", 256);
   if (nthreads != 64 && nthreads != 128 && nthreads != 256 && nthreads != 512) nthreads = 256;
   static bool attr_set = false;
   if (!attr_set) {  // tiles above 64 KiB of LDS need the opt-in
