@@ -398,8 +398,13 @@ struct Plan {
 
 static std::map<Key, PowTab> g_powtabs;
 static std::map<Key, Plan> g_plans;
+// one scratch vector shared by the NTT passes and the polynomial helpers; calls are serialised by the
+// library mutex, and an event orders consecutive users that run on different streams
 static fe* g_tmp = nullptr;
 static size_t g_tmp_elems = 0;
+static hipEvent_t g_tmp_event = nullptr;
+static hipStream_t g_tmp_stream = nullptr;
+static bool g_tmp_used = false;
 
 static fe host_fe(const uint64_t w[4]) {
   fe r;
@@ -495,17 +500,27 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
 }
 
 static int ensure_tmp(size_t elems, hipStream_t s) {
-  if (g_tmp_elems >= elems) return H2MI_OK;
-  if (g_tmp) {
-    H2_HIP(hipStreamSynchronize(s));
-    H2_HIP(hipFree(g_tmp));
-    g_tmp = nullptr;
-    g_tmp_elems = 0;
+  if (g_tmp_used && g_tmp_stream != s) H2_HIP(hipStreamWaitEvent(s, g_tmp_event, 0));  // previous user on another stream
+  if (g_tmp_elems < elems) {
+    if (g_tmp) {
+      H2_HIP(hipDeviceSynchronize());
+      H2_HIP(hipFree(g_tmp));
+      g_tmp = nullptr;
+      g_tmp_elems = 0;
+    }
+    hipError_t e = hipMalloc(&g_tmp, elems * 32);
+    if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+    H2_HIP(e);
+    g_tmp_elems = elems;
   }
-  hipError_t e = hipMalloc(&g_tmp, elems * 32);
-  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
-  H2_HIP(e);
-  g_tmp_elems = elems;
+  return H2MI_OK;
+}
+// call after the last kernel that touches g_tmp has been queued on `s`
+static int release_tmp(hipStream_t s) {
+  if (!g_tmp_event) H2_HIP(hipEventCreateWithFlags(&g_tmp_event, hipEventDisableTiming));
+  H2_HIP(hipEventRecord(g_tmp_event, s));
+  g_tmp_stream = s;
+  g_tmp_used = true;
   return H2MI_OK;
 }
 
@@ -589,6 +604,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     }
     log_seg -= pp.m;
   }
+  if (pl.P > 1) return release_tmp(s);
   return H2MI_OK;
 }
 
@@ -680,7 +696,7 @@ int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4],
   if (rc) return rc;
   H2_LAUNCH("k_eval_poly", k_eval_poly, nblocks, 256, 0, s, (const fe*)d_poly, n, logT, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
   H2_LAUNCH("k_sum_fe", k_sum_fe, 1, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
-  return H2MI_OK;
+  return release_tmp(s);
 }
 
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out, h2mi_stream_t stream) {
@@ -705,7 +721,7 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
   H2_LAUNCH("k_kate_finish", k_kate_finish, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, (const fe*)pi.lo,
             (const fe*)pi.hi, pi.h, (fe*)d_out);
-  return H2MI_OK;
+  return release_tmp(s);
 }
 
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, size_t count, size_t n, void* d_out, h2mi_stream_t stream) {

@@ -105,3 +105,46 @@ def test_full_add_and_double_trees(host):
         _chain(host, pts[:3], signs[:3], tree)                # mostly empty groups (identity operands)
     _chain(host, [pts[0]] * 16, [0] * 16, 16)                 # all groups equal: every fold step doubles
     _chain(host, [pts[0], pts[0]], [0, 1], 2)                 # groups cancel
+
+
+def test_long_chain_keeps_invariants(host):
+    """5,000 mixed additions into one accumulator: the loose-reduction invariants of g1_29.cuh must hold
+    indefinitely (a drift in the value bounds would eventually corrupt the sum)."""
+    rng = np.random.default_rng(99)
+    base = [o.g1_mul(int(rng.integers(1, 1 << 62)), o.G1_GEN) for _ in range(50)]
+    pts, signs = [], []
+    for i in range(5000):
+        pts.append(base[int(rng.integers(0, 50))])
+        signs.append(int(rng.integers(0, 2)))
+    P = o.pack_points(pts)
+    S = np.array(signs, dtype=np.uint8)
+    out = np.zeros(16, dtype=np.uint64)
+    host.f29t_madd_chain(P.ctypes.data, S.ctypes.data, len(pts), out.ctypes.data, 0)
+    # expected: sum over the 50 base points of (count_plus - count_minus) * P
+    coef = {}
+    for p, s in zip(pts, signs):
+        coef[p] = coef.get(p, 0) + (-1 if s else 1)
+    want = None
+    for p, c in coef.items():
+        want = o.g1_add(want, o.g1_mul(c % o.R, p))
+    assert _xyzz_to_affine(out) == want
+
+
+def test_extreme_limb_patterns(host):
+    """field elements whose 29-bit limbs are all-ones / alternating / near the modulus: worst cases for the
+    64-bit column accumulators of f29_mul and f29_sqr."""
+    for field, mod in [(0, o.Q), (1, o.R)]:
+        pats = [mod - 1, mod - 2, (1 << 254) - 1, ((1 << 254) - 1) - mod, int("1" * 253, 2), int("10" * 126, 2), int("01" * 127, 2),
+                ((1 << 29) - 1) * sum(1 << (29 * i) for i in range(8)), (1 << 232) - 1, (mod >> 1), (mod >> 1) + 1]
+        pats = [p % mod for p in pats]
+        A = o.pack([a for a in pats for _ in pats], mod)
+        B = o.pack([b for _ in pats for b in pats], mod)
+        n = len(A)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        av, bv = o.unpack(A, mod), o.unpack(B, mod)
+        host.f29t_mul(field, 0, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+        assert o.unpack(out, mod) == [x * y % mod for x, y in zip(av, bv)]
+        host.f29t_mul(field, 2, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+        assert o.unpack(out, mod) == [(x + y) * (x - y) % mod for x, y in zip(av, bv)]
+        host.f29t_mul(field, 4, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
+        assert o.unpack(out, mod) == [x * x % mod for x in av]
