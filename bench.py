@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--shape", choices=["standard_plonk", "halo2_lib_gate", "range_lookup"], default="standard_plonk",
                     help="proof shape to replay (BASELINE.json metric is quoted on standard_plonk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicate-all-ntts", action="store_true",
+                    help="N > 1: every rank replays every NTT (default: leaf transforms are spread round-robin)")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 size of the CPU baseline sample MSM/NTT")
     args = ap.parse_args()
 
@@ -74,7 +76,7 @@ def main():
     lib = h2.lib
     combine = PartialPointCombiner(device=coll_dev) if world > 1 else None
     shape = rp.SHAPES[args.shape]
-    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine)
+    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine, spread_leaf_ntts=not args.replicate_all_ntts)
     n = R.n
 
     def sync_all():
@@ -84,9 +86,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    commitments = None
     for _ in range(args.warmup):
         R.step()
-        R.finish()
+        commitments = R.finish()
 
     # G1 additions one step performs (bucket insertions + reduction adds), summed over the 11 MSMs
     import ctypes as C
@@ -113,7 +116,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         R.step()
-        R.finish()
+        commitments = R.finish()
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.h2mi_profile_enable(0)
@@ -147,6 +150,14 @@ def main():
             dist.destroy_process_group()
         return
 
+    # digest of the proof's commitments in canonical affine form: identical for every N (same inputs, same SRS)
+    import hashlib
+
+    import numpy as np
+
+    aff = np.zeros((len(commitments), 8), dtype=np.uint64)
+    h2._lib.check(lib.h2mi_g1_batch_normalize(np.ascontiguousarray(commitments).ctypes.data, len(commitments), aff.ctypes.data), "normalize")
+    digest = hashlib.sha256(aff.tobytes()).hexdigest()
     ms_per_step = elapsed / args.steps * 1e3
     value = adds / (ms_per_step * 1e-3)
     c, W, nb, nreg = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
@@ -198,6 +209,9 @@ def main():
             "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
             "what_is_timed": "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation",
         },
+        "commitments_sha256": digest,
+        "ntt_placement": ("single GPU" if world == 1 else "leaf transforms spread round-robin, consumed transforms on every rank"
+                          if R.spread else "every rank replays every transform"),
         "g1_adds_per_step": adds,
         "msm_pairs_per_s": round(shape.msm_per_proof * n / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": {"msm": round(msm_ms, 3), "ntt": round(ntt_ms, 3)},

@@ -14,9 +14,12 @@ Shapes:
   RANGE_LOOKUP    reference src/scaffold.rs:434-485 RangeWithInstanceCircuitBuilder (range.rs): adds one
                   lookup-advice column and one lookup argument => constraint degree 4, extended domain 4n.
 
-Multi-GPU: every rank replays the NTTs on its own GPU (NTT is single-GPU by design) and owns one
-contiguous slice of every base set; each MSM runs on the slice and the 96-byte partial points are
-combined once per proof by `combine` (all-gather + fold, see dist.py).
+Multi-GPU: every rank owns one contiguous slice of every base set; each MSM runs on the slice and the
+96-byte partial points are combined once per proof by `combine` (all-gather + fold, see dist.py).  Every
+NTT runs on ONE GPU (NTT is single-GPU by design): a transform whose output feeds a later
+commitment (h(X), the polynomials opened by SHPLONK) is replayed by every rank, which then reads its own
+slice with no exchange; the independent "leaf" transforms (coefficient / extended forms that only feed
+gate evaluation) are spread round-robin over the ranks as replicas — no collective.
 """
 from dataclasses import dataclass
 
@@ -67,8 +70,9 @@ NTT_PER_PROOF = STANDARD_PLONK.ntt_per_proof
 
 class ProofReplay:
     def __init__(self, shape: ProofShape, k: int, rank: int = 0, world: int = 1, srs_secret: int = 0x5EC2E7 + 0x48324D49, dist="uniform",
-                 combine=None):
+                 combine=None, spread_leaf_ntts: bool = True):
         self.shape = shape
+        self.spread = spread_leaf_ntts and world > 1
         self.k, self.n = k, 1 << k
         self.rank, self.world = rank, world
         self.combine = combine
@@ -121,15 +125,24 @@ class ProofReplay:
         self._slot += 1
         self.counts["msm"] += 1
 
-    def _to_coeff_and_extended(self, lagr: DevBuf, w: DevBuf, e: DevBuf):
-        """lagrange_to_coeff then coeff_to_extended (zero padding of e restored at the end of step())."""
+    def _mine(self) -> bool:
+        """round-robin owner of the next leaf transform"""
+        self._leaf += 1
+        return (not self.spread) or (self._leaf % self.world == self.rank)
+
+    def _to_coeff_and_extended(self, lagr: DevBuf, w: DevBuf, e: DevBuf, coeff_needed: bool = False):
+        """lagrange_to_coeff then coeff_to_extended (zero padding of e restored at the end of step()).
+        `coeff_needed`: the coefficient form feeds a later commitment, so every rank computes it."""
         n = self.n
-        w.copy_from(lagr, n * 32)
-        self.domain.lagrange_to_coeff_dev(w)
-        e.copy_from(w, n * 32)
-        self.domain.coeff_to_extended_dev(e)
-        self.counts["intt_n"] += 1
-        self.counts["coset_ntt_ext"] += 1
+        mine = self._mine()
+        if mine or coeff_needed:
+            w.copy_from(lagr, n * 32)
+            self.domain.lagrange_to_coeff_dev(w)
+            self.counts["intt_n"] += 1
+        if mine:
+            e.copy_from(w, n * 32)
+            self.domain.coeff_to_extended_dev(e)
+            self.counts["coset_ntt_ext"] += 1
 
     def step(self, phase_joins: bool = True):
         """one proof's worth of hot-path work, queued on the library streams (asynchronous).
@@ -140,6 +153,7 @@ class ProofReplay:
         sh, d, n = self.shape, self.domain, self.n
         join = (lambda: check(lib.h2mi_join(), "join")) if phase_joins else (lambda: None)
         self._slot = 0
+        self._leaf = -1
         w_it, e_it = iter(self.work), iter(self.ext)
         # phase 1: instance columns (KZG: hashed, not committed): lagrange_to_coeff (+ extended below)
         inst_we = [(c, next(w_it), next(e_it)) for c in self.instance]
@@ -156,7 +170,8 @@ class ProofReplay:
         # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per chunk
         for c in self.perm_z:
             self._msm(c, lagrange=True)
-            self._to_coeff_and_extended(c, next(w_it), next(e_it))
+            w = next(w_it)
+            self._to_coeff_and_extended(c, w, next(e_it), coeff_needed=w is self.work[0])
         # phase 5: lookup products
         for i in range(sh.n_lookups):
             self._msm(self.lookup[3 * i + 2], lagrange=True)
@@ -167,10 +182,11 @@ class ProofReplay:
         first_adv_w = None
         for c in self.advice:
             w = next(w_it)
+            first = first_adv_w is None
             first_adv_w = first_adv_w or w
-            self._to_coeff_and_extended(c, w, next(e_it))
+            self._to_coeff_and_extended(c, w, next(e_it), coeff_needed=first or w is self.work[0])
         for c, w, e in inst_we:
-            self._to_coeff_and_extended(c, w, e)
+            self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
         for c in self.lookup:
             self._to_coeff_and_extended(c, next(w_it), next(e_it))
         # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each -> challenge x
