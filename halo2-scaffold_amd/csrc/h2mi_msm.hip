@@ -644,10 +644,17 @@ int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* b
   return H2MI_OK;
 }
 
+// G1::identity() = (0, 1, 0) in Montgomery form: what best_multiexp returns for empty slices
+static const uint64_t G1_IDENTITY[12] = {0, 0, 0, 0, 0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL, 0, 0, 0, 0};
+
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
-  if (!d_scalars || !d_out_jacobian || n == 0) return H2MI_EINVAL;
+  if (!d_out_jacobian || (!d_scalars && n != 0)) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (n == 0) {  // empty sum
+    H2_HIP(hipMemcpyAsync(d_out_jacobian, G1_IDENTITY, 96, hipMemcpyHostToDevice, pick_stream(stream)));
+    return H2MI_OK;
+  }
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (n > it->second->n) return H2MI_ERANGE;
@@ -656,7 +663,12 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
 
 int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out[12]) {
   H2_REQUIRE_INIT();
-  if (!scalars || !out || n == 0) return H2MI_EINVAL;
+  if (!out) return H2MI_EINVAL;
+  if (n == 0) {  // best_multiexp(&[], &[]) = identity
+    memcpy(out, G1_IDENTITY, 96);
+    return H2MI_OK;
+  }
+  if (!scalars) return H2MI_EINVAL;
   if (handle == 0 && !bases) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   uint64_t h = handle;
