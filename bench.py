@@ -196,7 +196,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u32x8 (254-bit Montgomery integers)",
+        "dtype": "u32 (254-bit Montgomery integers as 9 x 29-bit limbs, 64-bit multiply-accumulate)",
         "data": "synthetic",
         "config": {
             "workload": f"{shape.name} hot-path replay k={args.k}: {shape.msm_per_proof} MSM(2^{args.k}) + {shape.ntt_per_proof['intt_n']} iNTT(2^{args.k}) + "

@@ -195,6 +195,12 @@ def test_msm_edge_cases(gpu):
     _msm_case(gpu, carry, pts[:6])
 
 
+def test_empty_msm_is_identity(gpu):
+    out = gpu.best_multiexp(np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64))
+    assert o.unpack_jacobian(out) is None
+    assert o.unpack(out[4:8].reshape(1, 4), o.Q) == [1]  # (0, 1, 0) = G1::identity()
+
+
 def test_length_mismatch_raises(gpu):
     with pytest.raises(AssertionError):
         gpu.best_multiexp(np.zeros((3, 4), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64))
