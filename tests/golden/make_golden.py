@@ -24,6 +24,38 @@ def pt(p):
     return None if p is None else [hx(p[0]), hx(p[1])]
 
 
+def replay_commitments(k):
+    """BASELINE config 0/1 (standard_plonk, plumbing size): the 11 commitments of the hot-path replay at 2^k rows,
+    computed entirely on the CPU (big-integer SRS scalars, C restatement of best_multiexp for the sums).
+    Inputs: SRS secret and column vectors exactly as halo2-scaffold_amd/replay.py seeds them."""
+    import numpy as np
+
+    from oracle import cref
+
+    n = 1 << k
+    secret = 0x5EC2E7 + 0x48324D49
+    pw, lag = o.srs_scalars(k, secret)
+    g = cref.g1_mul_gen(o.pack(pw, o.R), 4)
+    gl = cref.g1_mul_gen(o.pack(lag, o.R), 4)
+    dom = o.Domain(k, 3)
+    seed = o.SEED
+    advice = [o.random_field_limbs(n, seed + 10 + i) for i in range(3)]
+    perm_z = [o.random_field_limbs(n, seed + 60 + i) for i in range(3)]
+    random_poly = o.random_field_limbs(n, seed + 20)
+    hvals = o.unpack(o.random_field_limbs(1 << dom.extended_k, seed + 30), o.R)
+    hcoef = dom.extended_to_coeff(hvals)
+    commits = [cref.msm(c, gl, 2) for c in advice + perm_z]
+    commits.append(cref.msm(random_poly, g, 2))
+    for piece in range(2):
+        commits.append(cref.msm(o.pack(hcoef[piece * n : (piece + 1) * n], o.R), g, 2))
+    adv0 = o.pack(dom.lagrange_to_coeff(o.unpack(advice[0], o.R)), o.R)
+    z0 = o.pack(dom.lagrange_to_coeff(o.unpack(perm_z[0], o.R)), o.R)
+    commits.append(cref.msm(adv0, g, 2))
+    commits.append(cref.msm(z0, g, 2))
+    aff = cref.normalize(np.stack(commits))
+    return {"k": k, "srs_secret": hx(secret), "commitments": [pt(p) for p in o.unpack_points(aff)]}
+
+
 def main():
     out = {"comment": "self-derived known answers (oracle/bn254.py); canonical (non-Montgomery) integers", "seed": o.SEED}
     out["constants"] = {
@@ -65,6 +97,7 @@ def main():
     # extended domain (k = 3, cs degree 3)
     d = o.Domain(3, 3)
     out["domain"] = {"k": 3, "j": 3, "extended_k": d.extended_k, "coeff_to_extended": [hx(x) for x in d.coeff_to_extended(coeffs)]}
+    out["replay_k8"] = replay_commitments(8)
     with open(os.path.join(HERE, "bn254_vectors.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(HERE, "bn254_vectors.json"))

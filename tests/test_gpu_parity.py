@@ -504,3 +504,16 @@ def test_pipelined_msm_stress(gpu):
     for i in range(M):
         assert np.array_equal(got[i], want[i]), i
     params.release()
+
+
+def test_golden_replay_k8(gpu):
+    """BASELINE configs 0/1: the replay's 11 commitments at 2^8 rows equal the committed CPU-computed vectors."""
+    from oracle import cref
+    from halo2_scaffold_amd import replay as rp
+
+    gold = GOLD["replay_k8"]
+    R = rp.StandardPlonkReplay(gold["k"])
+    R.step()
+    got = o.unpack_points(cref.normalize(R.finish()))
+    assert got == [_gpt(p) for p in gold["commitments"]]
+    R.release()

@@ -172,3 +172,18 @@ def test_c_ntt_golden():
     a = o.pack([int(x, 16) for x in t["input"]], o.R)
     cref.ntt(a, o.pack([int(t["omega"], 16)], o.R)[0], t["log_n"], 2)
     assert o.unpack(a, o.R) == [int(x, 16) for x in t["forward"]]
+
+
+def test_golden_replay_k8_self_consistency():
+    """BASELINE config 0 (plumbing size, CPU only): the committed replay commitments are what the big-integer
+    oracle gets for the same seeded SRS and vectors (spot-check two of the eleven: naive double-and-add MSM)."""
+    r = GOLD["replay_k8"]
+    k, n = r["k"], 1 << r["k"]
+    secret = int(r["srs_secret"], 16)
+    pw, lag = o.srs_scalars(k, secret)
+    adv0 = o.unpack(o.random_field_limbs(n, o.SEED + 10), o.R)
+    # commit_lagrange(advice[0]) = (sum_i adv0[i] * L_i(s)) * G
+    assert _pt(r["commitments"][0]) == o.g1_mul(sum(a * l for a, l in zip(adv0, lag)) % o.R, o.G1_GEN)
+    rp = o.unpack(o.random_field_limbs(n, o.SEED + 20), o.R)
+    assert _pt(r["commitments"][6]) == o.g1_mul(sum(c * p for c, p in zip(rp, pw)) % o.R, o.G1_GEN)
+    assert len(r["commitments"]) == 11 and all(o.is_on_curve(_pt(p)) for p in r["commitments"])
