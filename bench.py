@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=20, help="log2 rows (BASELINE.json metric is quoted at k=20)")
-    ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--dist", choices=["uniform", "witness", "circuit"], default="uniform",
+                    help="advice/instance columns: uniform (dense worst case, default), witness (90 %% zeros), circuit (the 3 used rows + "
+                         "blinding rows of the reference's StandardPlonk; every other vector stays dense)")
     ap.add_argument("--shape", choices=["standard_plonk", "halo2_lib_gate", "range_lookup"], default="standard_plonk",
                     help="proof shape to replay (BASELINE.json metric is quoted on standard_plonk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -94,7 +94,7 @@ class ProofReplay:
             self.params._g_dev = DevBuf.from_numpy(g)
             self.params._gl_dev = DevBuf.from_numpy(gl)
             self.params._register()
-        gen = synth.witness_like_fr if dist == "witness" else synth.uniform_fr
+        gen = {"witness": synth.witness_like_fr, "circuit": synth.circuit_like_fr}.get(dist, synth.uniform_fr)
         sh = shape
         # Lagrange-basis vectors: advice, lookup (A', S', z) triples, permutation products, instance
         self.advice = [DevBuf.from_numpy(gen(n, synth.SEED + 10 + i)) for i in range(sh.n_advice)]

@@ -60,3 +60,14 @@ def witness_like_fr(n: int, seed: int = SEED) -> np.ndarray:
     uni = sel >= 95
     out[uni] = u[uni]
     return out
+
+
+def circuit_like_fr(n: int, seed: int = SEED, used_rows: int = 3, blinding_rows: int = 5) -> np.ndarray:
+    """an advice column of the reference's StandardPlonk circuit at 2^k rows (src/circuits/standard_plonk.rs:
+    83-108): `used_rows` assigned cells at the top, zeros below, random blinding factors in the last rows."""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    u = uniform_fr(used_rows + blinding_rows, seed)
+    out[: min(used_rows, n)] = u[: min(used_rows, n)]
+    if n > blinding_rows:
+        out[n - blinding_rows :] = u[used_rows:]
+    return out
