@@ -97,14 +97,16 @@ def main():
     import ctypes as C
 
     adds_local = 0
-    for lagrange, buf in [(True, R.cols[0]), (False, R.random_poly)]:
+    n_coeff = 1 + (shape.cs_degree - 1) + 2  # random poly, h pieces, SHPLONK: dense coefficient vectors
+    probes = [(True, R.advice[0], shape.n_advice), (True, R.perm_z[0], shape.n_perm_z), (False, R.random_poly, n_coeff)]
+    if shape.n_lookups:
+        probes.append((True, R.lookup[0], 3 * shape.n_lookups))
+    for lagrange, buf, mult in probes:
         handle = R.params.g_lagrange_handle if lagrange else R.params.g_handle
         h2._lib.check(lib.h2mi_msm_bn254_g1_dev(handle, buf.ptr + R.lo * 32, R.n_local, R.out.ptr, None), "msm")
         ba, ra = C.c_uint64(), C.c_uint64()
         h2._lib.check(lib.h2mi_msm_last_stats(handle, C.byref(ba), C.byref(ra)), "stats")
-        # uniform columns: every MSM of the step has the same expected insertion count
-        n_lagr = shape.n_advice + 3 * shape.n_lookups + shape.n_perm_z
-        adds_local += (ba.value + ra.value) * (n_lagr if lagrange else shape.msm_per_proof - n_lagr)
+        adds_local += (ba.value + ra.value) * mult  # vectors of one kind share a distribution
     adds = adds_local
     if dist is not None:
         t = torch.tensor([adds_local], dtype=torch.int64, device=coll_dev)
