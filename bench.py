@@ -251,6 +251,10 @@ def cpu_baseline(R, args, n):
 
     from oracle import cref
 
+    try:
+        cref.use_native()  # compile the restatement for this host's CPU
+    except Exception:
+        pass  # fall back to the portable build
     threads = host_threads()
     ls = args.cpu_sample_log if args.cpu_sample_log is not None else min(args.k, 20)
     ns = 1 << ls

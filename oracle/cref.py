@@ -21,12 +21,24 @@ def build(force=False):
 _lib = None
 
 
-def lib():
+def use_native():
+    """(bench.py's cpu_baseline leg) rebuild with -march=native ON THIS HOST and switch to that library, so
+    the timed CPU baseline gets the host's mulx/adx code generation; never shipped between machines."""
+    global _lib
+    so = os.path.join(_HERE, "libh2ref_native.so")
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libh2ref_native.so"])
+    _lib = None
+    lib(path=so)
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        build()
+        if path is None:
+            build()
+            path = _SO
         try:
-            _lib = C.CDLL(_SO)
+            _lib = C.CDLL(path)
         except OSError:
             build(force=True)
             _lib = C.CDLL(_SO)
