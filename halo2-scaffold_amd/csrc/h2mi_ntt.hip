@@ -375,6 +375,58 @@ __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe*
   pack_store(&out[i], r);
 }
 
+// ---- quotient numerator of the reference's StandardPlonk circuit -------------------------
+// halo2_proofs plonk/evaluation.rs `evaluate_h` specialised to src/circuits/standard_plonk.rs: one gate
+// q_a a + q_b b + q_c c + q_ab a b + constant, three permutation sets of one column each; terms combined by
+// Horner in y; result already divided by X^n - 1 (its inverse on the coset repeats with period 2^(ext_k-k)).
+// Element-wise over the extended domain; all vectors stay in HBM.  Montgomery-2^256 throughout (fp.cuh):
+// products of two data values need one closed domain.
+struct PlonkCosets {
+  const fe* advice[3];
+  const fe* fixed[5];
+  const fe* sigma[3];
+  const fe* z[3];
+  const fe* l0;
+  const fe* l_last;
+  const fe* l_active;
+};
+__global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma,
+                                                                    fe y, fe delta, fe zeta, const fe* xlo, const fe* xhi, uint32_t xh,
+                                                                    const fe* t_inv, fe* out) {
+  const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
+  uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= size) return;
+  const uint32_t r_next = (idx + rot) & (size - 1), r_last = (idx + size - last_rot * rot) & (size - 1);
+  fe a = fe_load(&c.advice[0][idx]), b = fe_load(&c.advice[1][idx]), cc = fe_load(&c.advice[2][idx]);
+  fe v = fe_mul<Fr>(fe_load(&c.fixed[0][idx]), a);
+  v = fe_add<Fr>(v, fe_mul<Fr>(fe_load(&c.fixed[1][idx]), b));
+  v = fe_add<Fr>(v, fe_mul<Fr>(fe_load(&c.fixed[2][idx]), cc));
+  v = fe_add<Fr>(v, fe_mul<Fr>(fe_mul<Fr>(fe_load(&c.fixed[3][idx]), a), b));
+  v = fe_add<Fr>(v, fe_load(&c.fixed[4][idx]));
+  fe z0 = fe_load(&c.z[0][idx]), z1 = fe_load(&c.z[1][idx]), z2 = fe_load(&c.z[2][idx]);
+  fe l0 = fe_load(&c.l0[idx]), ll = fe_load(&c.l_last[idx]), la = fe_load(&c.l_active[idx]);
+  const fe one = fe_one<Fr>();
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, z0), l0));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z2), z2), ll));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z1, fe_load(&c.z[0][r_last])), l0));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z2, fe_load(&c.z[1][r_last])), l0));
+  // X = zeta * extended_omega^idx ; current_delta = beta * X * DELTA^m
+  fe X;
+  f29_to_mont256<F9>(pow2tab(xlo, xhi, xh, idx), X.v);
+  fe cur = fe_mul<Fr>(beta, fe_mul<Fr>(zeta, X));
+  const fe adv[3] = {a, b, cc};
+  const fe zs[3] = {z0, z1, z2};
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    fe left = fe_mul<Fr>(fe_load(&c.z[m][r_next]), fe_add<Fr>(fe_add<Fr>(adv[m], fe_mul<Fr>(beta, fe_load(&c.sigma[m][idx]))), gamma));
+    fe right = fe_mul<Fr>(zs[m], fe_add<Fr>(fe_add<Fr>(adv[m], cur), gamma));
+    cur = fe_mul<Fr>(cur, delta);
+    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la));
+  }
+  v = fe_mul<Fr>(v, fe_load(&t_inv[idx & (rot - 1)]));
+  fe_store(&out[idx], v);
+}
+
 // ---- host side: plans and table caches -----------------------------------------------------------
 struct Key {
   uint64_t w[4];
@@ -738,6 +790,39 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, siz
     args.scalar[k] = host_fe(scalars + 4 * k);
   }
   H2_LAUNCH("k_lincomb", k_lincomb, ceil_div_u32(n, 256), 256, 0, s, args, n, (fe*)d_out);
+  return H2MI_OK;
+}
+
+
+int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,
+                                       const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4],
+                                       const uint64_t zeta[4], const uint64_t extended_omega[4], const uint64_t* t_inv, void* d_h_out,
+                                       h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
+  if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  PlonkCosets pc;
+  for (int i = 0; i < 3; i++) { pc.advice[i] = (const fe*)c->advice[i]; pc.sigma[i] = (const fe*)c->sigma[i]; pc.z[i] = (const fe*)c->z[i]; }
+  for (int i = 0; i < 5; i++) pc.fixed[i] = (const fe*)c->fixed[i];
+  pc.l0 = (const fe*)c->l0; pc.l_last = (const fe*)c->l_last; pc.l_active = (const fe*)c->l_active;
+  for (int i = 0; i < 3; i++) if (!pc.advice[i] || !pc.sigma[i] || !pc.z[i]) return H2MI_EINVAL;
+  for (int i = 0; i < 5; i++) if (!pc.fixed[i]) return H2MI_EINVAL;
+  if (!pc.l0 || !pc.l_last || !pc.l_active) return H2MI_EINVAL;
+  PowTab px;
+  int rc = get_powtab(extended_omega, extended_k, s, &px);
+  if (rc) return rc;
+  const uint32_t rot = 1u << (extended_k - k);
+  fe* d_tinv = nullptr;
+  H2_HIP(hipMalloc(&d_tinv, rot * 32));
+  H2_HIP(hipMemcpyAsync(d_tinv, t_inv, rot * 32, hipMemcpyHostToDevice, s));
+  const uint32_t size = 1u << extended_k;
+  H2_LAUNCH("k_evaluate_h_standard_plonk", k_evaluate_h_standard_plonk, ceil_div_u32(size, 256), 256, 0, s, pc, extended_k, k, blinding_factors + 1,
+            host_fe(beta), host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, (const fe*)d_tinv,
+            (fe*)d_h_out);
+  H2_HIP(hipStreamSynchronize(s));  // t_inv staging buffer is released here
+  hipFree(d_tinv);
   return H2MI_OK;
 }
 

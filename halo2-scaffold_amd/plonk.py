@@ -1,0 +1,53 @@
+"""Quotient step of create_proof for the reference's StandardPlonk circuit, on the device.
+
+Mirror of halo2_proofs plonk/evaluation.rs `evaluate_h` followed by `divide_by_vanishing_poly`, specialised
+to the constraint system of reference src/circuits/standard_plonk.rs:29-48 (one degree-3 gate, equality on
+a, b, c => three permutation sets of one column).  Inputs are extended-domain DevBufs; the per-domain
+scalars (coset generator, DELTA, the few inverses of X^n - 1 on the coset) are computed on the host as
+EvaluationDomain::new / keygen do.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import field as F
+from ._lib import check, lib
+from .device import DevBuf
+from .domain import EvaluationDomain
+
+FR_DELTA = pow(F.FR_MULTIPLICATIVE_GENERATOR, 1 << F.FR_S, F.FR_MODULUS)  # halo2curves Fr::DELTA
+BLINDING_FACTORS = 5  # ConstraintSystem::blinding_factors() for this circuit
+
+
+class _Cosets(C.Structure):
+    _fields_ = [("advice", C.c_void_p * 3), ("fixed", C.c_void_p * 5), ("sigma", C.c_void_p * 3), ("z", C.c_void_p * 3),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p)]
+
+
+def vanishing_inverses(domain: EvaluationDomain) -> np.ndarray:
+    """(X^n - 1)^-1 on the extended coset: 2^(extended_k - k) distinct values."""
+    r = F.FR_MODULUS
+    rot = 1 << (domain.extended_k - domain.k)
+    vals = []
+    for i in range(rot):
+        X = domain.g_coset * pow(domain.extended_omega, i, r) % r
+        vals.append(F.fr_inv((pow(X, domain.n, r) - 1) % r))
+    return np.stack([F.fr_to_mont_limbs(v) for v in vals])
+
+
+def evaluate_h(domain: EvaluationDomain, advice, fixed, sigma, z, l0: DevBuf, l_last: DevBuf, l_active: DevBuf, beta: int, gamma: int, y: int,
+               out: DevBuf, stream=None) -> None:
+    """h(X) on the extended coset (already divided by X^n - 1) into `out`; all operands are DevBufs of
+    extended_len() elements."""
+    assert len(advice) == 3 and len(fixed) == 5 and len(sigma) == 3 and len(z) == 3
+    cs = _Cosets()
+    for i in range(3):
+        cs.advice[i], cs.sigma[i], cs.z[i] = advice[i].ptr, sigma[i].ptr, z[i].ptr
+    for i in range(5):
+        cs.fixed[i] = fixed[i].ptr
+    cs.l0, cs.l_last, cs.l_active = l0.ptr, l_last.ptr, l_active.ptr
+    m = F.fr_to_mont_limbs
+    t_inv = np.ascontiguousarray(vanishing_inverses(domain))
+    args = [m(beta), m(gamma), m(y), m(FR_DELTA), m(domain.g_coset), m(domain.extended_omega)]
+    check(lib.h2mi_plonk_evaluate_h_standard_dev(C.byref(cs), domain.k, domain.extended_k, BLINDING_FACTORS, *[a.ctypes.data for a in args],
+                                                 t_inv.ctypes.data, out.ptr, stream), "evaluate_h")

@@ -126,6 +126,27 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars /* count*4 */, size_t count, size_t n, void* d_out,
                         h2mi_stream_t stream);
 
+/* ---- quotient numerator for the reference's StandardPlonk circuit -------------------------
+ * halo2_proofs plonk/evaluation.rs `evaluate_h` + vanishing division, specialised to the circuit of reference
+ * src/circuits/standard_plonk.rs (one degree-3 gate over 3 advice + 5 fixed columns, 3 permutation sets of one
+ * column).  All vectors are extended-domain evaluations (2^extended_k elements) resident in HBM. t_inv holds the
+ * 2^(extended_k - k) values of (X^n - 1)^-1 on the coset.  The result (h on the extended coset, already divided)
+ * goes to d_h_out; h2mi_ntt_bn254_fr_dev + h2mi_fr_scale_powers_dev bring it to coefficients. */
+typedef struct {
+  const void* advice[3];  /* a, b, c */
+  const void* fixed[5];   /* q_a, q_b, q_c, q_ab, constant */
+  const void* sigma[3];   /* permutation polynomials of a, b, c */
+  const void* z[3];       /* permutation products */
+  const void* l0;
+  const void* l_last;
+  const void* l_active;
+} h2mi_standard_plonk_cosets;
+int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* cosets, uint32_t k, uint32_t extended_k,
+                                       uint32_t blinding_factors, const uint64_t beta[4], const uint64_t gamma[4],
+                                       const uint64_t y[4], const uint64_t delta[4], const uint64_t zeta[4],
+                                       const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
+                                       void* d_h_out, h2mi_stream_t stream);
+
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
  * generator (1, 2) with on-device normalisation. */

@@ -517,3 +517,44 @@ def test_golden_replay_k8(gpu):
     got = o.unpack_points(cref.normalize(R.finish()))
     assert got == [_gpt(p) for p in gold["commitments"]]
     R.release()
+
+
+@pytest.mark.parametrize("k", [4, 6])
+def test_evaluate_h_standard_plonk(gpu, k):
+    """the quotient numerator of the reference's StandardPlonk circuit on the device equals the
+    oracle's restatement of evaluate_h element by element, and the resulting h(X) satisfies the PLONK quotient
+    identity at a random point (which no mis-stated gate / permutation / blinding could)."""
+    from oracle import plonk as P
+    from halo2_scaffold_amd import plonk as gp
+
+    inst = P.StandardPlonkInstance(k, 0xDEADBEEF1234567)
+    beta, gamma, y, x = 0x1111, 0x2222, 0x3333, 0x123456789ABCDEF
+    zs = inst.permutation_products(beta, gamma)
+    assert zs[2][inst.u] == 1
+    dom = gpu.EvaluationDomain(P.CS_DEGREE, k)
+    ext = dom.extended_len()
+
+    def to_ext_dev(lagr):  # lagrange values -> coefficients -> extended coset, all on the device
+        d = gpu.DevBuf(ext * 32)
+        d.upload(o.pack(lagr, o.R))
+        assert gpu.lib.h2mi_memset_zero(d.ptr + inst.n * 32, (ext - inst.n) * 32) == 0
+        dom.lagrange_to_coeff_dev(d)  # transforms the first n elements
+        dom.coeff_to_extended_dev(d)
+        return d
+
+    adv = [to_ext_dev(c) for c in inst.advice]
+    fix = [to_ext_dev(c) for c in inst.fixed]
+    sig = [to_ext_dev(c) for c in inst.sigma]
+    zc = [to_ext_dev(z) for z in zs]
+    l0, ll, la = to_ext_dev(inst.l0), to_ext_dev(inst.l_last), to_ext_dev(inst.l_active)
+    assert o.unpack(adv[0].to_numpy(shape=(ext, 4)), o.R) == inst.to_extended(inst.advice[0])
+    out = gpu.DevBuf(ext * 32)
+    gp.evaluate_h(dom, adv, fix, sig, zc, l0, ll, la, beta, gamma, y, out)
+    got = o.unpack(out.to_numpy(shape=(ext, 4)), o.R)
+    want = inst.divide_by_vanishing(inst.evaluate_h(zs, beta, gamma, y))
+    assert got == want
+    # to coefficients on the device, then the verifier's identity with the GPU-computed h
+    dom.extended_to_coeff_dev(out)
+    hc = o.unpack(out.to_numpy(shape=(ext, 4)), o.R)
+    assert not any(hc[inst.n * (P.CS_DEGREE - 1):])  # degree bound: the division was exact
+    assert P.check_quotient_identity(inst, zs, hc[: inst.n * (P.CS_DEGREE - 1)], beta, gamma, y, x)

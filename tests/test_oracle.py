@@ -187,3 +187,22 @@ def test_golden_replay_k8_self_consistency():
     rp = o.unpack(o.random_field_limbs(n, o.SEED + 20), o.R)
     assert _pt(r["commitments"][6]) == o.g1_mul(sum(c * p for c, p in zip(rp, pw)) % o.R, o.G1_GEN)
     assert len(r["commitments"]) == 11 and all(o.is_on_curve(_pt(p)) for p in r["commitments"])
+
+
+def test_plonk_quotient_oracle_identity():
+    """oracle/plonk.py: for the reference circuit's satisfying witness the quotient identity holds at random
+    points; for a broken witness or a broken copy constraint it does not."""
+    from oracle import plonk as P
+
+    beta, gamma, y = 0xB, 0xC, 0xD
+    inst = P.StandardPlonkInstance(4, 987654321)
+    zs = inst.permutation_products(beta, gamma)
+    assert zs[2][inst.u] == 1 and P.FR_DELTA == pow(7, 1 << 28, o.R)
+    hc = inst.dom.extended_to_coeff(inst.divide_by_vanishing(inst.evaluate_h(zs, beta, gamma, y)))
+    for x in (5, 0xABCDEF, o.R - 2):
+        assert P.check_quotient_identity(inst, zs, hc, beta, gamma, y, x)
+    bad = P.StandardPlonkInstance(4, 987654321)
+    bad.advice[1][2] = (bad.advice[1][2] + 1) % o.R  # b2 != x: breaks the gate and the copy constraint
+    zb = bad.permutation_products(beta, gamma)
+    hb = bad.dom.extended_to_coeff(bad.divide_by_vanishing(bad.evaluate_h(zb, beta, gamma, y)))
+    assert not P.check_quotient_identity(bad, zb, hb, beta, gamma, y, 5)
