@@ -814,15 +814,13 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint
   int rc = get_powtab(extended_omega, extended_k, s, &px);
   if (rc) return rc;
   const uint32_t rot = 1u << (extended_k - k);
-  fe* d_tinv = nullptr;
-  H2_HIP(hipMalloc(&d_tinv, rot * 32));
+  static fe* d_tinv = nullptr;  // 16 entries, reused: copies and kernels on one stream are ordered
+  if (!d_tinv) H2_HIP(hipMalloc(&d_tinv, 16 * 32));
   H2_HIP(hipMemcpyAsync(d_tinv, t_inv, rot * 32, hipMemcpyHostToDevice, s));
   const uint32_t size = 1u << extended_k;
   H2_LAUNCH("k_evaluate_h_standard_plonk", k_evaluate_h_standard_plonk, ceil_div_u32(size, 256), 256, 0, s, pc, extended_k, k, blinding_factors + 1,
             host_fe(beta), host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, (const fe*)d_tinv,
             (fe*)d_h_out);
-  H2_HIP(hipStreamSynchronize(s));  // t_inv staging buffer is released here
-  hipFree(d_tinv);
   return H2MI_OK;
 }
 

@@ -22,3 +22,15 @@ for log_n in [int(x) for x in sys.argv[1:]] or [16, 20, 22]:
     tl = t(lambda: lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, 4, n, out.ptr, None))
     print(f"log_n={log_n}: eval {te*1e6:7.1f} us ({32*n/te/8e12*100:4.1f}% of HBM roofline, 32n B) | kate_division {tk*1e6:7.1f} us ({64*n/tk/8e12*100:4.1f}%, 64n B) | "
           f"lincomb(4) {tl*1e6:7.1f} us ({160*n/tl/8e12*100:4.1f}%, 160n B)", flush=True)
+
+# quotient numerator of StandardPlonk (17 extended vectors in, 1 out)
+from halo2_scaffold_amd import plonk as gp
+for k in [16, 20]:
+    dom = h2.EvaluationDomain(3, k); ext = dom.extended_len()
+    bufs = [h2.DevBuf.from_numpy(synth.uniform_fr(ext, 300 + i)) for i in range(17)]
+    out = h2.DevBuf(ext * 32)
+    fn = lambda: gp.evaluate_h(dom, bufs[0:3], bufs[3:8], bufs[8:11], bufs[11:14], bufs[14], bufs[15], bufs[16], 3, 5, 7, out)
+    te = t(fn, R=10)
+    algo = ext * 32 * 18
+    print(f"k={k}: evaluate_h(standard_plonk) on 2^{dom.extended_k}: {te*1e6:8.1f} us ({algo/te/8e12*100:4.1f}% of HBM roofline, 18 x 32 B per point)", flush=True)
+    for b in bufs + [out]: b.free()
