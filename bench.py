@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--shape", choices=["standard_plonk", "halo2_lib_gate", "range_lookup"], default="standard_plonk",
                     help="proof shape to replay (BASELINE.json metric is quoted on standard_plonk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-evaluate-h", action="store_true",
+                    help="standard_plonk, N = 1: also time the device quotient evaluation (outside BASELINE's MSM+NTT metric)")
     ap.add_argument("--replicate-all-ntts", action="store_true",
                     help="N > 1: every rank replays every NTT (default: leaf transforms are spread round-robin)")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 size of the CPU baseline sample MSM/NTT")
@@ -78,7 +80,8 @@ def main():
     lib = h2.lib
     combine = PartialPointCombiner(device=coll_dev) if world > 1 else None
     shape = rp.SHAPES[args.shape]
-    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine, spread_leaf_ntts=not args.replicate_all_ntts)
+    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine, spread_leaf_ntts=not args.replicate_all_ntts,
+                       with_evaluate_h=args.with_evaluate_h)
     n = R.n
 
     def sync_all():
@@ -211,7 +214,8 @@ def main():
             "msm_windows": W.value,
             "msm_buckets": nb.value,
             "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
-            "what_is_timed": "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation",
+            "what_is_timed": ("MSM + NTT + evaluate_h kernels on HBM-resident vectors; not transcript / witness generation" if R.with_evaluate_h else
+                              "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation"),
         },
         "commitments_sha256": digest,
         "ntt_placement": ("single GPU" if world == 1 else "leaf transforms spread round-robin, consumed transforms on every rank"

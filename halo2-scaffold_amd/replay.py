@@ -70,8 +70,11 @@ NTT_PER_PROOF = STANDARD_PLONK.ntt_per_proof
 
 class ProofReplay:
     def __init__(self, shape: ProofShape, k: int, rank: int = 0, world: int = 1, srs_secret: int = 0x5EC2E7 + 0x48324D49, dist="uniform",
-                 combine=None, spread_leaf_ntts: bool = True):
+                 combine=None, spread_leaf_ntts: bool = True, with_evaluate_h: bool = False):
         self.shape = shape
+        # optional: compute h(X) from the extended forms with the device evaluate_h (StandardPlonk only; the
+        # proving-key cosets - fixed, sigma, l_0, l_last, l_active - are synthetic dense vectors)
+        self.with_evaluate_h = with_evaluate_h and shape.name == "standard_plonk" and world == 1
         self.spread = spread_leaf_ntts and world > 1
         self.k, self.n = k, 1 << k
         self.rank, self.world = rank, world
@@ -115,6 +118,8 @@ class ProofReplay:
         self._h_src = DevBuf(ext * 32)
         self._h_src.copy_from(self.h)
         self.counts = {"msm": 0, "intt_n": 0, "coset_ntt_ext": 0, "coset_intt_ext": 0}
+        if self.with_evaluate_h:
+            self.pk_cosets = [DevBuf.from_numpy(synth.uniform_fr(ext, synth.SEED + 100 + i)) for i in range(5 + 3 + 3)]
         check(lib.h2mi_sync(), "sync")
 
     # ---- primitives ----
@@ -190,7 +195,14 @@ class ProofReplay:
         for c in self.lookup:
             self._to_coeff_and_extended(c, next(w_it), next(e_it))
         # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each -> challenge x
-        self.h.copy_from(self._h_src)
+        if self.with_evaluate_h:
+            from . import plonk as gp
+
+            # ext buffers in allocation order: 3 permutation products, then 3 advice columns
+            zc, adv, pk = self.ext[0:3], self.ext[3:6], self.pk_cosets
+            gp.evaluate_h(d, adv, pk[0:5], pk[5:8], zc, pk[8], pk[9], pk[10], 0xBE7A, 0x6A33A, 0x1234567, self.h)
+        else:
+            self.h.copy_from(self._h_src)
         d.extended_to_coeff_dev(self.h)
         self.counts["coset_intt_ext"] += 1
         for piece in range(sh.cs_degree - 1):
