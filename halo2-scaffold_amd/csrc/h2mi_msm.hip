@@ -504,6 +504,10 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   const uint32_t s0 = pick_chunk(total);
   uint32_t ls0 = 0;
   while ((1u << ls0) < s0) ls0++;
+  // the partial buffers were sized at registration: never let an override (H2MI_MSM_S0) or a shorter
+  // vector produce more tasks than they hold
+  while (ls0 < 6 && (uint64_t)(total >> ls0) + nb > B->max_tasks0) ls0++;
+  if ((uint64_t)(total >> ls0) + nb > B->max_tasks0) return H2MI_ERANGE;
   if (pipelined) {
     hs = ctx().head_stream;
     as = ctx().accum_stream;

@@ -557,3 +557,21 @@ def test_evaluate_h_standard_plonk(gpu, k):
     hc = o.unpack(out.to_numpy(shape=(ext, 4)), o.R)
     assert not any(hc[inst.n * (P.CS_DEGREE - 1):])  # degree bound: the division was exact
     assert P.check_quotient_identity(inst, zs, hc[: inst.n * (P.CS_DEGREE - 1)], beta, gamma, y, x)
+
+
+def test_task_size_override_is_clamped_to_buffer_capacity(gpu):
+    """H2MI_MSM_S0 asks for more accumulation tasks than the registered workspace holds: the library must
+    clamp the task size (never overrun its partial buffers) and still return the right point."""
+    from oracle import cref
+
+    k = 18
+    params = gpu.ParamsKZG.setup(k, 0xFACE)
+    sc = o.random_field_limbs(1 << k, 321)
+    want = params.commit(sc)
+    os.environ["H2MI_MSM_S0"] = "8"
+    try:
+        got = params.commit(sc)
+    finally:
+        del os.environ["H2MI_MSM_S0"]
+    assert np.array_equal(cref.normalize(got), cref.normalize(want))
+    params.release()
