@@ -235,8 +235,10 @@ __global__ void __launch_bounds__(256) k_msm_fold(const uint8_t* pin, const uint
   if (t >= toff_out[nb]) return;
   uint32_t b = find_bucket(toff_out, nb, t);
   uint32_t j = t - toff_out[b];
-  uint32_t start = toff_in[b] + j * S1;
-  uint32_t len = min(S1, np_in[b] - j * S1);
+  const uint32_t m = np_in[b], np = toff_out[b + 1] - toff_out[b];  // balanced split, as in k_msm_accum
+  const uint32_t q = m / np, r = m - q * np;
+  uint32_t start = toff_in[b] + j * q + min(j, r);
+  uint32_t len = q + (j < r ? 1u : 0u);
   xyzz29 acc = part_load(pin + (size_t)start * PART_BYTES);
   for (uint32_t k = 1; k < len; k++) {
     xyzz29 p = part_load(pin + (size_t)(start + k) * PART_BYTES);
