@@ -219,6 +219,22 @@ H2_HD bool f29_is_zero_mod(const f29& a) {
   return z == 0 || e == 0;
 }
 
+// a^(p-2) (Fermat inversion) for a normalized input of any loose value; inv(0) = 0.  Output < 1.1p.
+template <class F>
+H2_HD f29 f29_inv(const f29& a) {
+  f29 r = f29_const<F>(F::ONE);
+  for (int i = 8; i >= 0; i--) {
+    // exponent p - 2 in 29-bit limbs: only limb 0 changes (P[0] is odd and > 2)
+    const uint32_t e = F::P[i] - (i == 0 ? 2u : 0u);
+    const int top = (i == 8) ? 21 : 28;  // p has 254 bits: limb 8 holds 22 of them
+    for (int b = top; b >= 0; b--) {
+      r = f29_sqr<F>(r);
+      if ((e >> b) & 1u) r = f29_mul<F>(r, a);
+    }
+  }
+  return r;
+}
+
 // Mont256 words (the ABI / memory format) <-> internal Mont261 limbs
 template <class F>
 H2_HD f29 f29_from_mont256(const uint32_t w[8]) {

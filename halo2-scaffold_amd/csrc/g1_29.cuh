@@ -151,4 +151,15 @@ H2_HD void xyzz29_add(xyzz29& a, const xyzz29& b) {
   a.zzz = zzz;
 }
 
+// XYZZ -> affine (canonical Montgomery-2^261 limbs): x = X / ZZ, y = Y / ZZZ with one inversion
+// (1/ZZ = (ZZ / ZZZ)^2 because ZZ^3 = ZZZ^2).  Identity -> (0, 0).
+H2_HD void xyzz29_to_affine(const xyzz29& p, f29& x, f29& y) {
+  using F = Fq29;
+  if (xyzz29_is_identity(p)) { x = f29_zero(); y = f29_zero(); return; }
+  f29 zi = f29_inv<F>(p.zzz);
+  y = f29_reduce_canonical<F>(f29_mul<F>(p.y, zi));
+  f29 t = f29_mul<F>(p.zz, zi);
+  x = f29_reduce_canonical<F>(f29_mul<F>(p.x, f29_sqr<F>(t)));
+}
+
 }  // namespace h2

@@ -67,7 +67,21 @@ struct Bases {
 static std::map<uint64_t, Bases*> g_bases;
 static uint64_t g_next_handle = 1;
 
-// ---- registration: table[w][i] = 2^(c*w) * P_i ----------------------------------------------------
+// ---- registration: table[w][i] = 2^(c*w) * P_i, stored as canonical Montgomery-2^261 words -------------
+// window 0: the caller's points (Montgomery-2^256) converted to the table format
+__global__ void __launch_bounds__(256) k_msm_table_first(const uint8_t* bases, uint8_t* table0, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine p = affine_load(bases + i * 64);
+  if (!affine_is_identity(p)) {
+    affine q;
+    f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.x.v)), q.x.v);
+    f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.y.v)), q.y.v);
+    p = q;
+  }
+  affine_store(table0 + i * 64, p);
+}
+// window w from window w-1: c doublings in XYZZ, one inversion back to affine
 __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uint8_t* next, size_t n, uint32_t c) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -76,9 +90,14 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
     affine_store(next + i * 64, p);
     return;
   }
-  xyzz acc = xyzz_dbl_affine(p);
-  for (uint32_t k = 1; k < c; k++) acc = xyzz_dbl(acc);
-  affine_store(next + i * 64, xyzz_to_affine(acc));
+  xyzz29 acc = xyzz29_dbl_affine(f29_unpack(p.x.v), f29_unpack(p.y.v));
+  for (uint32_t k = 1; k < c; k++) acc = xyzz29_dbl(acc);
+  f29 x, y;
+  xyzz29_to_affine(acc, x, y);
+  affine q;
+  f29_pack(x, q.x.v);
+  f29_pack(y, q.y.v);
+  affine_store(next + i * 64, q);
 }
 
 // ---- per call -------------------------------------------------------------------------------------
@@ -181,20 +200,6 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
     else hi = mid;
   }
   return lo;
-}
-
-// registration epilogue: the table is consumed only by k_msm_accum, which works in the lazy 29-bit-limb
-// representation (f29.cuh); store the points as canonical Montgomery-2^261 integers (still 8 x 32-bit
-// words per coordinate) so the inner loop only unpacks.
-__global__ void __launch_bounds__(256) k_msm_table_to261(uint8_t* table, size_t count) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  affine p = affine_load(table + i * 64);
-  if (affine_is_identity(p)) return;
-  affine q;
-  f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.x.v)), q.x.v);
-  f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p.y.v)), q.y.v);
-  affine_store(table + i * 64, q);
 }
 
 // level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
@@ -466,18 +471,17 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
       return H2MI_EHIP;
     }
   }
-  if (hipMemcpyAsync(B->table, d_bases, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
+  {
+    const bool prof_ = prof_on("k_msm_table_first");
+    if (prof_) prof_begin("k_msm_table_first", s);
+    hipLaunchKernelGGL(k_msm_table_first, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)d_bases, B->table, n);
+    if (prof_) prof_end(s);
+  }
   for (uint32_t w = 1; w < B->W; w++) {
     const bool prof_ = prof_on("k_msm_table_next");
     if (prof_) prof_begin("k_msm_table_next", s);
     hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * n * 64),
                        B->table + (size_t)w * n * 64, n, B->c);
-    if (prof_) prof_end(s);
-  }
-  {
-    const bool prof_ = prof_on("k_msm_table_to261");
-    if (prof_) prof_begin("k_msm_table_to261", s);
-    hipLaunchKernelGGL(k_msm_table_to261, dim3(ceil_div_u32(nW, 256)), dim3(256), 0, s, B->table, nW);
     if (prof_) prof_end(s);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }

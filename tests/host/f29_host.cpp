@@ -27,6 +27,9 @@ static void mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out, size_
     } else if (mode == 4) {  // dedicated squaring of a normalized input
       f29 x = f29_from_mont256<F>(a + 8 * i);
       f29_to_mont256<F>(f29_sqr<F>(x), out + 8 * i);
+    } else if (mode == 5) {  // Fermat inversion
+      f29 x = f29_from_mont256<F>(a + 8 * i);
+      f29_to_mont256<F>(f29_inv<F>(x), out + 8 * i);
     } else {  // pack(unpack(x)) round trip
       f29 x = f29_unpack(a + 8 * i);
       f29_pack(x, out + 8 * i);

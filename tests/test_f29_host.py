@@ -53,6 +53,8 @@ def test_f29_mul_modes(host, field, mod):
     assert o.unpack(out, mod) == [(x + y) * (x - y) % mod for x, y in zip(vals_a, vals_b)]
     host.f29t_mul(field, 4, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
     assert o.unpack(out, mod) == [x * x % mod for x in vals_a]
+    host.f29t_mul(field, 5, A.ctypes.data, B.ctypes.data, out.ctypes.data, 64)
+    assert o.unpack(out[:64], mod) == [pow(x, -1, mod) if x else 0 for x in vals_a[:64]]
     host.f29t_mul(field, 3, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
     assert np.array_equal(out, A)
     assert all(v < mod for v in o.unpack(out))
