@@ -143,6 +143,14 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const fe* scalars, size_
 
 static uint8_t* g_fixed_table = nullptr;
 
+// device allocation released on every exit path of the synchronous helper entry points
+struct DevMem {
+  void* p = nullptr;
+  ~DevMem() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 }  // namespace h2
 
 using namespace h2;
@@ -297,100 +305,93 @@ int h2mi_dbg_field_op(int field, int op, const uint64_t* a, const uint64_t* b, u
   if (!a || !out || n == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
-  fe *da = nullptr, *db = nullptr, *dout = nullptr;
-  H2_HIP(hipMalloc(&da, n * 32));
-  H2_HIP(hipMalloc(&dout, n * 32));
-  H2_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, s));
+  DevMem da, db, dout;
+  H2_HIP(da.alloc(n * 32));
+  H2_HIP(dout.alloc(n * 32));
+  H2_HIP(hipMemcpyAsync(da.p, a, n * 32, hipMemcpyHostToDevice, s));
   if (b) {
-    H2_HIP(hipMalloc(&db, n * 32));
-    H2_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, s));
+    H2_HIP(db.alloc(n * 32));
+    H2_HIP(hipMemcpyAsync(db.p, b, n * 32, hipMemcpyHostToDevice, s));
   }
   uint32_t grid = ceil_div_u32(n, 256);
   if (field == 0) {
-    H2_LAUNCH("k_dbg_field_fq", k_dbg_field<FqP>, grid, 256, 0, s, op, da, db, dout, n);
+    H2_LAUNCH("k_dbg_field_fq", k_dbg_field<FqP>, grid, 256, 0, s, op, da.as<fe>(), db.as<fe>(), dout.as<fe>(), n);
   } else {
-    H2_LAUNCH("k_dbg_field_fr", k_dbg_field<FrP>, grid, 256, 0, s, op, da, db, dout, n);
+    H2_LAUNCH("k_dbg_field_fr", k_dbg_field<FrP>, grid, 256, 0, s, op, da.as<fe>(), db.as<fe>(), dout.as<fe>(), n);
   }
-  H2_HIP(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipMemcpyAsync(out, dout.p, n * 32, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
-  hipFree(da);
-  hipFree(dout);
-  if (db) hipFree(db);
   return H2MI_OK;
 }
+
 
 int h2mi_dbg_g1_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {
   H2_REQUIRE_INIT();
   if (!p || !out_jac || n == 0 || (op != 1 && !q)) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
-  uint8_t *dp = nullptr, *dq = nullptr, *dout = nullptr;
-  H2_HIP(hipMalloc(&dp, n * 64));
-  H2_HIP(hipMalloc(&dout, n * 96));
-  H2_HIP(hipMemcpyAsync(dp, p, n * 64, hipMemcpyHostToDevice, s));
+  DevMem dp, dq, dout;
+  H2_HIP(dp.alloc(n * 64));
+  H2_HIP(dout.alloc(n * 96));
+  H2_HIP(hipMemcpyAsync(dp.p, p, n * 64, hipMemcpyHostToDevice, s));
   if (q) {
-    H2_HIP(hipMalloc(&dq, n * 64));
-    H2_HIP(hipMemcpyAsync(dq, q, n * 64, hipMemcpyHostToDevice, s));
+    H2_HIP(dq.alloc(n * 64));
+    H2_HIP(hipMemcpyAsync(dq.p, q, n * 64, hipMemcpyHostToDevice, s));
   }
-  H2_LAUNCH("k_dbg_g1", k_dbg_g1, ceil_div_u32(n, 256), 256, 0, s, op, dp, dq, dout, n);
-  H2_HIP(hipMemcpyAsync(out_jac, dout, n * 96, hipMemcpyDeviceToHost, s));
+  H2_LAUNCH("k_dbg_g1", k_dbg_g1, ceil_div_u32(n, 256), 256, 0, s, op, dp.as<uint8_t>(), dq.as<uint8_t>(), dout.as<uint8_t>(), n);
+  H2_HIP(hipMemcpyAsync(out_jac, dout.p, n * 96, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
-  hipFree(dp);
-  hipFree(dout);
-  if (dq) hipFree(dq);
   return H2MI_OK;
 }
+
 
 int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]) {
   H2_REQUIRE_INIT();
   if (!points || !out_jacobian || k == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
-  uint8_t *dp = nullptr, *dout = nullptr;
-  H2_HIP(hipMalloc(&dp, k * 96));
-  H2_HIP(hipMalloc(&dout, 96));
-  H2_HIP(hipMemcpyAsync(dp, points, k * 96, hipMemcpyHostToDevice, s));
-  H2_LAUNCH("k_g1_sum_jac", k_g1_sum_jac, 1, 64, 0, s, dp, k, dout);
-  H2_HIP(hipMemcpyAsync(out_jacobian, dout, 96, hipMemcpyDeviceToHost, s));
+  DevMem dp, dout;
+  H2_HIP(dp.alloc(k * 96));
+  H2_HIP(dout.alloc(96));
+  H2_HIP(hipMemcpyAsync(dp.p, points, k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_sum_jac", k_g1_sum_jac, 1, 64, 0, s, dp.as<uint8_t>(), k, dout.as<uint8_t>());
+  H2_HIP(hipMemcpyAsync(out_jacobian, dout.p, 96, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
-  hipFree(dp);
-  hipFree(dout);
   return H2MI_OK;
 }
+
 
 int h2mi_g1_fold_groups(const uint64_t* points, size_t world, size_t k, uint64_t* out) {
   H2_REQUIRE_INIT();
   if (!points || !out || world == 0 || k == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
-  uint8_t *dp = nullptr, *dout = nullptr;
-  H2_HIP(hipMalloc(&dp, world * k * 96));
-  H2_HIP(hipMalloc(&dout, k * 96));
-  H2_HIP(hipMemcpyAsync(dp, points, world * k * 96, hipMemcpyHostToDevice, s));
-  H2_LAUNCH("k_g1_fold_groups", k_g1_fold_groups, ceil_div_u32(k, 64), 64, 0, s, dp, world, k, dout);
-  H2_HIP(hipMemcpyAsync(out, dout, k * 96, hipMemcpyDeviceToHost, s));
+  DevMem dp, dout;
+  H2_HIP(dp.alloc(world * k * 96));
+  H2_HIP(dout.alloc(k * 96));
+  H2_HIP(hipMemcpyAsync(dp.p, points, world * k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_fold_groups", k_g1_fold_groups, ceil_div_u32(k, 64), 64, 0, s, dp.as<uint8_t>(), world, k, dout.as<uint8_t>());
+  H2_HIP(hipMemcpyAsync(out, dout.p, k * 96, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
-  hipFree(dp);
-  hipFree(dout);
   return H2MI_OK;
 }
+
 
 int h2mi_g1_batch_normalize(const uint64_t* jacp, size_t k, uint64_t* affine_out) {
   H2_REQUIRE_INIT();
   if (!jacp || !affine_out || k == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
-  uint8_t *dp = nullptr, *dout = nullptr;
-  H2_HIP(hipMalloc(&dp, k * 96));
-  H2_HIP(hipMalloc(&dout, k * 64));
-  H2_HIP(hipMemcpyAsync(dp, jacp, k * 96, hipMemcpyHostToDevice, s));
-  H2_LAUNCH("k_g1_normalize", k_g1_normalize, ceil_div_u32(k, 256), 256, 0, s, dp, k, dout);
-  H2_HIP(hipMemcpyAsync(affine_out, dout, k * 64, hipMemcpyDeviceToHost, s));
+  DevMem dp, dout;
+  H2_HIP(dp.alloc(k * 96));
+  H2_HIP(dout.alloc(k * 64));
+  H2_HIP(hipMemcpyAsync(dp.p, jacp, k * 96, hipMemcpyHostToDevice, s));
+  H2_LAUNCH("k_g1_normalize", k_g1_normalize, ceil_div_u32(k, 256), 256, 0, s, dp.as<uint8_t>(), k, dout.as<uint8_t>());
+  H2_HIP(hipMemcpyAsync(affine_out, dout.p, k * 64, hipMemcpyDeviceToHost, s));
   H2_HIP(hipStreamSynchronize(s));
-  hipFree(dp);
-  hipFree(dout);
   return H2MI_OK;
 }
+
 
 int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();

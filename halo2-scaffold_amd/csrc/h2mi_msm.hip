@@ -41,8 +41,8 @@ struct Slot {
   void* sort_tmp = nullptr;
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
-  uint32_t* np[3] = {nullptr, nullptr, nullptr};    // tasks per bucket: accumulation, fold 1, fold 2 (nb+1 entries, last = 0)
-  uint32_t* toff[3] = {nullptr, nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
+  uint32_t* np[2] = {nullptr, nullptr};    // tasks per bucket: accumulation, fold (nb+1 entries, last = 0)
+  uint32_t* toff[2] = {nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
   void* scan_tmp = nullptr;
   uint8_t* part[2] = {nullptr, nullptr};   // XYZZ partial buffers: accumulation output, fold output
   uint8_t* dense = nullptr;                // one XYZZ sum per bucket
@@ -61,7 +61,7 @@ struct Bases {
   size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
   Slot slot[NSLOT];
   int next_slot = 0, last_slot = 0;
-  uint32_t max_tasks0 = 0, max_tasks1 = 0, max_tasks2 = 0;
+  uint32_t max_tasks0 = 0, max_tasks1 = 0;
 };
 
 static std::map<uint64_t, Bases*> g_bases;
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n,
 // bucket boundaries in the sorted key array: off[b] = first index with key >= b, hist[b] = run length;
 // also the task counts of the accumulation (chunks of 2^ls0 entries) and of the fold (chunks of S1 partials)
 __global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32_t total, uint32_t nb, uint32_t ls0, uint32_t* off, uint32_t* hist,
-                                                     uint32_t* np0, uint32_t* np1, uint32_t* np2) {
+                                                     uint32_t* np0, uint32_t* np1) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > nb) return;
   uint32_t lo = 0, hi = total;  // first index with key >= b
@@ -161,9 +161,7 @@ __global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32
   }
   uint32_t f0 = (cnt + (1u << ls0) - 1) >> ls0;
   np0[b] = f0;                    // entry nb = 0: the scans then leave the totals in toff[nb]
-  uint32_t f1 = (f0 + S1 - 1) / S1;
-  np1[b] = f1;
-  np2[b] = (f1 + S1 - 1) / S1;
+  np1[b] = (f0 + S1 - 1) / S1;
 }
 
 // Partial bucket sums travel between the MSM kernels as raw xyzz29 values (4 x 9 normalized limbs =
@@ -399,7 +397,7 @@ static void free_bases(Bases* B) {
   for (Slot& S : B->slot) {
     hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
     hipFree(S.hist); hipFree(S.off);
-    for (int i = 0; i < 3; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
+    for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
     if (S.input_ready) hipEventDestroy(S.input_ready);
@@ -433,7 +431,6 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   const size_t nW = n * B->W;
   B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb);  // pick_chunk keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
-  B->max_tasks2 = 0;
   H2_ALLOC(B->table, nW * 64);
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
                                          (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
@@ -452,7 +449,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
     H2_ALLOC(S.hist, (size_t)B->nb * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 2; i++) {
       H2_ALLOC(S.np[i], (size_t)(B->nb + 1) * 4);
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
     }
@@ -546,17 +543,15 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(e);
   }
   H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, hs, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist, S.np[0],
-            S.np[1], S.np[2]);
+            S.np[1]);
   {
     const bool prof_ = prof_on("hipcub_scan");
     if (prof_) prof_begin("hipcub_scan", hs);
     hipError_t e0 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs);
     hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs);
-    hipError_t e2 = hipSuccess;
     if (prof_) prof_end(hs);
     H2_HIP(e0);
     H2_HIP(e1);
-    H2_HIP(e2);
   }
   uint32_t tasks0 = (uint32_t)((n * W >> ls0) + nb);
   if (pipelined) {
