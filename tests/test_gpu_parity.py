@@ -575,3 +575,27 @@ def test_task_size_override_is_clamped_to_buffer_capacity(gpu):
         del os.environ["H2MI_MSM_S0"]
     assert np.array_equal(cref.normalize(got), cref.normalize(want))
     params.release()
+
+
+def test_no_device_memory_leak(gpu):
+    """register / commit / release cycles and NTT plan churn must return device memory to where it started."""
+    import torch
+
+    def used():
+        free, total = torch.cuda.mem_get_info(0)
+        return total - free
+
+    k = 12
+    sc = o.random_field_limbs(1 << k, 1)
+    p = gpu.ParamsKZG.setup(k, 77)  # warm-up: one-time allocations (fixed-base table, scratch, caches)
+    p.commit(sc)
+    p.release()
+    gpu.lib.h2mi_sync()
+    base = used()
+    for i in range(12):
+        p = gpu.ParamsKZG.setup(k, 78 + i)
+        p.commit(sc)
+        p.commit_lagrange(sc)
+        p.release()
+    gpu.lib.h2mi_sync()
+    assert used() - base < (8 << 20), (used() - base) >> 20  # allow allocator granularity, not growth per cycle
