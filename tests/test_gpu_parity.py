@@ -599,3 +599,32 @@ def test_no_device_memory_leak(gpu):
         p.release()
     gpu.lib.h2mi_sync()
     assert used() - base < (8 << 20), (used() - base) >> 20  # allow allocator granularity, not growth per cycle
+
+
+def test_bench_world2_rehearsal_matches_single_gpu(gpu):
+    """the N > 1 path of bench.py (slice registration, per-rank replay, all-gather + fold) with two ranks sharing
+    this GPU over gloo: the proof's commitments must hash to the same digest as the single-process run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["bench.py", "--k", "13", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r1 = subprocess.run([sys.executable] + common, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env2 = dict(env, H2MI_DIST_BACKEND="gloo", H2MI_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + common + ["--gpus", "2"]
+    r2 = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env2)
+    assert r2.returncode == 0, r2.stdout[-1000:] + r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm-slice2" and two["scaling"] == "strong"
+    assert two["commitments_sha256"] == one["commitments_sha256"]
+    for key in ("metric", "value", "unit", "ms_per_step", "roofline", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert key in two and key in one
