@@ -47,6 +47,7 @@ def _load():
         "h2mi_msm_bn254_g1": ([C.c_uint64, vp, vp, sz, vp], C.c_int),
         "h2mi_msm_bn254_g1_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),
+        "h2mi_msm_set_canonical": ([C.c_int], C.c_int),
         "h2mi_g1_sum_jacobian": ([vp, sz, vp], C.c_int),
         "h2mi_g1_fold_groups": ([vp, sz, sz, vp], C.c_int),
         "h2mi_g1_batch_normalize": ([vp, sz, vp], C.c_int),

@@ -39,6 +39,10 @@ struct Slot {
   uint16_t* keys[2] = {nullptr, nullptr};     // [W][n] bucket id per (window, scalar); 0xFFFF = zero digit
   uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i ; [1] holds the sorted order
   void* sort_tmp = nullptr;
+  uint8_t* bkeys = nullptr;     // partition intermediate: bucket id within the bin, bin-major
+  uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
+  uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
+  void* bin_scan_tmp = nullptr;
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
   uint32_t* np[2] = {nullptr, nullptr};    // tasks per bucket: accumulation, fold (nb+1 entries, last = 0)
@@ -58,13 +62,16 @@ struct Bases {
   size_t n = 0;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
-  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
+  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0, bin_scan_tmp_bytes = 0;
+  uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
+  bool radix = false;           // H2MI_MSM_SORT=radix: the general key/value radix sort instead (A/B only)
   Slot slot[NSLOT];
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0;
 };
 
 static std::map<uint64_t, Bases*> g_bases;
+static bool g_canonical = false;
 static uint64_t g_next_handle = 1;
 
 // ---- registration: table[w][i] = 2^(c*w) * P_i, stored as canonical Montgomery-2^261 words -------------
@@ -162,6 +169,245 @@ __global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32
   uint32_t f0 = (cnt + (1u << ls0) - 1) >> ls0;
   np0[b] = f0;                    // entry nb = 0: the scans then leave the totals in toff[nb]
   np1[b] = (f0 + S1 - 1) / S1;
+}
+
+// ---- bucket partition (the default head of an MSM) -------------------------------------------------------
+// Groups the (bucket, point) pairs by bucket with a two-level counting partition instead of a general
+// radix sort; zero digits are never materialised.  NBINS top-level bins of 2^lb buckets each:
+//   k_msm_bin_count    per tile of P1_TS scalars: entries per bin                 (reads the scalars)
+//   exclusive scan     over [bin][tile] -> each tile's write offset in each bin
+//   k_msm_bin_scatter  recomputes the digits, groups the tile's entries by bin in LDS and writes each group as
+//                      one contiguous run: payload (u32) + bucket id within the bin (u8)
+//   k_msm_bin_sort     one workgroup per bin: counts its 2^lb buckets, writes the bucket tables (off, hist,
+//                      task counts) and moves the payloads into bucket order, LDS-staged in chunks.
+// HBM traffic per MSM at n = 2^20, W = 16: 2 x 32 MiB scalar reads, 84 MB + 84 MB for the intermediate
+// pairs, 67 MB of sorted payloads: 0.3 GB against 0.7 GB + 0.1 GB for key/value radix sorting.
+// The order of the points inside a bucket follows LDS-atomic arrival, so it is not reproducible: see
+// k_msm_final for what that means for the result.
+constexpr uint32_t P1_TS = 1024;       // scalars per partition tile = threads per workgroup
+constexpr uint32_t NBINS_MAX = 512;
+constexpr uint32_t P2_THREADS = 512, P2_PER = 16, P2_CH = P2_THREADS * P2_PER;
+
+// CT = compile-time window width (13, 15, 16: fully unrolled, limb indices become constants) or 0 = use
+// the run-time c (H2MI_MSM_C experiments only: the dynamically indexed limbs then live in LDS/scratch)
+template <uint32_t CT, class F>
+__device__ __forceinline__ void for_each_digit(const fe& s, uint32_t c_rt, uint32_t W_rt, F&& f) {
+  const uint32_t c = CT ? CT : c_rt;
+  const uint32_t W = CT ? (256 + CT - 1) / CT : W_rt;
+  uint32_t carry = 0;
+  const uint32_t half = 1u << (c - 1);
+#pragma unroll
+  for (uint32_t w = 0; w < W; w++) {
+    uint32_t bit = w * c;
+    uint32_t limb = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (limb < 8) {
+      uint64_t two = s.v[limb];
+      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
+      raw = (uint32_t)(two >> sh) & ((1u << c) - 1);
+    }
+    uint32_t d = raw + carry;  // 0 .. 2^c
+    uint32_t mag = d, neg = 0;
+    carry = 0;
+    if (d > half) {  // negative digit d - 2^c, carry 1
+      mag = (1u << c) - d;
+      neg = 1;
+      carry = 1;
+    }
+    if (mag) f(w, mag - 1, neg);
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, uint32_t c, uint32_t W, uint32_t lb, uint32_t nbins,
+                                                         uint32_t ntiles, uint32_t* cnt_out) {
+  __shared__ uint32_t cnt[NBINS_MAX];
+  const uint32_t tid = threadIdx.x;
+  if (tid < NBINS_MAX) cnt[tid] = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * P1_TS + tid;
+  if (i < n) {
+    fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+    for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> lb], 1u); });
+  }
+  __syncthreads();
+  if (tid < nbins) cnt_out[(size_t)tid * ntiles + blockIdx.x] = cnt[tid];
+  if (blockIdx.x == 0 && tid == 0) cnt_out[(size_t)nbins * ntiles] = 0;  // the scan leaves the total there
+}
+
+extern __shared__ uint4 h2_msm_smem[];
+
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
+                                                           uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
+                                                           uint8_t* keys_out) {
+  __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], gbase[NBINS_MAX], wsum[NBINS_MAX / 64];
+  uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);           // P1_TS * W payloads
+  uint8_t* stage_key = reinterpret_cast<uint8_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids within the bin
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  if (tid < NBINS_MAX) {
+    cnt[tid] = 0;
+    gbase[tid] = tid < nbins ? base[(size_t)tid * ntiles + tile] : 0;
+  }
+  __syncthreads();
+  size_t i = (size_t)tile * P1_TS + tid;
+  fe s;
+  const bool live = i < n;
+  // compile-time windows: the rank each entry drew from its bin counter is kept in registers, so the digits
+  // are walked once; run-time c walks them twice (count, then place) to stay out of scratch arrays
+  constexpr uint32_t WK = CT ? (256 + CT - 1) / CT : 1;
+  uint32_t ent[WK], rk[WK];
+#pragma unroll
+  for (uint32_t w = 0; w < WK; w++) ent[w] = 0xFFFFFFFFu;
+  if (live) {
+    s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+    for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
+      uint32_t r = atomicAdd(&cnt[bucket >> lb], 1u);
+      if (CT) {
+        ent[w] = bucket | (neg << 31);
+        rk[w] = r;
+      }
+    });
+  }
+  __syncthreads();
+  // exclusive scan of the bin counts: lstart[b] = first staging slot of bin b, cnt[b] = running cursor
+  uint32_t v = 0, inc = 0;
+  if (tid < NBINS_MAX) {
+    v = cnt[tid];
+    inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wave] = inc;
+  }
+  __syncthreads();
+  if (tid < NBINS_MAX) {
+    uint32_t add = 0;
+    for (uint32_t j = 0; j < wave; j++) add += wsum[j];
+    lstart[tid] = add + inc - v;
+    cnt[tid] = add + inc - v;
+    if (tid == NBINS_MAX - 1) lstart[NBINS_MAX] = add + inc;
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << lb) - 1;
+  if (CT) {
+#pragma unroll
+    for (uint32_t w = 0; w < WK; w++)
+      if (ent[w] != 0xFFFFFFFFu) {
+        const uint32_t bucket = ent[w] & 0x7FFFFFFFu;
+        const uint32_t pos = lstart[bucket >> lb] + rk[w];
+        stage_val[pos] = (ent[w] & 0x80000000u) | (uint32_t)((size_t)w * n_reg + i);
+        stage_key[pos] = (uint8_t)(bucket & mask);
+      }
+  } else if (live) {
+    for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
+      uint32_t pos = atomicAdd(&cnt[bucket >> lb], 1u);
+      stage_val[pos] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
+      stage_key[pos] = (uint8_t)(bucket & mask);
+    });
+  }
+  __syncthreads();
+  // each wave writes whole bins: one contiguous run per (bin, tile)
+  for (uint32_t b = wave; b < nbins; b += P1_TS / 64) {
+    const uint32_t ls = lstart[b], len = lstart[b + 1] - ls, g = gbase[b];
+    for (uint32_t j = lane; j < len; j += 64) {
+      vals_out[g + j] = stage_val[ls + j];
+      keys_out[g + j] = stage_key[ls + j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
+                                                             uint32_t nbins, uint32_t lb, uint32_t ls0, uint32_t nb, uint32_t* vals_out,
+                                                             uint32_t* off, uint32_t* hist, uint32_t* np0, uint32_t* np1) {
+  __shared__ uint32_t wh[P2_THREADS / 64][64];
+  __shared__ uint32_t run[64], ccnt[64], cstart[64];
+  __shared__ uint32_t stage[P2_CH];
+  __shared__ uint8_t stage_q[P2_CH];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, bin = blockIdx.x;
+  const uint32_t start = base[(size_t)bin * ntiles], end = base[(size_t)(bin + 1) * ntiles];
+  const uint32_t nq = 1u << lb;
+  for (uint32_t j = tid; j < (P2_THREADS / 64) * 64; j += P2_THREADS) (&wh[0][0])[j] = 0;
+  __syncthreads();
+  // 16 keys per load; the buffer is padded so that the aligned window may overhang [start, end)
+  for (uint32_t j = (start & ~15u) + tid * 16; j < end; j += P2_THREADS * 16) {
+    const uint4 kk = *reinterpret_cast<const uint4*>(keys_in + j);
+    const uint32_t w4[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+    for (uint32_t t = 0; t < 16; t++) {
+      const uint32_t idx = j + t;
+      if (idx >= start && idx < end) atomicAdd(&wh[wave][(w4[t >> 2] >> (8 * (t & 3))) & 0xFFu], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < P2_THREADS / 64; w++) tot += wh[w][tid];
+    uint32_t ex = wave_incl_scan(tot) - tot;
+    run[tid] = start + ex;
+    ccnt[tid] = 0;
+    if (tid < nq) {
+      const uint32_t b = (bin << lb) + tid;
+      off[b] = start + ex;
+      hist[b] = tot;
+      uint32_t f0 = (tot + (1u << ls0) - 1) >> ls0;
+      np0[b] = f0;
+      np1[b] = (f0 + S1 - 1) / S1;
+    }
+    if (bin == 0 && tid == 0) {  // entry nb: end of the sorted array; the task scans leave their totals there
+      off[nb] = base[(size_t)nbins * ntiles];
+      np0[nb] = 0;
+      np1[nb] = 0;
+    }
+  }
+  __syncthreads();
+  for (uint32_t cs = start; cs < end; cs += P2_CH) {
+    const uint32_t m = min(P2_CH, end - cs);
+    uint32_t q[P2_PER], v[P2_PER], r[P2_PER];
+#pragma unroll
+    for (uint32_t k = 0; k < P2_PER; k++) {
+      const uint32_t p = k * P2_THREADS + tid;
+      if (p < m) {
+        q[k] = keys_in[cs + p];
+        v[k] = vals_in[cs + p];
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < P2_PER; k++)
+      if (k * P2_THREADS + tid < m) r[k] = atomicAdd(&ccnt[q[k]], 1u);
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t cn = ccnt[tid];
+      cstart[tid] = wave_incl_scan(cn) - cn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < P2_PER; k++)
+      if (k * P2_THREADS + tid < m) {
+        const uint32_t pos = cstart[q[k]] + r[k];
+        stage[pos] = v[k];
+        stage_q[pos] = (uint8_t)q[k];
+      }
+    __syncthreads();
+    for (uint32_t p = tid; p < m; p += P2_THREADS) {
+      const uint32_t qq = stage_q[p];
+      vals_out[run[qq] + (p - cstart[qq])] = stage[p];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      run[tid] += ccnt[tid];
+      ccnt[tid] = 0;
+    }
+    __syncthreads();
+  }
 }
 
 // Partial bucket sums travel between the MSM kernels as raw xyzz29 values (4 x 9 normalized limbs =
@@ -295,8 +541,6 @@ __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2)
   }
 }
 
-extern __shared__ uint4 h2_msm_smem[];
-
 // bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
 __global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* dense, uint32_t logNh, uint32_t logNl, uint8_t* rc) {
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
@@ -335,8 +579,12 @@ __global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_
 
 // result = sum_beta 2^(beta + logNl) G_row[beta] + sum_beta 2^beta G_col[beta], returned as a Jacobian
 // point in the ABI's Montgomery-2^256 form: (X*ZZ, Y*ZZZ, ZZ) since ZZ^3 = ZZZ^2; identity = (0, R, 0).
+// The order of additions inside a bucket follows LDS-atomic arrival in the partition, so the projective
+// representative (not the group element) can differ between two runs on the same input: callers compare
+// or hash after h2mi_g1_batch_normalize, exactly as the reference's callers do with best_multiexp's result;
+// h2mi_msm_set_canonical(1) trades one field inversion per MSM for reproducible bits.
 __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t logNh, uint32_t logNl, uint8_t* out_jac, const uint32_t* off,
-                                                   uint32_t nb, uint64_t* stats) {
+                                                   uint32_t nb, uint64_t* stats, uint32_t canonical) {
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t tid = threadIdx.x;
   const uint32_t terms = logNh + logNl + 1;
@@ -354,6 +602,12 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t log
     jac j;
     if (xyzz29_is_identity(r)) {
       j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
+    } else if (canonical) {  // h2mi_msm_set_canonical(1): the representative with Z = 1
+      f29 ax, ay;
+      xyzz29_to_affine(r, ax, ay);
+      f29_to_mont256<Fq29>(ax, j.x.v);
+      f29_to_mont256<Fq29>(ay, j.y.v);
+      j.z = fe_one<Fq>();
     } else {
       f29_to_mont256<Fq29>(f29_mul<Fq29>(r.x, r.zz), j.x.v);
       f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
@@ -396,6 +650,7 @@ static void free_bases(Bases* B) {
   hipFree(B->table);
   for (Slot& S : B->slot) {
     hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
+    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp);
     hipFree(S.hist); hipFree(S.off);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
@@ -432,8 +687,21 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb);  // pick_chunk keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
-                                         (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
+  {
+    const char* ev = getenv("H2MI_MSM_SORT");
+    B->radix = ev && !strcmp(ev, "radix");
+  }
+  B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
+  B->nbins = B->nb >> B->lb;  // <= NBINS_MAX
+  const size_t ntiles_max = (n + P1_TS - 1) / P1_TS;
+  const size_t bin_cells = (size_t)B->nbins * ntiles_max + 1;
+  if (bin_cells >= ((size_t)1 << 31)) { free_bases(B); return H2MI_ERANGE; }
+  if (B->radix && hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
+                                                     (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
+    free_bases(B);
+    return H2MI_EHIP;
+  }
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, B->bin_scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)bin_cells, s) != hipSuccess) {
     free_bases(B);
     return H2MI_EHIP;
   }
@@ -443,10 +711,14 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   }
   for (Slot& S : B->slot) {
     for (int i = 0; i < 2; i++) {
-      H2_ALLOC(S.keys[i], nW * 2);
+      if (B->radix) H2_ALLOC(S.keys[i], nW * 2);
       H2_ALLOC(S.vals[i], nW * 4);
     }
-    H2_ALLOC(S.sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
+    if (B->radix) H2_ALLOC(S.sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
+    H2_ALLOC(S.bkeys, nW + 16);
+    H2_ALLOC(S.bincnt, bin_cells * 4);
+    H2_ALLOC(S.binbase, bin_cells * 4);
+    H2_ALLOC(S.bin_scan_tmp, B->bin_scan_tmp_bytes ? B->bin_scan_tmp_bytes : 16);
     H2_ALLOC(S.hist, (size_t)B->nb * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     for (int i = 0; i < 2; i++) {
@@ -522,7 +794,46 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     if (S.tail_pending) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
     if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
   }
-  H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
+  const uint32_t ntiles = ceil_div_u32(n, P1_TS);
+  static bool attr_set = false;
+  if (!attr_set) {  // the scatter kernel stages up to 100 KiB of pairs in LDS
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_set = true;
+  }
+  if (B->radix) {
+    H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
+  } else {
+    // the partition's first level reads the scalars twice (count, scatter): both stay on s
+#define H2_BIN_COUNT(CT) \
+  H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
+#define H2_BIN_SCATTER(CT)                                                                                                              \
+  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 5, s, (const fe*)d_scalars, n, B->n, B->c, W, \
+            B->lb, B->nbins, ntiles, (const uint32_t*)S.binbase, S.vals[0], S.bkeys)
+    switch (B->c) {
+      case 13: H2_BIN_COUNT(13); break;
+      case 15: H2_BIN_COUNT(15); break;
+      case 16: H2_BIN_COUNT(16); break;
+      default: H2_BIN_COUNT(0); break;
+    }
+    {
+      const bool prof_ = prof_on("binscan_hipcub");
+      if (prof_) prof_begin("binscan_hipcub", s);
+      hipError_t e = hipcub::DeviceScan::ExclusiveSum(S.bin_scan_tmp, B->bin_scan_tmp_bytes, S.bincnt, S.binbase, (int)(B->nbins * ntiles + 1), s);
+      if (prof_) prof_end(s);
+      H2_HIP(e);
+    }
+    switch (B->c) {
+      case 13: H2_BIN_SCATTER(13); break;
+      case 15: H2_BIN_SCATTER(15); break;
+      case 16: H2_BIN_SCATTER(16); break;
+      default: H2_BIN_SCATTER(0); break;
+    }
+#undef H2_BIN_COUNT
+#undef H2_BIN_SCATTER
+  }
   if (pipelined) {
     H2_HIP(hipEventRecord(S.input_ready, s));
     H2_HIP(hipStreamWaitEvent(hs, S.input_ready, 0));
@@ -534,16 +845,21 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.tail_pending = false;
   S.accum_pending = false;
   S.head_pending = false;
-  {
-    const bool prof_ = prof_on("hipcub_radix_sort");
-    if (prof_) prof_begin("hipcub_radix_sort", hs);
-    // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, hs);
-    if (prof_) prof_end(hs);
-    H2_HIP(e);
+  if (B->radix) {
+    {
+      const bool prof_ = prof_on("hipcub_radix_sort");
+      if (prof_) prof_begin("hipcub_radix_sort", hs);
+      // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
+      hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, hs);
+      if (prof_) prof_end(hs);
+      H2_HIP(e);
+    }
+    H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, hs, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist,
+              S.np[0], S.np[1]);
+  } else {
+    H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
+              (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
   }
-  H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, hs, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist, S.np[0],
-            S.np[1]);
   {
     const bool prof_ = prof_on("hipcub_scan");
     if (prof_) prof_begin("hipcub_scan", hs);
@@ -581,7 +897,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * PART_BYTES, t, (const uint8_t*)S.dense, B->logNh, B->logNl, S.rc);
   H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * PART_BYTES, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
   H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * PART_BYTES, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
-            nb, S.stats);
+            nb, S.stats, g_canonical ? 1u : 0u);
   H2_HIP(hipEventRecord(S.tail_done, t));
   S.tail_pending = true;
   return H2MI_OK;
@@ -696,6 +1012,13 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   if (d) hipFree(d);
   if (handle == 0) h2mi_bases_release(h);
   return rc;
+}
+
+int h2mi_msm_set_canonical(int on) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  g_canonical = on != 0;
+  return H2MI_OK;
 }
 
 int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds) {

@@ -80,12 +80,18 @@ int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* b
  * the first n registered bases.  Scalars are Fr values exactly as they sit in memory (Montgomery).
  * The result is a Jacobian representative of the exact group element (the caller batch-normalises
  * before hashing, as create_proof does); identity is returned as (0, R, 0) = G1::identity().
+ * Which representative (X : Y : Z) comes back is NOT reproducible between two calls on the same input:
+ * the order of additions inside a bucket follows arrival order in the bucket partition (the reference's
+ * representative likewise depends on its thread count).  h2mi_msm_set_canonical(1) makes every MSM end
+ * with a normalisation to Z = 1 (bit-reproducible output, about 0.17 ms more latency per MSM).
  * The reference asserts coeffs.len() == bases.len(); here n > registered n returns H2MI_ERANGE. */
 int h2mi_msm_bn254_g1(uint64_t handle_or_0, const uint64_t* bases_or_null /* used when handle==0 */,
                       const uint64_t* scalars /* n*4 limbs */, size_t n, uint64_t out_jacobian[12]);
 /* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
                           h2mi_stream_t stream);
+/* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */
+int h2mi_msm_set_canonical(int on);
 /* number of bucket insertions (non-zero signed digits) the last MSM on this handle performed, and the
  * running-sum reduction adds — the numerator of "G1-adds/s" (SURVEY.md 8d).  Synchronises. */
 int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds);

@@ -281,8 +281,9 @@ def test_golden_msm_and_srs(gpu):
 
 
 def test_msm_vs_c_oracle_large(gpu):
-    """2^16 points: the HIP MSM against the C restatement of best_multiexp (same group element), plus
-    run-to-run bit reproducibility of the Jacobian output (stable sort => fixed addition order)."""
+    """2^16 points: the HIP MSM against the C restatement of best_multiexp (same group element).  The
+    projective representative is only reproducible in canonical mode (h2mi_msm_set_canonical), where the
+    result has Z = 1 and equals the normalised point bit for bit."""
     from oracle import cref
 
     n = 1 << 16
@@ -290,9 +291,16 @@ def test_msm_vs_c_oracle_large(gpu):
     bases = params.get_g()
     for limbs in (o.random_field_limbs(n, o.SEED), o.witness_like_limbs(n, o.SEED)):
         got = params.commit(limbs)
-        want = cref.msm(limbs, bases, 8)
-        assert np.array_equal(cref.normalize(got), cref.normalize(want))
-        assert np.array_equal(got, params.commit(limbs))
+        want = cref.normalize(cref.msm(limbs, bases, 8))
+        assert np.array_equal(cref.normalize(got), want)
+        assert np.array_equal(cref.normalize(params.commit(limbs)), want)
+        assert gpu.lib.h2mi_msm_set_canonical(1) == 0
+        try:
+            canon = params.commit(limbs)
+            assert np.array_equal(canon, params.commit(limbs))
+            assert np.array_equal(canon[:8], want.reshape(-1)[:8]) and o.unpack(canon[8:12].reshape(1, 4), o.Q) == [1]
+        finally:
+            assert gpu.lib.h2mi_msm_set_canonical(0) == 0
     # shorter polynomial than the SRS (SHPLONK quotients): first m bases only
     m = 40000
     got = params.commit(o.random_field_limbs(m, 9))
@@ -500,8 +508,10 @@ def test_pipelined_msm_stress(gpu):
             assert lib.h2mi_join() == 0
     assert lib.h2mi_sync() == 0
     got = out.to_numpy(shape=(M, 12))
-    for i in range(M):
-        assert np.array_equal(got[i], want[i]), i
+    from oracle import cref
+
+    for i in range(M):  # same group elements (the projective representatives need not match)
+        assert np.array_equal(cref.normalize(got[i]), cref.normalize(want[i])), i
     params.release()
 
 
