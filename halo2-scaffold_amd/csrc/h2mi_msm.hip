@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
                                                            uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
                                                            uint8_t* keys_out) {
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], gbase[NBINS_MAX], wsum[NBINS_MAX / 64];
-  uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);           // P1_TS * W payloads
-  uint8_t* stage_key = reinterpret_cast<uint8_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids within the bin
+  uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);             // P1_TS * W payloads
+  uint16_t* stage_key = reinterpret_cast<uint16_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
   if (tid < NBINS_MAX) {
     cnt[tid] = 0;
@@ -304,23 +304,27 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
         const uint32_t bucket = ent[w] & 0x7FFFFFFFu;
         const uint32_t pos = lstart[bucket >> lb] + rk[w];
         stage_val[pos] = (ent[w] & 0x80000000u) | (uint32_t)((size_t)w * n_reg + i);
-        stage_key[pos] = (uint8_t)(bucket & mask);
+        stage_key[pos] = (uint16_t)bucket;
       }
   } else if (live) {
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
       uint32_t pos = atomicAdd(&cnt[bucket >> lb], 1u);
       stage_val[pos] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
-      stage_key[pos] = (uint8_t)(bucket & mask);
+      stage_key[pos] = (uint16_t)bucket;
     });
   }
   __syncthreads();
   // each wave writes whole bins: one contiguous run per (bin, tile)
-  for (uint32_t b = wave; b < nbins; b += P1_TS / 64) {
-    const uint32_t ls = lstart[b], len = lstart[b + 1] - ls, g = gbase[b];
-    for (uint32_t j = lane; j < len; j += 64) {
-      vals_out[g + j] = stage_val[ls + j];
-      keys_out[g + j] = stage_key[ls + j];
-    }
+  // the staged pairs are grouped by bin: slot p of bin b goes to gbase[b] + (p - lstart[b]); consecutive
+  // slots are consecutive in HBM inside a (bin, tile) run, so a wavefront's stores coalesce
+  if (tid < NBINS_MAX) gbase[tid] -= lstart[tid];
+  __syncthreads();
+  const uint32_t total = lstart[NBINS_MAX];
+  for (uint32_t p = tid; p < total; p += P1_TS) {
+    const uint32_t key = stage_key[p];
+    const uint32_t dst = p + gbase[key >> lb];
+    vals_out[dst] = stage_val[p];
+    keys_out[dst] = (uint8_t)(key & mask);
   }
 }
 
@@ -407,6 +411,52 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
       ccnt[tid] = 0;
     }
     __syncthreads();
+  }
+}
+
+// Exclusive scan of m <= 65536 counters (m a multiple of 4) by ONE workgroup, out[m] = total; block y of the
+// grid picks the array.  Each thread keeps a contiguous slice in registers (16-byte loads), so the data is
+// read once; the library scan costs 25-50 us of launch latency at these sizes.
+constexpr uint32_t SCAN_SMALL_MAX = 65536;
+__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1, uint32_t m) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t* in = blockIdx.x ? in1 : in0;
+  uint32_t* out = blockIdx.x ? out1 : out0;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t per = (((m + 1023) / 1024) + 3) & ~3u;  // <= 64
+  const uint32_t lo = min(tid * per, m), hi = min(lo + per, m);
+  uint4 r[16];
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint32_t j = lo + 4 * k;
+    r[k] = make_uint4(0, 0, 0, 0);
+    if (j < hi) {
+      r[k] = *reinterpret_cast<const uint4*>(in + j);
+      sum += r[k].x + r[k].y + r[k].z + r[k].w;
+    }
+  }
+  const uint32_t inc = wave_incl_scan(sum);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t a = inc - sum;
+  for (uint32_t w = 0; w < wave; w++) a += wsum[w];
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint32_t j = lo + 4 * k;
+    if (j < hi) {
+      uint4 o;
+      o.x = a; a += r[k].x;
+      o.y = a; a += r[k].y;
+      o.z = a; a += r[k].z;
+      o.w = a; a += r[k].w;
+      *reinterpret_cast<uint4*>(out + j) = o;
+    }
+  }
+  if (tid == 0) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < 16; w++) t += wsum[w];
+    out[m] = t;
   }
 }
 
@@ -810,7 +860,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
 #define H2_BIN_COUNT(CT) \
   H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
 #define H2_BIN_SCATTER(CT)                                                                                                              \
-  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 5, s, (const fe*)d_scalars, n, B->n, B->c, W, \
+  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 6, s, (const fe*)d_scalars, n, B->n, B->c, W, \
             B->lb, B->nbins, ntiles, (const uint32_t*)S.binbase, S.vals[0], S.bkeys)
     switch (B->c) {
       case 13: H2_BIN_COUNT(13); break;
@@ -818,10 +868,14 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 16: H2_BIN_COUNT(16); break;
       default: H2_BIN_COUNT(0); break;
     }
-    {
+    const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 unless nbins < 4 (tiny H2MI_MSM_C)
+    if (cells <= SCAN_SMALL_MAX && (cells & 3) == 0) {
+      H2_LAUNCH("k_scan_small_bins", k_scan_small, 1, 1024, 0, s, (const uint32_t*)S.bincnt, S.binbase, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                cells);
+    } else {
       const bool prof_ = prof_on("binscan_hipcub");
       if (prof_) prof_begin("binscan_hipcub", s);
-      hipError_t e = hipcub::DeviceScan::ExclusiveSum(S.bin_scan_tmp, B->bin_scan_tmp_bytes, S.bincnt, S.binbase, (int)(B->nbins * ntiles + 1), s);
+      hipError_t e = hipcub::DeviceScan::ExclusiveSum(S.bin_scan_tmp, B->bin_scan_tmp_bytes, S.bincnt, S.binbase, (int)(cells + 1), s);
       if (prof_) prof_end(s);
       H2_HIP(e);
     }
@@ -860,14 +914,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
               (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
   }
-  {
-    const bool prof_ = prof_on("hipcub_scan");
-    if (prof_) prof_begin("hipcub_scan", hs);
-    hipError_t e0 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs);
-    hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs);
-    if (prof_) prof_end(hs);
-    H2_HIP(e0);
-    H2_HIP(e1);
+  if (nb >= 4 && nb <= SCAN_SMALL_MAX) {
+    H2_LAUNCH("k_scan_small_tasks", k_scan_small, 2, 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb);
+  } else {
+    H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
+    H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
   }
   uint32_t tasks0 = (uint32_t)((n * W >> ls0) + nb);
   if (pipelined) {
