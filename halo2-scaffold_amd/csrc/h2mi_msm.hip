@@ -43,6 +43,7 @@ struct Slot {
   uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
   uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
   void* bin_scan_tmp = nullptr;
+  uint32_t* binseg = nullptr;   // sums of the 65536-cell segments of bincnt
   uint32_t* hist = nullptr;     // nb
   uint32_t* off = nullptr;      // nb+1
   uint32_t* np[2] = {nullptr, nullptr};    // tasks per bucket: accumulation, fold (nb+1 entries, last = 0)
@@ -251,13 +252,14 @@ template <uint32_t CT>
 __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
                                                            uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
                                                            uint8_t* keys_out) {
-  __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], gbase[NBINS_MAX], wsum[NBINS_MAX / 64];
+  __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
   uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);             // P1_TS * W payloads
   uint16_t* stage_key = reinterpret_cast<uint16_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  uint32_t gb = 0;
   if (tid < NBINS_MAX) {
     cnt[tid] = 0;
-    gbase[tid] = tid < nbins ? base[(size_t)tid * ntiles + tile] : 0;
+    gb = tid < nbins ? base[(size_t)tid * ntiles + tile] : 0;  // this tile's first slot in bin `tid`
   }
   __syncthreads();
   size_t i = (size_t)tile * P1_TS + tid;
@@ -315,14 +317,14 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   }
   __syncthreads();
   // each wave writes whole bins: one contiguous run per (bin, tile)
-  // the staged pairs are grouped by bin: slot p of bin b goes to gbase[b] + (p - lstart[b]); consecutive
+  // the staged pairs are grouped by bin: slot p of bin b goes to base[b][tile] + (p - lstart[b]); consecutive
   // slots are consecutive in HBM inside a (bin, tile) run, so a wavefront's stores coalesce
-  if (tid < NBINS_MAX) gbase[tid] -= lstart[tid];
+  if (tid < NBINS_MAX) cnt[tid] = gb - lstart[tid];
   __syncthreads();
   const uint32_t total = lstart[NBINS_MAX];
   for (uint32_t p = tid; p < total; p += P1_TS) {
     const uint32_t key = stage_key[p];
-    const uint32_t dst = p + gbase[key >> lb];
+    const uint32_t dst = p + cnt[key >> lb];
     vals_out[dst] = stage_val[p];
     keys_out[dst] = (uint8_t)(key & mask);
   }
@@ -414,21 +416,56 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
   }
 }
 
-// Exclusive scan of m <= 65536 counters (m a multiple of 4) by ONE workgroup, out[m] = total; block y of the
-// grid picks the array.  Each thread keeps a contiguous slice in registers (16-byte loads), so the data is
-// read once; the library scan costs 25-50 us of launch latency at these sizes.
-constexpr uint32_t SCAN_SMALL_MAX = 65536;
-__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1, uint32_t m) {
+// Exclusive scan of m counters (m a multiple of 4), out[m] = total.  One workgroup per segment of SEG
+// counters, each thread keeping a contiguous slice in registers (16-byte loads); with more than one segment
+// k_scan_segsum runs first and every workgroup adds the sums of the segments before its own.  blockIdx.y
+// picks the array.  (The library's look-back scan takes 15-70 us at these sizes, mostly launch latency.)
+constexpr uint32_t SCAN_SEG_TASKS = 65536;  // the task counts (<= 32769): one launch, one workgroup per array
+constexpr uint32_t SCAN_SEG_BINS = 8192;    // the [bin][tile] matrix: many short segments spread over the CUs
+__device__ __forceinline__ uint32_t block_sum_1024(uint32_t v, uint32_t* wsum /* 16 */) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t t = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; w++) t += wsum[w];
+  return t;
+}
+template <uint32_t SEG>
+__global__ void __launch_bounds__(1024) k_scan_segsum(const uint32_t* in, uint32_t m, uint32_t* segsum) {
   __shared__ uint32_t wsum[16];
-  const uint32_t* in = blockIdx.x ? in1 : in0;
-  uint32_t* out = blockIdx.x ? out1 : out0;
+  const uint32_t seg0 = blockIdx.x * SEG, len = min(SEG, m - seg0);
+  uint32_t sum = 0;
+  for (uint32_t j = threadIdx.x * 4; j < len; j += 4096) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + seg0 + j);
+    sum += v.x + v.y + v.z + v.w;
+  }
+  const uint32_t t = block_sum_1024(sum, wsum);
+  if (threadIdx.x == 0) segsum[blockIdx.x] = t;
+}
+template <uint32_t SEG>
+__global__ void __launch_bounds__(1024) k_scan_seg(const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1, uint32_t m,
+                                                   const uint32_t* segsum) {
+  __shared__ uint32_t wsum[16], wsum2[16];
+  constexpr uint32_t NV = SEG / 4096;  // 16-byte vectors per thread
+  const uint32_t seg = blockIdx.x, seg0 = seg * SEG, len = min(SEG, m - seg0);
+  const uint32_t* in = (blockIdx.y ? in1 : in0) + seg0;
+  uint32_t* out = (blockIdx.y ? out1 : out0) + seg0;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t per = (((m + 1023) / 1024) + 3) & ~3u;  // <= 64
-  const uint32_t lo = min(tid * per, m), hi = min(lo + per, m);
-  uint4 r[16];
+  uint32_t before = 0;  // sum of the earlier segments
+  if (seg) {
+    uint32_t part = 0;
+    for (uint32_t j = tid; j < seg; j += 1024) part += segsum[j];
+    before = block_sum_1024(part, wsum2);
+  }
+  const uint32_t per = (((len + 1023) / 1024) + 3) & ~3u;  // <= 4 * NV
+  const uint32_t lo = min(tid * per, len), hi = min(lo + per, len);
+  uint4 r[NV];
   uint32_t sum = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < 16; k++) {
+  for (uint32_t k = 0; k < NV; k++) {
     const uint32_t j = lo + 4 * k;
     r[k] = make_uint4(0, 0, 0, 0);
     if (j < hi) {
@@ -439,10 +476,10 @@ __global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* in0, uint32
   const uint32_t inc = wave_incl_scan(sum);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  uint32_t a = inc - sum;
+  uint32_t a = before + inc - sum;
   for (uint32_t w = 0; w < wave; w++) a += wsum[w];
 #pragma unroll
-  for (uint32_t k = 0; k < 16; k++) {
+  for (uint32_t k = 0; k < NV; k++) {
     const uint32_t j = lo + 4 * k;
     if (j < hi) {
       uint4 o;
@@ -453,10 +490,10 @@ __global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* in0, uint32
       *reinterpret_cast<uint4*>(out + j) = o;
     }
   }
-  if (tid == 0) {
-    uint32_t t = 0;
+  if (tid == 0 && seg0 + len == m) {
+    uint32_t t = before;
     for (uint32_t w = 0; w < 16; w++) t += wsum[w];
-    out[m] = t;
+    out[len] = t;
   }
 }
 
@@ -700,7 +737,7 @@ static void free_bases(Bases* B) {
   hipFree(B->table);
   for (Slot& S : B->slot) {
     hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
-    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp);
+    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
     hipFree(S.hist); hipFree(S.off);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
@@ -769,6 +806,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.bincnt, bin_cells * 4);
     H2_ALLOC(S.binbase, bin_cells * 4);
     H2_ALLOC(S.bin_scan_tmp, B->bin_scan_tmp_bytes ? B->bin_scan_tmp_bytes : 16);
+    H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
     H2_ALLOC(S.hist, (size_t)B->nb * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     for (int i = 0; i < 2; i++) {
@@ -869,9 +907,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       default: H2_BIN_COUNT(0); break;
     }
     const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 unless nbins < 4 (tiny H2MI_MSM_C)
-    if (cells <= SCAN_SMALL_MAX && (cells & 3) == 0) {
-      H2_LAUNCH("k_scan_small_bins", k_scan_small, 1, 1024, 0, s, (const uint32_t*)S.bincnt, S.binbase, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                cells);
+    if ((cells & 3) == 0) {
+      const uint32_t nseg = ceil_div_u32(cells, SCAN_SEG_BINS);
+      if (nseg > 1) H2_LAUNCH("k_scan_segsum", k_scan_segsum<SCAN_SEG_BINS>, nseg, 1024, 0, s, (const uint32_t*)S.bincnt, cells, S.binseg);
+      H2_LAUNCH("k_scan_seg_bins", k_scan_seg<SCAN_SEG_BINS>, dim3(nseg, 1), 1024, 0, s, (const uint32_t*)S.bincnt, S.binbase, (const uint32_t*)nullptr,
+                (uint32_t*)nullptr, cells, (const uint32_t*)S.binseg);
     } else {
       const bool prof_ = prof_on("binscan_hipcub");
       if (prof_) prof_begin("binscan_hipcub", s);
@@ -914,8 +954,9 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
               (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
   }
-  if (nb >= 4 && nb <= SCAN_SMALL_MAX) {
-    H2_LAUNCH("k_scan_small_tasks", k_scan_small, 2, 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb);
+  if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
+    H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
+              (const uint32_t*)nullptr);
   } else {
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
@@ -926,7 +967,13 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipStreamWaitEvent(as, S.head_done, 0));
     S.head_pending = true;
   }
-  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, 0, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
+  // Occupancy cap: the accumulation runs as fast with 2 wavefronts per SIMD as with 4 (it is bound by VALU
+  // issue, not latency), but at 4 it owns every VGPR of the chip and the short kernels of the neighbouring
+  // MSMs (bucket reduction, partition) cannot start until it drains.  An unused dynamic-LDS reservation of
+  // 56000 B holds it at two workgroups per CU and leaves half the registers and 48 KB of LDS per CU free:
+  // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
+  static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
             (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
   hipStream_t t = ts;
   if (pipelined) {

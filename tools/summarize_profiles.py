@@ -22,7 +22,7 @@ def per_kernel(path, counter):
             continue
         k = r["Kernel_Name"].split("(")[0].replace("h2::", "")
         if "rocprim" in k:
-            k = "rocprim_radix_sort"
+            k = "rocprim_scan"
         tot[k] += float(r["Counter_Value"])
         cnt[k] += 1
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
@@ -61,7 +61,7 @@ n = collections.Counter()
 for r in csv.DictReader(open(f"{src}/sq/s_counter_collection.csv")):
     k = r["Kernel_Name"].split("(")[0].replace("h2::", "")
     if "rocprim" in k:
-        k = "rocprim_radix_sort"
+        k = "rocprim_scan"
     sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVE_CYCLES":
         n[k] += 1
