@@ -6,12 +6,13 @@
 //
 // MI355X-first design (not the reference's per-thread serial Pippenger):
 //  * bases are registered once and kept in HBM together with the table 2^(c*w) * P_i for every window
-//    w (W x n x 64 B; 1 GiB at n = 2^20, c = 16 — HBM is 288 GB).  All windows then feed ONE set of
+//    w (W x n x 64 B; 0.94 GiB at n = 2^20, c = 17 — HBM is 288 GB).  All windows then feed ONE set of
 //    2^(c-1) buckets, so there is no per-window reduction and no c-doubling Horner chain;
 //  * scalars: Montgomery -> canonical, signed c-bit digits (halves the bucket count), zero digits skipped;
-//  * (bucket, point) pairs are radix-sorted by bucket id (stable, so the addition order — and with it
-//    every output bit — is reproducible); global atomics are avoided: on gfx950 a device-scope atomic is a
-//    64-B memory-side transaction (~24 G/s measured), 10x slower than sorting;
+//  * (bucket, point) pairs are grouped by bucket with a two-level counting partition in LDS (tile ->
+//    512 bins -> buckets; see "bucket partition" below) instead of a general key/value radix sort; global
+//    atomics are avoided: on gfx950 a device-scope atomic is a 64-B memory-side transaction (~24 G/s
+//    measured), far slower than staging through LDS;
 //  * bucket accumulation is load-balanced: a bucket's sorted run is cut into tasks of <= 64 points, one
 //    thread per task, mixed additions in XYZZ coordinates on 64-B gathered table points, so a hot
 //    bucket (witness columns full of 0/1) never serialises a wavefront; partial sums are folded by
@@ -36,9 +37,7 @@ constexpr uint32_t FG = 8;       // lanes that cooperate on one bucket in k_msm_
 // per-call workspace; two slots per handle so that the latency-bound tail of one MSM (fold, bucket
 // reduction) runs on the tail stream while the next MSM's sort and accumulation already run.
 struct Slot {
-  uint16_t* keys[2] = {nullptr, nullptr};     // [W][n] bucket id per (window, scalar); 0xFFFF = zero digit
-  uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i ; [1] holds the sorted order
-  void* sort_tmp = nullptr;
+  uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i : [0] grouped by bin, [1] by bucket
   uint8_t* bkeys = nullptr;     // partition intermediate: bucket id within the bin, bin-major
   uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
   uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
@@ -63,9 +62,8 @@ struct Bases {
   size_t n = 0;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
-  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0, bin_scan_tmp_bytes = 0;
+  size_t scan_tmp_bytes = 0, bin_scan_tmp_bytes = 0;
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
-  bool radix = false;           // H2MI_MSM_SORT=radix: the general key/value radix sort instead (A/B only)
   Slot slot[NSLOT];
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0;
@@ -109,70 +107,7 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
 }
 
 // ---- per call -------------------------------------------------------------------------------------
-// signed-digit recoding: digit d_w in [-2^(c-1)+1, 2^(c-1)]; emits the sort key (bucket |d|-1, or 0xFFFF
-// for a zero digit, which sorts behind every bucket) and the payload sign<<31 | table index.
-__global__ void __launch_bounds__(256) k_msm_digits(const fe* scalars, size_t n, size_t n_reg, uint16_t* keys, uint32_t* vals, uint32_t c,
-                                                     uint32_t W) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
-  uint32_t carry = 0;
-  const uint32_t half = 1u << (c - 1);
-  for (uint32_t w = 0; w < W; w++) {
-    uint32_t bit = w * c;
-    uint32_t limb = bit >> 5, sh = bit & 31;
-    uint32_t raw = 0;
-    if (limb < 8) {
-      uint64_t two = s.v[limb];
-      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
-      raw = (uint32_t)(two >> sh) & ((1u << c) - 1);
-    }
-    uint32_t d = raw + carry;  // 0 .. 2^c
-    uint32_t mag, neg;
-    if (d > half) {  // negative digit d - 2^c, carry 1
-      mag = (1u << c) - d;  // 0 .. 2^(c-1)-1
-      neg = 1;
-      carry = 1;
-    } else {
-      mag = d;
-      neg = 0;
-      carry = 0;
-    }
-    keys[(size_t)w * n + i] = mag ? (uint16_t)(mag - 1) : (uint16_t)0xFFFFu;
-    vals[(size_t)w * n + i] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
-  }
-}
-
-// bucket boundaries in the sorted key array: off[b] = first index with key >= b, hist[b] = run length;
-// also the task counts of the accumulation (chunks of 2^ls0 entries) and of the fold (chunks of S1 partials)
-__global__ void __launch_bounds__(256) k_msm_bounds(const uint16_t* keys, uint32_t total, uint32_t nb, uint32_t ls0, uint32_t* off, uint32_t* hist,
-                                                     uint32_t* np0, uint32_t* np1) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nb) return;
-  uint32_t lo = 0, hi = total;  // first index with key >= b
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (keys[mid] < b) lo = mid + 1;
-    else hi = mid;
-  }
-  off[b] = lo;
-  uint32_t cnt = 0;
-  if (b < nb) {
-    uint32_t lo2 = lo, hi2 = total;
-    while (lo2 < hi2) {
-      uint32_t mid = (lo2 + hi2) >> 1;
-      if (keys[mid] < b + 1) lo2 = mid + 1;
-      else hi2 = mid;
-    }
-    cnt = lo2 - lo;
-    hist[b] = cnt;
-  }
-  uint32_t f0 = (cnt + (1u << ls0) - 1) >> ls0;
-  np0[b] = f0;                    // entry nb = 0: the scans then leave the totals in toff[nb]
-  np1[b] = (f0 + S1 - 1) / S1;
-}
-
-// ---- bucket partition (the default head of an MSM) -------------------------------------------------------
+// ---- bucket partition (the head of an MSM) -------------------------------------------------------
 // Groups the (bucket, point) pairs by bucket with a two-level counting partition instead of a general
 // radix sort; zero digits are never materialised.  NBINS top-level bins of 2^lb buckets each:
 //   k_msm_bin_count    per tile of P1_TS scalars: entries per bin                 (reads the scalars)
@@ -189,12 +124,14 @@ constexpr uint32_t P1_TS = 1024;       // scalars per partition tile = threads p
 constexpr uint32_t NBINS_MAX = 512;
 constexpr uint32_t P2_THREADS = 512, P2_PER = 16, P2_CH = P2_THREADS * P2_PER;
 
-// CT = compile-time window width (13, 15, 16: fully unrolled, limb indices become constants) or 0 = use
+// Windows: a canonical scalar has 254 bits and the signed recoding can carry one into the top window, so
+// W = ceil(255 / c) windows suffice (the top digit then stays <= 2^(c-1): never negative, no carry out).
+// CT = compile-time window width (13, 15, 16, 17: fully unrolled, limb indices become constants) or 0 = use
 // the run-time c (H2MI_MSM_C experiments only: the dynamically indexed limbs then live in LDS/scratch)
 template <uint32_t CT, class F>
 __device__ __forceinline__ void for_each_digit(const fe& s, uint32_t c_rt, uint32_t W_rt, F&& f) {
   const uint32_t c = CT ? CT : c_rt;
-  const uint32_t W = CT ? (256 + CT - 1) / CT : W_rt;
+  const uint32_t W = CT ? (255 + CT - 1) / CT : W_rt;
   uint32_t carry = 0;
   const uint32_t half = 1u << (c - 1);
 #pragma unroll
@@ -267,7 +204,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   const bool live = i < n;
   // compile-time windows: the rank each entry drew from its bin counter is kept in registers, so the digits
   // are walked once; run-time c walks them twice (count, then place) to stay out of scratch arrays
-  constexpr uint32_t WK = CT ? (256 + CT - 1) / CT : 1;
+  constexpr uint32_t WK = CT ? (255 + CT - 1) / CT : 1;
   uint32_t ent[WK], rk[WK];
 #pragma unroll
   for (uint32_t w = 0; w < WK; w++) ent[w] = 0xFFFFFFFFu;
@@ -330,17 +267,18 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   }
 }
 
+constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 512 bins)
 __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
                                                              uint32_t nbins, uint32_t lb, uint32_t ls0, uint32_t nb, uint32_t* vals_out,
                                                              uint32_t* off, uint32_t* hist, uint32_t* np0, uint32_t* np1) {
-  __shared__ uint32_t wh[P2_THREADS / 64][64];
-  __shared__ uint32_t run[64], ccnt[64], cstart[64];
+  __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
+  __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
   __shared__ uint32_t stage[P2_CH];
   __shared__ uint8_t stage_q[P2_CH];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, bin = blockIdx.x;
   const uint32_t start = base[(size_t)bin * ntiles], end = base[(size_t)(bin + 1) * ntiles];
   const uint32_t nq = 1u << lb;
-  for (uint32_t j = tid; j < (P2_THREADS / 64) * 64; j += P2_THREADS) (&wh[0][0])[j] = 0;
+  for (uint32_t j = tid; j < (P2_THREADS / 64) * NQ_MAX; j += P2_THREADS) (&wh[0][0])[j] = 0;
   __syncthreads();
   // 16 keys per load; the buffer is padded so that the aligned window may overhang [start, end)
   for (uint32_t j = (start & ~15u) + tid * 16; j < end; j += P2_THREADS * 16) {
@@ -349,15 +287,21 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
 #pragma unroll
     for (uint32_t t = 0; t < 16; t++) {
       const uint32_t idx = j + t;
-      if (idx >= start && idx < end) atomicAdd(&wh[wave][(w4[t >> 2] >> (8 * (t & 3))) & 0xFFu], 1u);
+      if (idx >= start && idx < end) atomicAdd(&wh[wave][(w4[t >> 2] >> (8 * (t & 3))) & (NQ_MAX - 1)], 1u);
     }
   }
   __syncthreads();
-  if (tid < 64) {
-    uint32_t tot = 0;
+  // exclusive scan over the bin's buckets (two wavefronts of 64)
+  uint32_t tot = 0, inc = 0;
+  if (tid < NQ_MAX) {
 #pragma unroll
     for (uint32_t w = 0; w < P2_THREADS / 64; w++) tot += wh[w][tid];
-    uint32_t ex = wave_incl_scan(tot) - tot;
+    inc = wave_incl_scan(tot);
+    if (tid == 63) carry64 = inc;
+  }
+  __syncthreads();
+  if (tid < NQ_MAX) {
+    const uint32_t ex = inc - tot + (tid >= 64 ? carry64 : 0);
     run[tid] = start + ex;
     ccnt[tid] = 0;
     if (tid < nq) {
@@ -382,7 +326,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
     for (uint32_t k = 0; k < P2_PER; k++) {
       const uint32_t p = k * P2_THREADS + tid;
       if (p < m) {
-        q[k] = keys_in[cs + p];
+        q[k] = keys_in[cs + p] & (NQ_MAX - 1);
         v[k] = vals_in[cs + p];
       }
     }
@@ -390,10 +334,14 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
     for (uint32_t k = 0; k < P2_PER; k++)
       if (k * P2_THREADS + tid < m) r[k] = atomicAdd(&ccnt[q[k]], 1u);
     __syncthreads();
-    if (tid < 64) {
-      const uint32_t cn = ccnt[tid];
-      cstart[tid] = wave_incl_scan(cn) - cn;
+    uint32_t cn = 0, cinc = 0;
+    if (tid < NQ_MAX) {
+      cn = ccnt[tid];
+      cinc = wave_incl_scan(cn);
+      if (tid == 63) carry64 = cinc;
     }
+    __syncthreads();
+    if (tid < NQ_MAX) cstart[tid] = cinc - cn + (tid >= 64 ? carry64 : 0);
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < P2_PER; k++)
@@ -408,7 +356,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
       vals_out[run[qq] + (p - cstart[qq])] = stage[p];
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < NQ_MAX) {
       run[tid] += ccnt[tid];
       ccnt[tid] = 0;
     }
@@ -710,14 +658,16 @@ static uint32_t pick_window(size_t n) {
   const char* ev = getenv("H2MI_MSM_C");
   if (ev) {
     int c = atoi(ev);
-    if (c >= 4 && c <= 16) return (uint32_t)c;
+    if (c >= 11 && c <= 17) return (uint32_t)c;  // below 11 the scatter tile (1024 x W pairs) outgrows LDS
   }
   uint32_t lg = 0;
   while (((size_t)1 << lg) < n) lg++;
-  // Larger windows mean fewer point additions (n * ceil(256/c)); the bucket phase is latency-bound and
+  // Larger windows mean fewer point additions (n * ceil(255/c)); the bucket phase is latency-bound and
   // nearly independent of the bucket count.  Only windows whose TOP window still holds many scalar bits
-  // are used (254 mod c large): c = 12 or 14 leave 2 bits there, i.e. four buckets that each receive n/4
-  // points.
+  // are used: c = 12 or 14 leave 2 bits there, i.e. four buckets that each receive n/4 points.
+  // c = 17 (15 windows, the widest the bucket-matrix kernels take; H2MI_MSM_C=17) measured 2 % faster
+  // than c = 16 at 2^20 and no faster at 2^22 — twice the buckets to reduce for 6 % fewer additions — so
+  // it is not the default.
   int c = lg >= 20 ? 16 : lg >= 18 ? 15 : 13;
   return (uint32_t)c;
 }
@@ -736,7 +686,7 @@ static uint32_t pick_chunk(size_t entries) {
 static void free_bases(Bases* B) {
   hipFree(B->table);
   for (Slot& S : B->slot) {
-    hipFree(S.keys[0]); hipFree(S.keys[1]); hipFree(S.vals[0]); hipFree(S.vals[1]); hipFree(S.sort_tmp);
+    hipFree(S.vals[0]); hipFree(S.vals[1]);
     hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
     hipFree(S.hist); hipFree(S.off);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
@@ -765,7 +715,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   Bases* B = new Bases();
   B->n = n;
   B->c = pick_window(n);
-  B->W = (256 + B->c - 1) / B->c;
+  B->W = (255 + B->c - 1) / B->c;
   B->nb = 1u << (B->c - 1);
   B->logNl = (B->c - 1 + 1) / 2;
   B->logNh = (B->c - 1) - B->logNl;
@@ -774,20 +724,11 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb);  // pick_chunk keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
-  {
-    const char* ev = getenv("H2MI_MSM_SORT");
-    B->radix = ev && !strcmp(ev, "radix");
-  }
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
   B->nbins = B->nb >> B->lb;  // <= NBINS_MAX
   const size_t ntiles_max = (n + P1_TS - 1) / P1_TS;
   const size_t bin_cells = (size_t)B->nbins * ntiles_max + 1;
   if (bin_cells >= ((size_t)1 << 31)) { free_bases(B); return H2MI_ERANGE; }
-  if (B->radix && hipcub::DeviceRadixSort::SortPairs(nullptr, B->sort_tmp_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
-                                                     (uint32_t*)nullptr, (unsigned int)nW, 0, 16, s) != hipSuccess) {
-    free_bases(B);
-    return H2MI_EHIP;
-  }
   if (hipcub::DeviceScan::ExclusiveSum(nullptr, B->bin_scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)bin_cells, s) != hipSuccess) {
     free_bases(B);
     return H2MI_EHIP;
@@ -797,11 +738,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     return H2MI_EHIP;
   }
   for (Slot& S : B->slot) {
-    for (int i = 0; i < 2; i++) {
-      if (B->radix) H2_ALLOC(S.keys[i], nW * 2);
-      H2_ALLOC(S.vals[i], nW * 4);
-    }
-    if (B->radix) H2_ALLOC(S.sort_tmp, B->sort_tmp_bytes ? B->sort_tmp_bytes : 16);
+    for (int i = 0; i < 2; i++) H2_ALLOC(S.vals[i], nW * 4);
     H2_ALLOC(S.bkeys, nW + 16);
     H2_ALLOC(S.bincnt, bin_cells * 4);
     H2_ALLOC(S.binbase, bin_cells * 4);
@@ -859,8 +796,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   B->last_slot = B->next_slot;
   B->next_slot = (B->next_slot + 1) % NSLOT;
   // streams: caller-provided stream => everything in order on it.  Library stream => three stages:
-  //   s : digit extraction (the only reader of the caller's scalars)
-  //   hs: sort, bounds, scans
+  //   s : partition level 1: bin count, offsets, scatter (the only readers of the caller's scalars)
+  //   hs: partition level 2 (per-bin sort, bucket tables), task offsets
   //   as: accumulation                   (never blocks s: NTTs queued on s meanwhile run beside it)
   //   ts: fold ... final                 (joined into s by h2mi_join / h2mi_sync / h2mi_memcpy_d2h)
   hipStream_t hs = s, as = s, ts = s;
@@ -875,8 +812,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     hs = ctx().head_stream;
     as = ctx().accum_stream;
     ts = ctx().tail_stream;
-    // the digit kernel is the only reader of the caller's scalars: it stays on s, so work queued on s after
-    // this call may overwrite them.  It writes keys[0]/vals[0], last read by this slot's previous sort.
+    // the first partition level (count, scan, scatter) is the only reader of the caller's scalars and stays
+    // on s.  It writes bincnt/binbase/bkeys/vals[0], last read by this slot's previous k_msm_bin_sort.
     if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
   } else {
     if (S.tail_pending) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
@@ -884,17 +821,18 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   }
   const uint32_t ntiles = ceil_div_u32(n, P1_TS);
   static bool attr_set = false;
-  if (!attr_set) {  // the scatter kernel stages up to 100 KiB of pairs in LDS
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  if ((size_t)P1_TS * W * 6 > 150 * 1024) return H2MI_ERANGE;
+  if (!attr_set) {  // the scatter kernel stages up to 144 KiB of pairs in LDS (W = 24; 90 KiB at W = 15)
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  if (B->radix) {
-    H2_LAUNCH("k_msm_digits", k_msm_digits, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n, B->n, S.keys[0], S.vals[0], B->c, W);
-  } else {
-    // the partition's first level reads the scalars twice (count, scatter): both stay on s
+  {
+    // the partition's first level reads the scalars twice (count, scatter): both stay on s, so work queued
+    // on s after this call may overwrite them
 #define H2_BIN_COUNT(CT) \
   H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
 #define H2_BIN_SCATTER(CT)                                                                                                              \
@@ -904,6 +842,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 13: H2_BIN_COUNT(13); break;
       case 15: H2_BIN_COUNT(15); break;
       case 16: H2_BIN_COUNT(16); break;
+      case 17: H2_BIN_COUNT(17); break;
       default: H2_BIN_COUNT(0); break;
     }
     const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 unless nbins < 4 (tiny H2MI_MSM_C)
@@ -923,6 +862,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 13: H2_BIN_SCATTER(13); break;
       case 15: H2_BIN_SCATTER(15); break;
       case 16: H2_BIN_SCATTER(16); break;
+      case 17: H2_BIN_SCATTER(17); break;
       default: H2_BIN_SCATTER(0); break;
     }
 #undef H2_BIN_COUNT
@@ -939,21 +879,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.tail_pending = false;
   S.accum_pending = false;
   S.head_pending = false;
-  if (B->radix) {
-    {
-      const bool prof_ = prof_on("hipcub_radix_sort");
-      if (prof_) prof_begin("hipcub_radix_sort", hs);
-      // keys are bucket ids < 2^(c-1) or the 0xFFFF sentinel: all 16 bits take part
-      hipError_t e = hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, B->sort_tmp_bytes, S.keys[0], S.keys[1], S.vals[0], S.vals[1], total, 0, 16, hs);
-      if (prof_) prof_end(hs);
-      H2_HIP(e);
-    }
-    H2_LAUNCH("k_msm_bounds", k_msm_bounds, ceil_div_u32(nb + 1, 256), 256, 0, hs, (const uint16_t*)S.keys[1], total, nb, ls0, S.off, S.hist,
-              S.np[0], S.np[1]);
-  } else {
-    H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
-              (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
-  }
+  H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
+            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
   if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
     H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
               (const uint32_t*)nullptr);

@@ -587,6 +587,30 @@ def test_task_size_override_is_clamped_to_buffer_capacity(gpu):
     params.release()
 
 
+@pytest.mark.parametrize("c", [17, 14, 12, 11])
+def test_window_width_override_matches_default(gpu, c):
+    """H2MI_MSM_C picks another window width at registration: 17 is the widest supported (2^16 buckets, 128
+    per partition bin), 14 leaves a thin top window (hot buckets), 12 and 11 take the run-time digit loop, 11
+    with the largest scatter tile that fits LDS.  Every width must give the same group element."""
+    from oracle import cref
+
+    k = 14
+    g = gpu.ParamsKZG.setup(k, 0xBEEF)
+    bases = g.get_g()
+    os.environ["H2MI_MSM_C"] = str(c)
+    try:
+        alt = gpu.ParamsKZG.from_bases(k, bases)
+    finally:
+        del os.environ["H2MI_MSM_C"]
+    cc, W, nb, nn = (C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64())
+    assert gpu.lib.h2mi_bases_info(alt.g_handle, C.byref(cc), C.byref(W), C.byref(nb), C.byref(nn)) == 0
+    assert (cc.value, W.value, nb.value) == (c, -(-255 // c), 1 << (c - 1))
+    for sc in (o.random_field_limbs(1 << k, 77), o.witness_like_limbs(1 << k, 78), o.pack([o.R - 1] * (1 << k), o.R)):
+        assert np.array_equal(cref.normalize(alt.commit(sc)), cref.normalize(g.commit(sc)))
+    alt.release()
+    g.release()
+
+
 def test_no_device_memory_leak(gpu):
     """register / commit / release cycles and NTT plan churn must return device memory to where it started."""
     import torch
