@@ -176,6 +176,7 @@ int h2mi_init(int device) {
 void h2mi_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   if (!ctx().inited) return;
+  msm_join_all(ctx().stream);
   hipStreamSynchronize(ctx().stream);
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; }
   hipDeviceSynchronize();

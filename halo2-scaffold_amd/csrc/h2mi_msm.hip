@@ -34,8 +34,8 @@ constexpr uint32_t S0_MAX = 64;  // points per accumulation task (smaller for sm
 constexpr uint32_t S1 = 8;       // partials per fold task
 constexpr uint32_t FG = 8;       // lanes that cooperate on one bucket in k_msm_finish
 
-// per-call workspace; two slots per handle so that the latency-bound tail of one MSM (fold, bucket
-// reduction) runs on the tail stream while the next MSM's sort and accumulation already run.
+// per-call workspace; several slots per handle so that consecutive MSMs overlap (partition of one beside
+// the accumulation of another) and their bucket reductions can be deferred and run as one batch.
 struct Slot {
   uint32_t* vals[2] = {nullptr, nullptr};     // sign<<31 | w*n_reg+i : [0] grouped by bin, [1] by bucket
   uint8_t* bkeys = nullptr;     // partition intermediate: bucket id within the bin, bin-major
@@ -55,8 +55,12 @@ struct Slot {
   uint64_t* stats = nullptr;                        // [0] = insertions
   hipEvent_t input_ready = nullptr, head_done = nullptr, accum_done = nullptr, tail_done = nullptr;
   bool tail_pending = false, accum_pending = false, head_pending = false;
+  bool tail_deferred = false;   // accumulation queued, bucket reduction not yet launched (see flush_tails)
+  void* d_out = nullptr;        // where that reduction will write the result
+  uint32_t tasks1 = 0;          // its fold grid bound
 };
-constexpr int NSLOT = 2;
+// slots per handle = MSMs that can be in flight between two joins before a flush is forced
+constexpr int NSLOT = 4;
 
 struct Bases {
   size_t n = 0;
@@ -512,23 +516,42 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
   part_store(part + (size_t)t * PART_BYTES, acc);
 }
 
+// ---- bucket reduction ("tail"), batched --------------------------------------------------------------
+// fold -> finish -> rowcol -> weighted -> final is a chain of ~40 dependent point operations (5-9 us each
+// for a lone wavefront) over little data, so its cost is latency, not throughput.  MSMs queued on the
+// library stream therefore only leave their accumulated partials behind; the tails of all MSMs since the
+// last join run as ONE batch of these kernels (blockIdx.y = MSM), paying the latency once per batch.
+constexpr uint32_t TAIL_BATCH = 8;
+struct TailDesc {
+  const uint8_t* part0;   // accumulation output
+  const uint32_t *toff0, *np0, *toff1, *np1, *off;
+  uint8_t *part1, *dense, *rc, *g, *out;
+  uint64_t* stats;
+  uint32_t nb, logNh, logNl, canonical;
+};
+struct TailBatch {
+  TailDesc d[TAIL_BATCH];
+};
+
 // fold level: one thread per task of <= S1 partials of one bucket
-__global__ void __launch_bounds__(256) k_msm_fold(const uint8_t* pin, const uint32_t* toff_in, const uint32_t* np_in, const uint32_t* toff_out,
-                                                   uint32_t nb, uint8_t* pout) {
+__global__ void __launch_bounds__(256) k_msm_fold(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
+  const uint32_t nb = d.nb;
+  const uint32_t *toff_out = d.toff1, *toff_in = d.toff0, *np_in = d.np0;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= toff_out[nb]) return;
   uint32_t b = find_bucket(toff_out, nb, t);
   uint32_t j = t - toff_out[b];
-  const uint32_t m = np_in[b], np = toff_out[b + 1] - toff_out[b];  // balanced split, as in k_msm_accum
+  const uint32_t m = np_in[b], np = toff_out[b + 1] - toff_out[b];  // balanced split of the bucket's partials
   const uint32_t q = m / np, r = m - q * np;
   uint32_t start = toff_in[b] + j * q + min(j, r);
   uint32_t len = q + (j < r ? 1u : 0u);
-  xyzz29 acc = part_load(pin + (size_t)start * PART_BYTES);
+  xyzz29 acc = part_load(d.part0 + (size_t)start * PART_BYTES);
   for (uint32_t k = 1; k < len; k++) {
-    xyzz29 p = part_load(pin + (size_t)(start + k) * PART_BYTES);
+    xyzz29 p = part_load(d.part0 + (size_t)(start + k) * PART_BYTES);
     xyzz29_add(acc, p);
   }
-  part_store(pout + (size_t)t * PART_BYTES, acc);
+  part_store(d.part1 + (size_t)t * PART_BYTES, acc);
 }
 
 // bucket finish: FG lanes cooperate on one bucket: lane l sums partials l, l+FG, ... (one partial each in
@@ -544,22 +567,25 @@ __device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta
   }
   return r;
 }
-__global__ void __launch_bounds__(256) k_msm_finish(const uint8_t* part, const uint32_t* toff, const uint32_t* np, uint32_t nb, uint8_t* dense) {
+__global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
+  const uint32_t nb = d.nb;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t b = t / FG, l = t % FG;
+  if (blockIdx.x * blockDim.x / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
   xyzz29 acc = xyzz29_identity();
   if (b < nb) {
-    uint32_t cnt = np[b], s = toff[b];
+    uint32_t cnt = d.np1[b], s = d.toff1[b];
     for (uint32_t k = l; k < cnt; k += FG) {
-      xyzz29 p = part_load(part + (size_t)(s + k) * PART_BYTES);
+      xyzz29 p = part_load(d.part1 + (size_t)(s + k) * PART_BYTES);
       xyzz29_add(acc, p);
     }
   }
-  for (uint32_t d = FG / 2; d > 0; d >>= 1) {
-    xyzz29 o = shfl_down_xyzz(acc, d);
-    if (l < d) xyzz29_add(acc, o);
+  for (uint32_t dd = FG / 2; dd > 0; dd >>= 1) {
+    xyzz29 o = shfl_down_xyzz(acc, dd);
+    if (l < dd) xyzz29_add(acc, o);
   }
-  if (b < nb && l == 0) part_store(dense + (size_t)b * PART_BYTES, acc);
+  if (b < nb && l == 0) part_store(d.dense + (size_t)b * PART_BYTES, acc);
 }
 
 // block-wide tree sum of up to 256 XYZZ values held in LDS
@@ -577,39 +603,43 @@ __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2)
 }
 
 // bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
-__global__ void __launch_bounds__(256) k_msm_rowcol(const uint8_t* dense, uint32_t logNh, uint32_t logNl, uint8_t* rc) {
+__global__ void __launch_bounds__(256) k_msm_rowcol(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
-  const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
+  const uint32_t logNl = d.logNl, Nh = 1u << d.logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  if (blk >= Nh + Nl) return;
   xyzz29 v = xyzz29_identity();
   if (blk < Nh) {
-    if (tid < Nl) v = part_load(dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
+    if (tid < Nl) v = part_load(d.dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
   } else {
-    if (tid < Nh) v = part_load(dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
+    if (tid < Nh) v = part_load(d.dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
   }
   lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, max(Nh, Nl));
-  if (tid == 0) part_store(rc + (size_t)blk * PART_BYTES, lds[0]);
+  if (tid == 0) part_store(d.rc + (size_t)blk * PART_BYTES, lds[0]);
 }
 
 // bit-decomposed weights: block beta < logNh sums rows with bit beta of hi set; block logNh + beta sums
 // columns with bit beta of (lo+1) set (beta <= logNl).
-__global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_t logNh, uint32_t logNl, uint8_t* g) {
+__global__ void __launch_bounds__(256) k_msm_weighted(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
-  const uint32_t Nh = 1u << logNh, Nl = 1u << logNl;
+  const uint32_t logNh = d.logNh, logNl = d.logNl, Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+  if (blk >= logNh + logNl + 1) return;
   xyzz29 v = xyzz29_identity();
   if (blk < logNh) {
-    if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(rc + (size_t)tid * PART_BYTES);
+    if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(d.rc + (size_t)tid * PART_BYTES);
   } else {
     uint32_t beta = blk - logNh;
-    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(rc + (size_t)(Nh + tid) * PART_BYTES);
+    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(d.rc + (size_t)(Nh + tid) * PART_BYTES);
   }
   lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, max(Nh, Nl));
-  if (tid == 0) part_store(g + (size_t)blk * PART_BYTES, lds[0]);
+  if (tid == 0) part_store(d.g + (size_t)blk * PART_BYTES, lds[0]);
 }
 
 // result = sum_beta 2^(beta + logNl) G_row[beta] + sum_beta 2^beta G_col[beta], returned as a Jacobian
@@ -618,14 +648,15 @@ __global__ void __launch_bounds__(256) k_msm_weighted(const uint8_t* rc, uint32_
 // representative (not the group element) can differ between two runs on the same input: callers compare
 // or hash after h2mi_g1_batch_normalize, exactly as the reference's callers do with best_multiexp's result;
 // h2mi_msm_set_canonical(1) trades one field inversion per MSM for reproducible bits.
-__global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t logNh, uint32_t logNl, uint8_t* out_jac, const uint32_t* off,
-                                                   uint32_t nb, uint64_t* stats, uint32_t canonical) {
+__global__ void __launch_bounds__(64) k_msm_final(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.x];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t tid = threadIdx.x;
+  const uint32_t logNh = d.logNh, logNl = d.logNl;
   const uint32_t terms = logNh + logNl + 1;
   xyzz29 v = xyzz29_identity();
   if (tid < terms) {
-    v = part_load(g + (size_t)tid * PART_BYTES);
+    v = part_load(d.g + (size_t)tid * PART_BYTES);
     uint32_t shift = tid < logNh ? tid + logNl : tid - logNh;
     for (uint32_t k = 0; k < shift; k++) v = xyzz29_dbl(v);
   }
@@ -637,7 +668,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t log
     jac j;
     if (xyzz29_is_identity(r)) {
       j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
-    } else if (canonical) {  // h2mi_msm_set_canonical(1): the representative with Z = 1
+    } else if (d.canonical) {  // h2mi_msm_set_canonical(1): the representative with Z = 1
       f29 ax, ay;
       xyzz29_to_affine(r, ax, ay);
       f29_to_mont256<Fq29>(ax, j.x.v);
@@ -648,8 +679,8 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* g, uint32_t log
       f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
       f29_to_mont256<Fq29>(r.zz, j.z.v);
     }
-    jac_store(out_jac, j);
-    if (stats) stats[0] = off[nb];
+    jac_store(d.out, j);
+    if (d.stats) d.stats[0] = d.off[d.nb];
   }
 }
 
@@ -785,9 +816,20 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   return H2MI_OK;
 }
 
-// One MSM.  On the library's own stream the call is split: sort + accumulation on `s`, the
-// latency-bound tail on the tail stream (joined by msm_join_all / h2mi_sync / the next use of the slot).
-// On a caller-provided stream everything stays on that stream.
+struct Deferred {
+  Bases* B;
+  Slot* S;
+};
+static std::vector<Deferred> g_deferred;
+static int flush_tails();
+static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
+                        hipStream_t t);
+static TailDesc tail_desc(const Bases* B, const Slot& S);
+
+// One MSM.  On the library's own stream the call is split over internal streams and only queues the
+// partition and the accumulation; the latency-bound bucket reduction is deferred to the next join
+// (msm_join_all: h2mi_join / h2mi_sync / h2mi_memcpy_d2h), a full batch, or the reuse of the slot.
+// On a caller-provided stream everything runs in order on that stream.
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   const uint32_t nb = B->nb, W = B->W;
   const uint32_t total = (uint32_t)(n * W);
@@ -795,12 +837,16 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
   B->next_slot = (B->next_slot + 1) % NSLOT;
+  if (S.tail_deferred) {  // every slot of this handle is waiting for its reduction
+    int rc = flush_tails();
+    if (rc) return rc;
+  }
   // streams: caller-provided stream => everything in order on it.  Library stream => three stages:
   //   s : partition level 1: bin count, offsets, scatter (the only readers of the caller's scalars)
   //   hs: partition level 2 (per-bin sort, bucket tables), task offsets
   //   as: accumulation                   (never blocks s: NTTs queued on s meanwhile run beside it)
-  //   ts: fold ... final                 (joined into s by h2mi_join / h2mi_sync / h2mi_memcpy_d2h)
-  hipStream_t hs = s, as = s, ts = s;
+  //   tail stream: fold ... final, batched over the MSMs since the last join (flush_tails)
+  hipStream_t hs = s, as = s;
   const uint32_t s0 = pick_chunk(total);
   uint32_t ls0 = 0;
   while ((1u << ls0) < s0) ls0++;
@@ -811,7 +857,6 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   if (pipelined) {
     hs = ctx().head_stream;
     as = ctx().accum_stream;
-    ts = ctx().tail_stream;
     // the first partition level (count, scan, scatter) is the only reader of the caller's scalars and stays
     // on s.  It writes bincnt/binbase/bkeys/vals[0], last read by this slot's previous k_msm_bin_sort.
     if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
@@ -902,34 +947,87 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
             (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
-  hipStream_t t = ts;
+  S.d_out = d_out;
+  S.tasks1 = tasks0 / S1 + nb;
   if (pipelined) {
+    // the bucket reduction is deferred: flush_tails() runs it for every MSM queued since the last join
     H2_HIP(hipEventRecord(S.accum_done, as));
-    H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
     S.accum_pending = true;
+    S.tail_deferred = true;
+    g_deferred.push_back({B, &S});
+    static const bool eager = getenv("H2MI_MSM_EAGER_TAIL") != nullptr;  // A/B: one reduction per MSM, at once
+    if (eager || g_deferred.size() >= TAIL_BATCH) return flush_tails();
+    return H2MI_OK;
   }
-  // one fold level (<= S1 partials per task: part[0] -> part[1]), then FG lanes per bucket finish into the
-  // dense array.  A bucket holding m points leaves ceil(m / (s0 * S1)) partials for the finish kernel: 1 in
-  // the uniform case at k = 20, <= ~50 for the hot 0/1 buckets of witness-like columns (7 serial additions
-  // per lane), n / (s0 * S1) if every scalar is the same (slow but correct).
-  uint32_t tasks1 = tasks0 / S1 + nb;
-  H2_LAUNCH("k_msm_fold", k_msm_fold, ceil_div_u32(tasks1, 256), 256, 0, t, (const uint8_t*)S.part[0], (const uint32_t*)S.toff[0],
-            (const uint32_t*)S.np[0], (const uint32_t*)S.toff[1], nb, S.part[1]);
-  H2_LAUNCH("k_msm_finish", k_msm_finish, ceil_div_u32((uint64_t)nb * FG, 256), 256, 0, t, (const uint8_t*)S.part[1], (const uint32_t*)S.toff[1],
-            (const uint32_t*)S.np[1], nb, S.dense);
-  // weighted bucket sum
-  const uint32_t Nh = 1u << B->logNh, Nl = 1u << B->logNl;
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, Nh + Nl, 256, 256 * PART_BYTES, t, (const uint8_t*)S.dense, B->logNh, B->logNl, S.rc);
-  H2_LAUNCH("k_msm_weighted", k_msm_weighted, B->logNh + B->logNl + 1, 256, 256 * PART_BYTES, t, (const uint8_t*)S.rc, B->logNh, B->logNl, S.g);
-  H2_LAUNCH("k_msm_final", k_msm_final, 1, 64, 64 * PART_BYTES, t, (const uint8_t*)S.g, B->logNh, B->logNl, (uint8_t*)d_out, (const uint32_t*)S.off,
-            nb, S.stats, g_canonical ? 1u : 0u);
-  H2_HIP(hipEventRecord(S.tail_done, t));
+  TailBatch tb;
+  for (uint32_t j = 0; j < TAIL_BATCH; j++) tb.d[j] = tail_desc(B, S);
+  int rc = launch_tails(tb, 1, S.tasks1, nb, B->logNh, B->logNl, s);
+  if (rc) return rc;
+  H2_HIP(hipEventRecord(S.tail_done, s));
   S.tail_pending = true;
   return H2MI_OK;
 }
 
-// make stream `s` wait for every outstanding MSM tail (device-side join, no host synchronisation)
+// one fold level (<= S1 partials per task: part[0] -> part[1]), then FG lanes per bucket finish into the
+// dense array.  A bucket holding m points leaves ceil(m / (s0 * S1)) partials for the finish kernel: 1 in
+// the uniform case at k = 20, <= ~50 for the hot 0/1 buckets of witness-like columns (7 serial additions
+// per lane), n / (s0 * S1) if every scalar is the same (slow but correct).  Then the weighted bucket sum.
+static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
+                        hipStream_t t) {
+  H2_LAUNCH("k_msm_fold", k_msm_fold, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
+  H2_LAUNCH("k_msm_finish", k_msm_finish, dim3(ceil_div_u32((uint64_t)max_nb * FG, 256), count), 256, 0, t, tb);
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3((1u << max_logNh) + (1u << max_logNl), count), 256, 256 * PART_BYTES, t, tb);
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1, count), 256, 256 * PART_BYTES, t, tb);
+  H2_LAUNCH("k_msm_final", k_msm_final, count, 64, 64 * PART_BYTES, t, tb);
+  return H2MI_OK;
+}
+
+static TailDesc tail_desc(const Bases* B, const Slot& S) {
+  TailDesc d;
+  d.part0 = S.part[0];
+  d.toff0 = S.toff[0]; d.np0 = S.np[0]; d.toff1 = S.toff[1]; d.np1 = S.np[1]; d.off = S.off;
+  d.part1 = S.part[1]; d.dense = S.dense; d.rc = S.rc; d.g = S.g; d.out = (uint8_t*)S.d_out;
+  d.stats = S.stats;
+  d.nb = B->nb; d.logNh = B->logNh; d.logNl = B->logNl; d.canonical = g_canonical ? 1u : 0u;
+  return d;
+}
+
+// launch the deferred bucket reductions (all handles) as batches on the tail stream
+static int flush_tails() {
+  hipStream_t t = ctx().tail_stream;
+  size_t i = 0;
+  while (i < g_deferred.size()) {
+    TailBatch tb;
+    uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0;
+    const size_t first = i;
+    for (; i < g_deferred.size() && count < TAIL_BATCH; i++, count++) {
+      Bases* B = g_deferred[i].B;
+      Slot& S = *g_deferred[i].S;
+      H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
+      tb.d[count] = tail_desc(B, S);
+      max_tasks1 = std::max(max_tasks1, S.tasks1);
+      max_nb = std::max(max_nb, B->nb);
+      max_logNh = std::max(max_logNh, B->logNh);
+      max_logNl = std::max(max_logNl, B->logNl);
+    }
+    for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
+    int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, t);
+    if (rc) return rc;
+    for (size_t j = first; j < i; j++) {
+      Slot& S = *g_deferred[j].S;
+      H2_HIP(hipEventRecord(S.tail_done, t));
+      S.tail_pending = true;
+      S.tail_deferred = false;
+    }
+  }
+  g_deferred.clear();
+  return H2MI_OK;
+}
+
+// make stream `s` wait for every outstanding MSM (device-side join, no host synchronisation)
 int msm_join_all(hipStream_t s) {
+  int rc = flush_tails();
+  if (rc) return rc;
   for (auto& kv : g_bases)
     for (Slot& S : kv.second->slot)
       if (S.tail_pending) {
@@ -973,6 +1071,7 @@ int h2mi_bases_release(uint64_t handle) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
+  flush_tails();
   hipDeviceSynchronize();
   free_bases(it->second);
   g_bases.erase(it);
@@ -1052,6 +1151,10 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   Bases* B = it->second;
+  {
+    int rc = flush_tails();
+    if (rc) return rc;
+  }
   H2_HIP(hipDeviceSynchronize());
   uint64_t st = 0;
   H2_HIP(hipMemcpy(&st, B->slot[B->last_slot].stats, 8, hipMemcpyDeviceToHost));
