@@ -152,48 +152,53 @@ class ProofReplay:
     def step(self, phase_joins: bool = True):
         """one proof's worth of hot-path work, queued on the library streams (asynchronous).
 
-        The order follows create_proof.  Where the real prover must hash commitments into
-        the transcript before it can continue (challenges theta, beta/gamma, y, x, u), the replay joins the
-        MSM pipeline (`h2mi_join`), so no overlap is claimed that a prover could not have."""
+        The commitments follow create_proof's order.  Where the real prover must hash
+        commitments into the transcript before it can continue (challenges theta, beta/gamma, y, x, u), the
+        replay joins the MSM pipeline (`h2mi_join`), so no overlap is claimed that a prover could not have;
+        a column's transforms are queued as soon as the column exists (see below)."""
         sh, d, n = self.shape, self.domain, self.n
         join = (lambda: check(lib.h2mi_join(), "join")) if phase_joins else (lambda: None)
         self._slot = 0
         self._leaf = -1
+        # buffers are handed out in create_proof's order of use (instance, permutation products, advice, lookups)
         w_it, e_it = iter(self.work), iter(self.ext)
-        # phase 1: instance columns (KZG: hashed, not committed): lagrange_to_coeff (+ extended below)
         inst_we = [(c, next(w_it), next(e_it)) for c in self.instance]
-        # phase 2: advice commitments (Lagrange basis) -> challenge theta
+        perm_we = [(c, next(w_it), next(e_it)) for c in self.perm_z]
+        adv_we = [(c, next(w_it), next(e_it)) for c in self.advice]
+        look_we = [(c, next(w_it), next(e_it)) for c in self.lookup]
+        first_adv_w = adv_we[0][1]
+        # The transforms of a column depend on that column only, not on the challenges, so they are queued as
+        # soon as the column exists — before the join that follows its commitment — and run while the batched
+        # bucket reductions of that phase (latency-bound, on the tail stream) finish.  create_proof itself runs
+        # them later (inside evaluate_h's preparation); the data dependencies are the same.
+        # phase 2: advice commitments (Lagrange basis) -> challenge theta; their coefficient / extended forms
         for c in self.advice:
             self._msm(c, lagrange=True)
+        for i, (c, w, e) in enumerate(adv_we):
+            self._to_coeff_and_extended(c, w, e, coeff_needed=i == 0 or w is self.work[0])
         join()
         # phase 3: lookups: commit permuted input / table columns -> challenges beta, gamma
         for i in range(sh.n_lookups):
             self._msm(self.lookup[3 * i], lagrange=True)
             self._msm(self.lookup[3 * i + 1], lagrange=True)
+        for j, (c, w, e) in enumerate(look_we):
+            if j % 3 != 2:  # the permuted input / table columns; the product column exists only after beta, gamma
+                self._to_coeff_and_extended(c, w, e)
         if sh.n_lookups:
             join()
         # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per chunk
-        for c in self.perm_z:
+        for c, w, e in perm_we:
             self._msm(c, lagrange=True)
-            w = next(w_it)
-            self._to_coeff_and_extended(c, w, next(e_it), coeff_needed=w is self.work[0])
+            self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
         # phase 5: lookup products
         for i in range(sh.n_lookups):
             self._msm(self.lookup[3 * i + 2], lagrange=True)
-        # phase 6: random polynomial commitment (coefficient basis) -> challenge y
+            self._to_coeff_and_extended(*look_we[3 * i + 2])
+        # phase 6: random polynomial commitment (coefficient basis) -> challenge y; instance columns
         self._msm(self.random_poly, lagrange=False)
-        join()
-        # phase 7: advice / instance / lookup polynomials to coefficient and extended form (evaluate_h inputs)
-        first_adv_w = None
-        for c in self.advice:
-            w = next(w_it)
-            first = first_adv_w is None
-            first_adv_w = first_adv_w or w
-            self._to_coeff_and_extended(c, w, next(e_it), coeff_needed=first or w is self.work[0])
         for c, w, e in inst_we:
             self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
-        for c in self.lookup:
-            self._to_coeff_and_extended(c, next(w_it), next(e_it))
+        join()
         # phase 8: h(X) back to coefficients, split into degree-1 pieces of n, commit each -> challenge x
         if self.with_evaluate_h:
             from . import plonk as gp
