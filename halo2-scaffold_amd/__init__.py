@@ -7,6 +7,7 @@ reaches through ``create_proof`` (reference examples/standard_plonk.rs:41-49, sr
   domain.EvaluationDomain                  halo2_proofs::poly::EvaluationDomain
   params.ParamsKZG                         halo2_proofs::poly::kzg::commitment::ParamsKZG
   replay.StandardPlonkReplay               the MSM/NTT sequence one StandardPlonk proof issues
+  transcript.Blake2bWrite / Blake2bRead    halo2_proofs::transcript (Challenge255), serde: to_repr / to_bytes
 
 All arithmetic runs in hand-written HIP kernels; there is no CPU fallback — importing this package
 without a built ``libh2mi.so`` raises, and compute calls without a GPU return H2MI_ENODEV.
@@ -19,3 +20,4 @@ from .device import DevBuf  # noqa: F401
 from .arithmetic import best_fft, best_multiexp, eval_polynomial, kate_division, lincomb  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .params import ParamsKZG  # noqa: F401
+from . import serde, transcript  # noqa: F401

@@ -48,6 +48,12 @@ def _load():
         "h2mi_msm_bn254_g1_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),
         "h2mi_msm_set_canonical": ([C.c_int], C.c_int),
+        "h2mi_fe_to_repr_dev": ([C.c_int, vp, sz, vp, vp], C.c_int),
+        "h2mi_fe_from_repr_dev": ([C.c_int, vp, sz, vp, u64p], C.c_int),
+        "h2mi_g1_compress_dev": ([vp, sz, vp, vp], C.c_int),
+        "h2mi_g1_decompress_dev": ([vp, sz, vp, u64p], C.c_int),
+        "h2mi_g1_compress": ([vp, sz, vp], C.c_int),
+        "h2mi_g1_decompress": ([vp, sz, vp, u64p], C.c_int),
         "h2mi_g1_sum_jacobian": ([vp, sz, vp], C.c_int),
         "h2mi_g1_fold_groups": ([vp, sz, sz, vp], C.c_int),
         "h2mi_g1_batch_normalize": ([vp, sz, vp], C.c_int),

@@ -143,14 +143,6 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const fe* scalars, size_
 
 static uint8_t* g_fixed_table = nullptr;
 
-// device allocation released on every exit path of the synchronous helper entry points
-struct DevMem {
-  void* p = nullptr;
-  ~DevMem() { if (p) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
 }  // namespace h2
 
 using namespace h2;

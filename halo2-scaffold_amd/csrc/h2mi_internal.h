@@ -70,6 +70,14 @@ inline bool prof_on(const char* name) {
     H2_HIP(hipGetLastError());                                                         \
   } while (0)
 
+// device allocation released on every exit path of the synchronous helper entry points
+struct DevMem {
+  void* p = nullptr;
+  ~DevMem() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // h2mi_msm.hip: make `s` wait for all outstanding MSM tails
 int msm_join_all(hipStream_t s);
 

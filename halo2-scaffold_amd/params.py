@@ -7,10 +7,13 @@ all computed by the device kernels and kept registered in HBM.  commit / commit_
 best_multiexp against the matching base set (KZG ignores the blind).
 """
 import ctypes as C
+import struct
 
 import numpy as np
 
 from . import field as F
+from . import g2 as G2
+from . import serde
 from ._lib import check, lib
 from .device import DevBuf
 
@@ -23,11 +26,15 @@ class ParamsKZG:
         self.g_lagrange_handle = None
         self._g_dev = None
         self._gl_dev = None
+        self.g2_bytes = None    # the verifier's two G2 elements, carried as their 64-byte encodings
+        self.s_g2_bytes = None
 
     @classmethod
     def setup(cls, k: int, s: int) -> "ParamsKZG":
         p = cls(k)
         n = p.n
+        p.g2_bytes = G2.to_bytes(G2.G2_GENERATOR)
+        p.s_g2_bytes = G2.to_bytes(G2.scalar_mul(s))
         s_m = F.fr_to_mont_limbs(s)
         pw = DevBuf(n * 32)
         check(lib.h2mi_fr_powers_dev(pw.ptr, n, s_m.ctypes.data, None), "powers")
@@ -62,6 +69,46 @@ class ParamsKZG:
             h2 = C.c_uint64()
             check(lib.h2mi_bases_register_dev(self._gl_dev.ptr, self.n, C.byref(h2)), "register g_lagrange")
             self.g_lagrange_handle = h2.value
+
+    # ---- ParamsKZG::write / read: k (u32 LE), g, g_lagrange (32-byte compressed points), g2, s_g2 ----
+    # [RECALL poly/kzg/commitment.rs of v2023_02_02; the file the scaffold caches as params/kzg_bn254_{k}.srs]
+    def write(self, writer) -> None:
+        if self.g2_bytes is None or self._gl_dev is None:
+            raise ValueError("write needs the full SRS (g, g_lagrange, g2, s_g2)")
+        writer.write(struct.pack("<I", self.k))
+        tmp = DevBuf(self.n * 32)
+        for dev in (self._g_dev, self._gl_dev):
+            serde.g1_to_bytes_dev(dev, self.n, tmp)
+            writer.write(tmp.to_numpy(shape=(self.n, 4)).tobytes())
+        tmp.free()
+        writer.write(self.g2_bytes)
+        writer.write(self.s_g2_bytes)
+
+    @classmethod
+    def read(cls, reader) -> "ParamsKZG":
+        head = reader.read(4)
+        if len(head) != 4:
+            raise serde.DecodeError("SRS file too short")
+        (k,) = struct.unpack("<I", head)
+        if not 1 <= k <= 26:
+            raise serde.DecodeError(f"implausible k = {k} in SRS file")
+        p = cls(k)
+        n = p.n
+        tmp = DevBuf(n * 32)
+        devs = []
+        for _ in range(2):
+            raw = reader.read(n * 32)
+            if len(raw) != n * 32:
+                raise serde.DecodeError("SRS file too short")
+            tmp.upload(np.frombuffer(raw, dtype=np.uint64))
+            devs.append(serde.g1_from_bytes_dev(tmp, n))
+        tmp.free()
+        p._g_dev, p._gl_dev = devs
+        p.g2_bytes, p.s_g2_bytes = reader.read(64), reader.read(64)
+        if len(p.g2_bytes) != 64 or len(p.s_g2_bytes) != 64:
+            raise serde.DecodeError("SRS file too short")
+        p._register()
+        return p
 
     def get_g(self) -> np.ndarray:
         return self._g_dev.to_numpy(shape=(self.n, 8))

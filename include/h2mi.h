@@ -160,6 +160,20 @@ int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affi
 /* out[i] = base^i for i < n (the powers-of-s vector of ParamsKZG::setup), Montgomery in and out */
 int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_stream_t stream);
 
+/* ---- wire encodings: what create_proof writes to the transcript and what
+ * ParamsKZG::{write,read} keep on disk.  Conventions restated from halo2curves 0.3.x [RECALL, see
+ * csrc/h2mi_serde.hip]: field elements as 32 little-endian canonical bytes (Fr::to_repr); G1Affine as 32
+ * bytes = x with flags in byte 31 (0x40: y odd, 0x80: point at infinity).  field: 0 = Fq, 1 = Fr.
+ * The *_from_* / decompress forms report the number of invalid encodings (>= modulus, not on the curve,
+ * inconsistent flags) through invalid_out — such entries decode to zero / the identity — and synchronise. */
+int h2mi_fe_to_repr_dev(int field, const void* d_in, size_t n, void* d_out32, h2mi_stream_t stream);
+int h2mi_fe_from_repr_dev(int field, const void* d_in32, size_t n, void* d_out, uint64_t* invalid_out);
+int h2mi_g1_compress_dev(const void* d_affine, size_t n, void* d_out32, h2mi_stream_t stream);
+int h2mi_g1_decompress_dev(const void* d_in32, size_t n, void* d_affine_out, uint64_t* invalid_out);
+/* host-pointer forms (synchronous): G1Affine::to_bytes / from_bytes over n points */
+int h2mi_g1_compress(const uint64_t* affine /* n*8 */, size_t n, uint8_t* out32 /* n*32 */);
+int h2mi_g1_decompress(const uint8_t* in32 /* n*32 */, size_t n, uint64_t* affine_out /* n*8 */, uint64_t* invalid_out);
+
 /* ---- profiling: per-kernel device time measured with HIP events on the launching stream ---------- */
 int h2mi_profile_enable(int on);         /* 1 = record events around every kernel launch */
 /* restrict event recording to kernels whose name starts with `prefix` (NULL or "" = all kernels) */

@@ -14,7 +14,10 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <istream>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -318,6 +321,7 @@ class ParamsKZG {
   ParamsKZG(ParamsKZG&& o) noexcept { *this = std::move(o); }
   ParamsKZG& operator=(ParamsKZG&& o) noexcept {
     k_ = o.k_; n_ = o.n_; d_g_ = o.d_g_; d_gl_ = o.d_gl_; h_g_ = o.h_g_; h_gl_ = o.h_gl_;
+    g2_ = o.g2_; s_g2_ = o.s_g2_; have_g2_ = o.have_g2_;
     o.d_g_ = o.d_gl_ = nullptr; o.h_g_ = o.h_gl_ = 0;
     return *this;
   }
@@ -334,6 +338,59 @@ class ParamsKZG {
   // commit / commit_lagrange: best_multiexp against the matching base set (KZG ignores the blind)
   G1 commit(const std::vector<Fr>& poly) const { return msm(h_g_, poly); }
   G1 commit_lagrange(const std::vector<Fr>& poly) const { return msm(h_gl_, poly); }
+
+  // ParamsKZG::write / read [RECALL poly/kzg/commitment.rs of v2023_02_02; the file the scaffold caches as
+  // params/kzg_bn254_{k}.srs]: k as u32 LE, g then g_lagrange as 32-byte compressed points, g2, s_g2 (64-byte
+  // compressed G2).  The prover never uses the two G2 elements; they are carried as opaque bytes (set_g2 after
+  // setup — the one G2 scalar multiplication is the Python host's or the ceremony's job — or taken from `read`).
+  typedef std::array<uint8_t, 64> G2Bytes;
+  void set_g2(const G2Bytes& g2, const G2Bytes& s_g2) { g2_ = g2; s_g2_ = s_g2; have_g2_ = true; }
+  void write(std::ostream& w) const {
+    if (!have_g2_) throw Error(H2MI_EINVAL, "ParamsKZG::write: g2 / s_g2 not set");
+    const uint32_t k32 = k_;  // little-endian host
+    w.write(reinterpret_cast<const char*>(&k32), 4);
+    void* tmp = nullptr;
+    check(h2mi_malloc(n_ * 32, &tmp), "h2mi_malloc");
+    std::vector<char> host(n_ * 32);
+    for (void* d : {d_g_, d_gl_}) {
+      int rc = h2mi_g1_compress_dev(d, n_, tmp, nullptr);
+      if (!rc) rc = h2mi_memcpy_d2h(host.data(), tmp, n_ * 32);
+      if (rc) { h2mi_free(tmp); check(rc, "ParamsKZG::write"); }
+      w.write(host.data(), (std::streamsize)host.size());
+    }
+    h2mi_free(tmp);
+    w.write(reinterpret_cast<const char*>(g2_.data()), 64);
+    w.write(reinterpret_cast<const char*>(s_g2_.data()), 64);
+  }
+  static ParamsKZG read(std::istream& r) {
+    uint32_t k32 = 0;
+    r.read(reinterpret_cast<char*>(&k32), 4);
+    if (!r || k32 < 1 || k32 > 26) throw Error(H2MI_EINVAL, "ParamsKZG::read: bad header");
+    ParamsKZG p(k32);
+    const size_t n = p.n_;
+    void* tmp = nullptr;
+    check(h2mi_malloc(n * 32, &tmp), "h2mi_malloc");
+    std::vector<char> host(n * 32);
+    void** dst[2] = {&p.d_g_, &p.d_gl_};
+    for (int i = 0; i < 2; i++) {
+      r.read(host.data(), (std::streamsize)host.size());
+      uint64_t bad = 0;
+      int rc = r ? H2MI_OK : H2MI_EINVAL;
+      if (!rc) rc = h2mi_malloc(n * 64, dst[i]);
+      if (!rc) rc = h2mi_memcpy_h2d(tmp, host.data(), n * 32);
+      if (!rc) rc = h2mi_g1_decompress_dev(tmp, n, *dst[i], &bad);
+      if (!rc && bad) rc = H2MI_EINVAL;
+      if (rc) { h2mi_free(tmp); check(rc, "ParamsKZG::read: truncated file or invalid point"); }
+    }
+    h2mi_free(tmp);
+    r.read(reinterpret_cast<char*>(p.g2_.data()), 64);
+    r.read(reinterpret_cast<char*>(p.s_g2_.data()), 64);
+    if (!r) throw Error(H2MI_EINVAL, "ParamsKZG::read: truncated file");
+    p.have_g2_ = true;
+    check(h2mi_bases_register_dev(p.d_g_, n, &p.h_g_), "register g");
+    check(h2mi_bases_register_dev(p.d_gl_, n, &p.h_gl_), "register g_lagrange");
+    return p;
+  }
 
  private:
   explicit ParamsKZG(uint32_t k) : k_(k), n_((uint64_t)1 << k) {}
@@ -352,6 +409,8 @@ class ParamsKZG {
   uint64_t n_ = 0;
   void *d_g_ = nullptr, *d_gl_ = nullptr;
   uint64_t h_g_ = 0, h_gl_ = 0;
+  G2Bytes g2_{}, s_g2_{};
+  bool have_g2_ = false;
 };
 }  // namespace kzg
 }  // namespace poly

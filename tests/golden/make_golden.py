@@ -24,6 +24,35 @@ def pt(p):
     return None if p is None else [hx(p[0]), hx(p[1])]
 
 
+def formats_vectors():
+    """wire formats (oracle/formats.py): encodings of a few points, a transcript run, the SRS file of (k=3, s=5)."""
+    import hashlib
+
+    from oracle import formats as fm
+
+    pts = [o.g1_mul(k, o.G1_GEN) for k in (1, 2, 3, 0x1234567, o.R - 1)]
+    scal = [0, 1, 0xDEADBEEF, o.R - 1]
+    t = fm.Blake2bTranscript()
+    ch = []
+    for p in pts:
+        t.write_point(p)
+    ch.append(t.squeeze_challenge())
+    for v in scal:
+        t.write_scalar(v)
+    ch.append(t.squeeze_challenge())
+    ch.append(t.squeeze_challenge())
+    return {
+        "points": [pt(p) for p in pts],
+        "compressed": [fm.g1_to_bytes(p).hex() for p in pts] + [fm.g1_to_bytes(None).hex()],
+        "scalars": [hx(v) for v in scal],
+        "transcript_proof": bytes(t.proof).hex(),
+        "transcript_challenges": [hx(c) for c in ch],
+        "g2_generator": fm.g2_to_bytes(fm.G2_GEN).hex(),
+        "srs_k3_s5_sha256": hashlib.sha256(fm.srs_bytes(3, 5)).hexdigest(),
+        "srs_k3_s5_tail": fm.srs_bytes(3, 5)[-64:].hex(),
+    }
+
+
 def replay_commitments(k):
     """BASELINE config 0/1 (standard_plonk, plumbing size): the 11 commitments of the hot-path replay at 2^k rows,
     computed entirely on the CPU (big-integer SRS scalars, C restatement of best_multiexp for the sums).
@@ -98,6 +127,7 @@ def main():
     d = o.Domain(3, 3)
     out["domain"] = {"k": 3, "j": 3, "extended_k": d.extended_k, "coeff_to_extended": [hx(x) for x in d.coeff_to_extended(coeffs)]}
     out["replay_k8"] = replay_commitments(8)
+    out["formats"] = formats_vectors()
     with open(os.path.join(HERE, "bn254_vectors.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(HERE, "bn254_vectors.json"))
