@@ -60,6 +60,7 @@ struct PassParams {
   const fe* plo;  // pre-scale tables (first pass only) or null      (Mont261)
   const fe* phi;
   uint32_t ph;
+  uint32_t tfull, pfull;  // the twiddle / pre-scale table holds every power: fetch instead of hi * lo
   int has_post;
   fe post;        // Mont256 (as passed by the caller)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
@@ -126,11 +127,16 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
         }
         f29 a0 = f29_add(x0, t1), a1 = f29_sub(x0, t1, F9::K2);
         f29 a2 = f29_add(x2, t3), a3 = f29_sub(x2, t3, F9::K2);
-        f29 u2 = f29_mul<F9>(a2, f29_unpack(tw[pos << (m - 2 - s)].v));
         f29 u3 = f29_mul<F9>(a3, f29_unpack(tw[(pos + h) << (m - 2 - s)].v));
-        lds_put(lds, dstride, i, f29_normalize(f29_add(a0, u2)));
+        if (s == 0) {  // pos = 0: the twiddle of (a0, a2) is omega^0 — no multiplication; a2 = x2 + x3 < 4p, limbs < 2^30
+          lds_put(lds, dstride, i, f29_normalize(f29_add(a0, a2)));
+          lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, a2, F9::KW4)));
+        } else {
+          f29 u2 = f29_mul<F9>(a2, f29_unpack(tw[pos << (m - 2 - s)].v));
+          lds_put(lds, dstride, i, f29_normalize(f29_add(a0, u2)));
+          lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, u2, F9::K2)));
+        }
         lds_put(lds, dstride, i + h, f29_normalize(f29_add(a1, u3)));
-        lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, u2, F9::K2)));
         lds_put(lds, dstride, i + 3 * h, f29_normalize(f29_sub(a1, u3, F9::K2)));
       }
       __syncthreads();
@@ -157,6 +163,9 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
 __device__ __forceinline__ f29 pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {  // Mont261
   return f29_mul<F9>(load_unpack(&hi[e >> h]), load_unpack(&lo[e & ((1u << h) - 1)]));
 }
+__device__ __forceinline__ f29 powtab(const fe* lo, const fe* hi, uint32_t h, uint32_t full, uint32_t e) {
+  return full ? load_unpack(&lo[e]) : pow2tab(lo, hi, h, e);
+}
 
 extern __shared__ uint32_t h2_smem[];
 
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
     uint32_t c = o & (C - 1), e = o >> logC;
     size_t idx = base + ((size_t)e << logS) + jl0 + c;
     f29 x = load_unpack(&p.in[idx]);
-    if (p.plo) x = f29_mul<F9>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
   for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
@@ -189,7 +198,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
     uint32_t c = o & (C - 1), k = o >> logC;
     f29 x = lds_get(lds, dstride, (c << m) | k);
     uint32_t ex = ((jl0 + c) * k) << sh;  // < n
-    x = f29_mul<F9>(x, pow2tab(p.tlo, p.thi, p.h, ex));
+    x = f29_mul<F9>(x, powtab(p.tlo, p.thi, p.h, p.tfull, ex));
     pack_store(&p.out[base + ((size_t)k << logS) + jl0 + c], x);
   }
 }
@@ -210,20 +219,25 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
     size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
     size_t idx = (rho << m) + e;
     f29 x = load_unpack(&p.in[idx]);
-    if (p.plo) x = f29_mul<F9>(x, pow2tab(p.plo, p.phi, p.ph, (uint32_t)idx));
+    if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
   if (m) for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
   __syncthreads();
   local_ntt(lds, dstride, tw, m, logC);
-  // the closing multiplication also brings the lazily accumulated value back below 2p:
-  // by the caller's post-scale (Mont256 -> Mont261 first) or by the Montgomery one
-  f29 fin = p.has_post ? f29_from_mont256<F9>(p.post.v) : f29_const<F9>(F9::ONE);
+  // the caller's post-scale (Mont256 -> Mont261 first) also brings the lazily accumulated value back below 2p
+  f29 fin = p.has_post ? f29_from_mont256<F9>(p.post.v) : f29_zero();
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
-    f29 x = f29_mul<F9>(lds_get(lds, dstride, (c << m) | k), fin);
+    f29 x = lds_get(lds, dstride, (c << m) | k);
     size_t oidx = (size_t)(k1_0 + c) + ((size_t)k2 << p.logN1) + ((size_t)k << (p.logN1 + p.logN2));
-    pack_store(&p.out[oidx], x);
+    if (p.has_post) {
+      pack_store(&p.out[oidx], f29_mul<F9>(x, fin));
+    } else {  // m/2 lazy rounds leave a value below (2 + 6 * ceil(m/2)) p <= 32p: reduce it directly
+      fe o_;
+      f29_pack(f29_reduce_loose<F9>(x), o_.v);
+      fe_store(&p.out[oidx], o_);
+    }
   }
 }
 
@@ -431,15 +445,19 @@ __global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c
 struct Key {
   uint64_t w[4];
   uint32_t log_n;
+  bool full = false;
   bool operator<(const Key& o) const {
     if (log_n != o.log_n) return log_n < o.log_n;
+    if (full != o.full) return full < o.full;
     return memcmp(w, o.w, 32) < 0;
   }
 };
-struct PowTab {  // base^i split as hi/lo for i < 2^log_n
+struct PowTab {  // base^i split as hi/lo for i < 2^log_n; full: lo holds every power (h = log_n, hi = {1})
   fe* lo = nullptr;
   fe* hi = nullptr;
   uint32_t h = 0;
+  bool full = false;
+  size_t bytes = 0;
 };
 struct Plan {
   int P = 0;
@@ -464,22 +482,29 @@ static fe host_fe(const uint64_t w[4]) {
   return r;
 }
 
-static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, PowTab* out) {
+// `full`: one table entry per power (32 B x 2^log_n) so that a kernel fetches base^e instead of multiplying
+// two table entries: for the bases that live as long as a domain (omega, the coset generator), up to 2^22.
+constexpr uint32_t FULL_TABLE_MAX_LOG = 22;
+static size_t g_powtab_bytes = 0;
+static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, PowTab* out, bool full = false) {
+  full = full && log_n <= FULL_TABLE_MAX_LOG && !getenv("H2MI_NTT_NO_FULL_TABLES");
   Key k;
   memcpy(k.w, base, 32);
   k.log_n = log_n;
+  k.full = full;
   auto it = g_powtabs.find(k);
   if (it != g_powtabs.end()) {
     *out = it->second;
     return H2MI_OK;
   }
-  if (g_powtabs.size() > 64) {  // bounded cache: drop everything (tables are tiny and cheap to rebuild)
+  if (g_powtabs.size() > 64 || g_powtab_bytes > ((size_t)3 << 30)) {  // bounded cache: drop everything (cheap to rebuild)
     H2_HIP(hipStreamSynchronize(s));
     for (auto& kv : g_powtabs) {
       hipFree(kv.second.lo);
       hipFree(kv.second.hi);
     }
     g_powtabs.clear();
+    g_powtab_bytes = 0;
     for (auto& kv : g_plans)
       for (int i = 0; i < 3; i++) {
         fe* p = kv.second.loc[i];
@@ -491,8 +516,11 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
     g_plans.clear();
   }
   PowTab t;
-  t.h = (log_n + 1) / 2;
+  t.full = full;
+  t.h = full ? log_n : (log_n + 1) / 2;
   uint32_t nlo = 1u << t.h, nhi = 1u << (log_n - t.h);
+  t.bytes = ((size_t)nlo + nhi) * 32;
+  g_powtab_bytes += t.bytes;
   H2_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
   H2_HIP(hipMalloc(&t.hi, (size_t)nhi * 32));
   fe b = host_fe(base);
@@ -531,7 +559,7 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
   }
   Plan pl;
   choose_split(log_n, &pl);
-  int rc = get_powtab(omega, log_n, s, &pl.tw);
+  int rc = get_powtab(omega, log_n, s, &pl.tw, /*full=*/pl.P > 1);  // single-pass sizes have no inter-pass twiddles
   if (rc) return rc;
   fe w = host_fe(omega);
   for (int p = 0; p < pl.P; p++) {
@@ -588,7 +616,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
   if (rc) return rc;
   PowTab pt;
   if (pre) {
-    rc = get_powtab(pre, log_n, s, &pt);
+    rc = get_powtab(pre, log_n, s, &pt, /*full=*/true);
     if (rc) return rc;
   }
   const size_t n = (size_t)1 << log_n;
@@ -621,11 +649,13 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     pp.tlo = pl.tw.lo;
     pp.thi = pl.tw.hi;
     pp.h = pl.tw.h;
+    pp.tfull = pl.tw.full;
     pp.remap = remap;
     if (p == 0 && pre) {
       pp.plo = pt.lo;
       pp.phi = pt.hi;
       pp.ph = pt.h;
+      pp.pfull = pt.full;
     }
     uint32_t logC = pp.m >= tile_elems_log ? 0 : tile_elems_log - pp.m;
     if (!last) {

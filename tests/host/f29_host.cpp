@@ -43,6 +43,16 @@ void f29t_mul(int field, int mode, const uint32_t* a, const uint32_t* b, uint32_
   else mul_words<Fr29>(a, b, out, n, mode);
 }
 
+// f29_reduce_loose on raw normalized 9-limb values (value < 64p): in 9 words, out 9 words per element
+void f29t_reduce_loose(int field, const uint32_t* in, uint32_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    f29 x, r;
+    for (int k = 0; k < 9; k++) x.v[k] = in[9 * i + k];
+    r = field == 0 ? f29_reduce_loose<Fq29>(x) : f29_reduce_loose<Fr29>(x);
+    for (int k = 0; k < 9; k++) out[9 * i + k] = r.v[k];
+  }
+}
+
 // accumulate n affine points (Mont256, 16 words each; (0,0) skipped) with signs[i] != 0 meaning -P_i;
 // writes the XYZZ result as 4 x 8 words Mont256 (canonical)
 void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz, int tree) {

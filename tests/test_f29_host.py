@@ -60,6 +60,23 @@ def test_f29_mul_modes(host, field, mod):
     assert all(v < mod for v in o.unpack(out))
 
 
+@pytest.mark.parametrize("field,mod", [(0, o.Q), (1, o.R)])
+def test_reduce_loose(host, field, mod):
+    """the multiplication-free final reduction of the NTT: any normalized value below 64p -> canonical."""
+    rng = np.random.default_rng(11 + field)
+    vals = [0, 1, mod - 1, mod, mod + 1, 2 * mod - 1, 2 * mod, 3 * mod - 1, 3 * mod, 31 * mod + 5, 64 * mod - 1, 63 * mod, (1 << 232) - 1, 1 << 232]
+    vals += [k * mod + d for k in range(0, 64, 7) for d in (0, 1, mod - 1)]
+    vals += [int.from_bytes(rng.bytes(33), "little") % (64 * mod) for _ in range(20000)]
+    n = len(vals)
+    limbs = np.array([[(v >> (29 * i)) & ((1 << 29) - 1) if i < 8 else v >> 232 for i in range(9)] for v in vals], dtype=np.uint32)
+    out = np.zeros_like(limbs)
+    host.f29t_reduce_loose.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    host.f29t_reduce_loose(field, limbs.ctypes.data, out.ctypes.data, n)
+    got = [sum(int(out[j, i]) << (29 * i) for i in range(9)) for j in range(n)]
+    assert got == [v % mod for v in vals]
+    assert (out[:, :8] < (1 << 29)).all()
+
+
 def _xyzz_to_affine(out):
     X, Y, ZZ, ZZZ = (o.limbs_to_int(out[4 * i : 4 * i + 4]) * pow(o.MONT_R, -1, o.Q) % o.Q for i in range(4))
     if ZZ == 0:
