@@ -310,9 +310,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
     ccnt[tid] = 0;
     if (tid < nq) {
       const uint32_t b = (bin << lb) + tid;
-      off[b] = start + ex;
+      const uint32_t o = start + ex;
+      off[b] = o;
       hist[b] = tot;
-      uint32_t f0 = (tot + (1u << ls0) - 1) >> ls0;
+      // partial sums the accumulation leaves for this bucket: one, plus one per chunk start inside its run
+      uint32_t f0 = tot ? 1u + ((o + tot - 1) >> ls0) - (o >> ls0) : 0u;
       np0[b] = f0;
       np1[b] = (f0 + S1 - 1) / S1;
     }
@@ -485,25 +487,41 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
   return lo;
 }
 
-// level 0: one thread per task of <= S0 sorted entries of one bucket; gathers table points (64 B) and
-// accumulates with mixed additions in the lazy 29-bit-limb representation (g1_29.cuh).
-__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* hist, const uint32_t* toff,
-                                                    uint32_t nb, uint32_t S0, const uint8_t* table, uint8_t* part) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= toff[nb]) return;
-  uint32_t b = find_bucket(toff, nb, t);
-  uint32_t j = t - toff[b];
-  uint32_t start = off[b] + j * S0;
-  uint32_t len = min(S0, hist[b] - j * S0);
+// level 0: the bucket-ordered entry array is cut into chunks of exactly S0 = 2^ls0 entries, one thread per
+// chunk, regardless of bucket boundaries: every lane of a wavefront performs the same number of additions
+// (cutting each bucket into its own tasks left a short remainder task per bucket: ~7 % idle lanes at 512
+// entries per bucket).  A chunk that crosses a bucket boundary closes one partial sum and opens the next;
+// partial sums are numbered in array order, so bucket b owns np0[b] = 1 + (#chunk starts strictly inside
+// its run) consecutive partials starting at toff[b] (the exclusive scan of np0) — the layout the fold
+// expects.  Gathers table points (64 B), mixed additions in the lazy 29-bit-limb representation.
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb, uint32_t ls0,
+                                                    const uint8_t* table, uint8_t* part) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = off[nb];
+  if (((uint64_t)t << ls0) >= total) return;
+  const uint32_t start = t << ls0;
+  const uint32_t end = min(start + (1u << ls0), total);
+  uint32_t b = find_bucket(off, nb, start);  // the (non-empty) bucket that holds entry `start`
+  uint32_t pidx = toff[b] + (t - (off[b] >> ls0));
+  uint32_t bend = off[b + 1];
   xyzz29 acc = xyzz29_identity();
   uint32_t e = entries[start];
   affine nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
   uint32_t nneg = e >> 31;
-  for (uint32_t k = 0; k < len; k++) {
+  for (uint32_t k = start; k < end; k++) {
+    if (k == bend) {  // bucket boundary inside the chunk: close this partial, move to the next non-empty bucket
+      part_store(part + (size_t)pidx * PART_BYTES, acc);
+      pidx++;
+      acc = xyzz29_identity();
+      do {
+        b++;
+        bend = off[b + 1];
+      } while (bend == k);
+    }
     affine p = nxt;
     uint32_t neg = nneg;
-    if (k + 1 < len) {
-      e = entries[start + k + 1];
+    if (k + 1 < end) {
+      e = entries[k + 1];
       nxt = affine_load(table + (size_t)(e & 0x7fffffffu) * 64);
       nneg = e >> 31;
     }
@@ -513,7 +531,7 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
     if (neg) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
     xyzz29_madd(acc, x2, y2);
   }
-  part_store(part + (size_t)t * PART_BYTES, acc);
+  part_store(part + (size_t)pidx * PART_BYTES, acc);
 }
 
 // ---- bucket reduction ("tail"), batched --------------------------------------------------------------
@@ -752,7 +770,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->logNh = (B->c - 1) - B->logNl;
   if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = n * B->W;
-  B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb);  // pick_chunk keeps tasks below this
+  B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb + 1);  // pick_chunk keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
@@ -852,8 +870,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   while ((1u << ls0) < s0) ls0++;
   // the partial buffers were sized at registration: never let an override (H2MI_MSM_S0) or a shorter
   // vector produce more tasks than they hold
-  while (ls0 < 6 && (uint64_t)(total >> ls0) + nb > B->max_tasks0) ls0++;
-  if ((uint64_t)(total >> ls0) + nb > B->max_tasks0) return H2MI_ERANGE;
+  while (ls0 < 6 && (((uint64_t)total + (1u << ls0) - 1) >> ls0) + nb > B->max_tasks0) ls0++;
+  if ((((uint64_t)total + (1u << ls0) - 1) >> ls0) + nb > B->max_tasks0) return H2MI_ERANGE;
   if (pipelined) {
     hs = ctx().head_stream;
     as = ctx().accum_stream;
@@ -933,7 +951,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
   }
-  uint32_t tasks0 = (uint32_t)((n * W >> ls0) + nb);
+  const uint32_t chunks0 = (uint32_t)(((uint64_t)total + (1u << ls0) - 1) >> ls0);  // upper bound: zero digits leave no entry
+  const uint32_t tasks0 = chunks0 + nb;                                             // upper bound of the partial sums
   if (pipelined) {
     H2_HIP(hipEventRecord(S.head_done, hs));
     H2_HIP(hipStreamWaitEvent(as, S.head_done, 0));
@@ -945,8 +964,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // 56000 B holds it at two workgroups per CU and leaves half the registers and 48 KB of LDS per CU free:
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
-  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(tasks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.hist, (const uint32_t*)S.toff[0], nb, 1u << ls0, (const uint8_t*)B->table, S.part[0]);
+  H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
+            (const uint32_t*)S.toff[0], nb, ls0, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;
   S.tasks1 = tasks0 / S1 + nb;
   if (pipelined) {
