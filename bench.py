@@ -60,7 +60,15 @@ def main():
     backend = os.environ.get("H2MI_DIST_BACKEND", "nccl")
     if "H2MI_DEVICE" in os.environ:
         local_rank = int(os.environ["H2MI_DEVICE"])
-    if world > 1:
+    # H2MI_FORCE_DIST=1: take the N > 1 code path (process group, all-gather + fold, barriers) with a single
+    # rank, so that a 1-GPU box exercises the RCCL plumbing the driver's multi-GPU run depends on
+    force_dist = world == 1 and os.environ.get("H2MI_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -78,7 +86,7 @@ def main():
 
     h2.init(local_rank)
     lib = h2.lib
-    combine = PartialPointCombiner(device=coll_dev) if world > 1 else None
+    combine = PartialPointCombiner(device=coll_dev) if dist is not None else None
     shape = rp.SHAPES[args.shape]
     R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine, spread_leaf_ntts=not args.replicate_all_ntts,
                        with_evaluate_h=args.with_evaluate_h)

@@ -227,7 +227,7 @@ class ProofReplay:
         """wait, fetch the partial results, combine across ranks -> (msm_per_proof, 12)."""
         check(lib.h2mi_sync(), "sync")
         part = self.out.to_numpy(shape=(self.shape.msm_per_proof, 12))
-        if self.world > 1 and self.combine is not None:
+        if self.combine is not None:  # N > 1 (or a forced single-rank rehearsal of the collective path)
             return self.combine(part)
         return part
 

@@ -662,3 +662,13 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     assert two["commitments_sha256"] == one["commitments_sha256"]
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert key in two and key in one
+    # the same code path over RCCL ("nccl" backend) with a single rank: process group on the GPU, device
+    # all-gather of the partial points, fold, barriers — what the driver's multi-GPU run relies on
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env3 = dict(env, H2MI_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r3 = subprocess.run([sys.executable] + common, cwd=root, capture_output=True, text=True, timeout=600, env=env3)
+    assert r3.returncode == 0, r3.stdout[-1000:] + r3.stderr[-2000:]
+    rccl = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
+    assert rccl["commitments_sha256"] == one["commitments_sha256"] and rccl["n_gpus"] == 1
