@@ -73,6 +73,7 @@ def _load():
         "h2mi_profile_query": ([C.c_char_p, C.POINTER(C.c_double), u64p], C.c_int),
         "h2mi_dbg_field_op": ([C.c_int, C.c_int, vp, vp, vp, sz], C.c_int),
         "h2mi_dbg_g1_op": ([C.c_int, vp, vp, vp, sz], C.c_int),
+        "h2mi_dbg_g1_quad_op": ([C.c_int, vp, vp, vp, sz], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)  # AttributeError here = a symbol the header declares is missing

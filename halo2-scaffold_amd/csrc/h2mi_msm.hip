@@ -26,6 +26,7 @@
 
 #include "g1.cuh"
 #include "g1_29.cuh"
+#include "g1_29_quad.cuh"
 #include "h2mi_internal.h"
 
 namespace h2 {
@@ -702,6 +703,34 @@ __global__ void __launch_bounds__(64) k_msm_final(const TailBatch tb) {
   }
 }
 
+// debug hook for the lane-cooperative point operations (g1_29_quad.cuh): four lanes per element.
+// op 0: (P) + (Q) with both operands brought to non-trivial XYZZ representatives; op 1: 2 (P).
+__global__ void __launch_bounds__(256) k_dbg_quad(int op, const uint8_t* pp, const uint8_t* qq, uint8_t* out, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (i >= n) return;  // n is padded by the host so that whole quads share the decision
+  auto lift = [](const uint8_t* src) {  // affine Mont256 -> XYZZ with ZZ != 1: (2P) + (-P)
+    affine a = affine_load(src);
+    if (affine_is_identity(a)) return xyzz29_identity();
+    f29 x = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.x.v));
+    f29 y = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.y.v));
+    xyzz29 r = xyzz29_dbl_affine(x, y);
+    xyzz29_madd(r, x, f29_sub(f29_zero(), y, Fq29::K2));
+    return r;
+  };
+  xyzz29 a = lift(pp + i * 64);
+  xyzz29 r = op == 0 ? xyzz29_add_quad(a, lift(qq + i * 64)) : xyzz29_dbl_quad(a);
+  if ((threadIdx.x & 3u) != (uint32_t)(i & 3u)) return;  // one lane of the quad writes (a different one per element)
+  jac j;
+  if (xyzz29_is_identity(r)) {
+    j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
+  } else {
+    f29_to_mont256<Fq29>(f29_mul<Fq29>(r.x, r.zz), j.x.v);
+    f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
+    f29_to_mont256<Fq29>(r.zz, j.z.v);
+  }
+  jac_store(out + i * 96, j);
+}
+
 // ---- host -----------------------------------------------------------------------------------------
 static uint32_t pick_window(size_t n) {
   const char* ev = getenv("H2MI_MSM_C");
@@ -1155,6 +1184,25 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   if (d) hipFree(d);
   if (handle == 0) h2mi_bases_release(h);
   return rc;
+}
+
+int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {
+  H2_REQUIRE_INIT();
+  if (!p || !out_jac || n == 0 || (op != 0 && op != 1) || (op == 0 && !q)) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = ctx().stream;
+  DevMem dp, dq, dout;
+  H2_HIP(dp.alloc(n * 64));
+  H2_HIP(dout.alloc(n * 96));
+  H2_HIP(hipMemcpyAsync(dp.p, p, n * 64, hipMemcpyHostToDevice, s));
+  if (q) {
+    H2_HIP(dq.alloc(n * 64));
+    H2_HIP(hipMemcpyAsync(dq.p, q, n * 64, hipMemcpyHostToDevice, s));
+  }
+  H2_LAUNCH("k_dbg_quad", k_dbg_quad, ceil_div_u32(n * 4, 256), 256, 0, s, op, dp.as<uint8_t>(), dq.as<uint8_t>(), dout.as<uint8_t>(), n);
+  H2_HIP(hipMemcpyAsync(out_jac, dout.p, n * 96, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  return H2MI_OK;
 }
 
 int h2mi_msm_set_canonical(int on) {

@@ -187,6 +187,9 @@ int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,
                       const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op 0: out = P + Q (affine inputs, via XYZZ mixed add); 1: 2P; 2: P + Q via XYZZ full add; output Jacobian (12 limbs each) */
 int h2mi_dbg_g1_op(int op, const uint64_t* p_affine, const uint64_t* q_affine, uint64_t* out_jac, size_t n);
+/* the lane-cooperative point operations of the bucket reduction (csrc/g1_29_quad.cuh), four lanes per
+ * element: op 0 = P[i] + Q[i] (XYZZ + XYZZ), op 1 = 2 P[i]; affine Montgomery in, Jacobian out */
+int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q_or_null, uint64_t* out_jac, size_t n);
 
 #ifdef __cplusplus
 }

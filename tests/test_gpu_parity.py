@@ -84,6 +84,24 @@ def test_g1_ops(gpu):
     assert o.unpack_jacobian(s) == acc
 
 
+def test_g1_quad_lane_ops(gpu):
+    """the lane-cooperative XYZZ addition / doubling of the bucket reduction (four lanes per operation) against
+    the oracle's group law, including identity operands, P + P, P + (-P), and element counts that do not fill
+    a wavefront."""
+    for n_rand, seed in ((3, 11), (61, 12), (200, 13)):
+        P = _points(n_rand, seed)
+        Qs = _points(n_rand, seed + 100)
+        P += [None, P[0], P[1], None, P[2], o.G1_GEN]
+        Qs += [Qs[0], None, P[1], None, o.g1_neg(P[2]), o.G1_GEN]
+        n = len(P)
+        A, B = o.pack_points(P), o.pack_points(Qs)
+        out = np.zeros((n, 12), dtype=np.uint64)
+        assert gpu.lib.h2mi_dbg_g1_quad_op(0, A.ctypes.data, B.ctypes.data, out.ctypes.data, n) == 0
+        assert [o.unpack_jacobian(out[i]) for i in range(n)] == [o.g1_add(p, q) for p, q in zip(P, Qs)]
+        assert gpu.lib.h2mi_dbg_g1_quad_op(1, A.ctypes.data, None, out.ctypes.data, n) == 0
+        assert [o.unpack_jacobian(out[i]) for i in range(n)] == [o.g1_double(p) for p in P]
+
+
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13])
 def test_ntt_matches_oracle(gpu, log_n):
     n = 1 << log_n
