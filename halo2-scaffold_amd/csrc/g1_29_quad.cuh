@@ -44,6 +44,7 @@ __device__ __forceinline__ f29 quad_pick(uint32_t role, const f29& a0, const f29
 __device__ __forceinline__ xyzz29 xyzz29_dbl_quad(const xyzz29& p) {
   using F = Fq29;
   const uint32_t role = threadIdx.x & 3u;
+  if (!__any(!xyzz29_is_identity(p))) return p;  // no quad of this wavefront holds a point: skip the arithmetic
   f29 u = f29_normalize(f29_dbl(p.y));
   // round 1: V = U^2 | XX = X^2
   f29 a = quad_pick(role, u, p.x, u, u);
@@ -70,6 +71,10 @@ __device__ __forceinline__ xyzz29 xyzz29_dbl_quad(const xyzz29& p) {
 __device__ __forceinline__ xyzz29 xyzz29_add_quad(const xyzz29& a, const xyzz29& b) {
   using F = Fq29;
   const uint32_t role = threadIdx.x & 3u;
+  // reductions over sparse data add mostly identities: when no quad of the wavefront has two real operands
+  // the four rounds are skipped (wavefront-uniform branch)
+  const bool a_id = xyzz29_is_identity(a), b_id = xyzz29_is_identity(b);
+  if (!__any(!(a_id || b_id))) return b_id ? a : b;
   // round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1
   f29 m1 = f29_mul<F>(quad_pick(role, a.x, b.x, a.y, b.y), quad_pick(role, b.zz, a.zz, b.zzz, a.zzz));
   f29 u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
@@ -91,8 +96,8 @@ __device__ __forceinline__ xyzz29 xyzz29_add_quad(const xyzz29& a, const xyzz29&
   out.zzz = quad_bcast<2>(m4);
   out.y = f29_normalize(f29_sub(t1, t2, F::K2));
   // special cases: every flag is computed from replicated values, hence uniform inside the quad
-  if (xyzz29_is_identity(b)) return a;
-  if (xyzz29_is_identity(a)) return b;
+  if (b_id) return a;
+  if (a_id) return b;
   if (f29_is_zero_mod<F>(pp)) {  // same x: equal or opposite points (rare)
     if (f29_is_zero_mod<F>(rr)) return xyzz29_dbl_quad(a);
     return xyzz29_identity();

@@ -552,12 +552,20 @@ struct TailBatch {
   TailDesc d[TAIL_BATCH];
 };
 
-// fold level: one thread per task of <= S1 partials of one bucket
+// Every point operation below is lane-cooperative (g1_29_quad.cuh): the four lanes of a quad hold the same
+// operands and compute one addition / doubling together in 4 / 3 multiplication rounds instead of 14 / 10
+// dependent multiplications, which is what shortens the chain.  "quad q" = lanes 4q .. 4q+3.
+constexpr uint32_t TAIL_THREADS = 512;  // rowcol / weighted: 128 quads reduce up to 256 values
+
+// fold level: one worker per task of <= S1 partials of one bucket.  A worker is a quad (QUAD: small grids,
+// where the chain's latency is what counts) or a single lane (large grids, where the fold is bound by
+// throughput and the cooperative form's ~2x instruction count would cost more than its shorter chain saves).
+template <bool QUAD>
 __global__ void __launch_bounds__(256) k_msm_fold(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   const uint32_t nb = d.nb;
   const uint32_t *toff_out = d.toff1, *toff_in = d.toff0, *np_in = d.np0;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
   if (t >= toff_out[nb]) return;
   uint32_t b = find_bucket(toff_out, nb, t);
   uint32_t j = t - toff_out[b];
@@ -568,13 +576,15 @@ __global__ void __launch_bounds__(256) k_msm_fold(const TailBatch tb) {
   xyzz29 acc = part_load(d.part0 + (size_t)start * PART_BYTES);
   for (uint32_t k = 1; k < len; k++) {
     xyzz29 p = part_load(d.part0 + (size_t)(start + k) * PART_BYTES);
-    xyzz29_add(acc, p);
+    if (QUAD) acc = xyzz29_add_quad(acc, p);
+    else xyzz29_add(acc, p);
   }
-  part_store(d.part1 + (size_t)t * PART_BYTES, acc);
+  if (!QUAD || (threadIdx.x & 3u) == 0) part_store(d.part1 + (size_t)t * PART_BYTES, acc);
 }
 
-// bucket finish: FG lanes cooperate on one bucket: lane l sums partials l, l+FG, ... (one partial each in
-// the common case), then a log2(FG)-level shuffle tree; writes one dense XYZZ value per bucket.
+// bucket finish: FG workers (quads or lanes, as above) cooperate on one bucket: worker l sums partials l,
+// l+FG, ... (one partial each in the common case), then a log2(FG)-level shuffle tree; writes one dense XYZZ
+// value per bucket.
 __device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta) {
   xyzz29 r;
 #pragma unroll
@@ -586,55 +596,61 @@ __device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta
   }
   return r;
 }
+template <bool QUAD>
 __global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   const uint32_t nb = d.nb;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t b = t / FG, l = t % FG;
-  if (blockIdx.x * blockDim.x / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
+  constexpr uint32_t LW = QUAD ? 2 : 0;  // log2(lanes per worker)
+  const uint32_t worker = (blockIdx.x * blockDim.x + threadIdx.x) >> LW;
+  const uint32_t b = worker / FG, l = worker % FG;
+  if ((blockIdx.x * blockDim.x >> LW) / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
   xyzz29 acc = xyzz29_identity();
   if (b < nb) {
     uint32_t cnt = d.np1[b], s = d.toff1[b];
     for (uint32_t k = l; k < cnt; k += FG) {
       xyzz29 p = part_load(d.part1 + (size_t)(s + k) * PART_BYTES);
-      xyzz29_add(acc, p);
+      if (QUAD) acc = xyzz29_add_quad(acc, p);
+      else xyzz29_add(acc, p);
     }
   }
   for (uint32_t dd = FG / 2; dd > 0; dd >>= 1) {
-    xyzz29 o = shfl_down_xyzz(acc, dd);
-    if (l < dd) xyzz29_add(acc, o);
+    xyzz29 o = shfl_down_xyzz(acc, dd << LW);  // the same role dd workers up; a bucket spans FG << LW aligned lanes
+    if (l < dd) {
+      if (QUAD) acc = xyzz29_add_quad(acc, o);
+      else xyzz29_add(acc, o);
+    }
   }
-  if (b < nb && l == 0) part_store(d.dense + (size_t)b * PART_BYTES, acc);
+  if (b < nb && l == 0 && (!QUAD || (threadIdx.x & 3u) == 0)) part_store(d.dense + (size_t)b * PART_BYTES, acc);
 }
 
-// block-wide tree sum of up to 256 XYZZ values held in LDS
+// block-wide tree sum of up to 256 XYZZ values held in LDS, one quad per pair
 __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2) {
-  const uint32_t tid = threadIdx.x;
+  const uint32_t quad = threadIdx.x >> 2, nquads = blockDim.x >> 2;
   for (uint32_t s = count_pow2 >> 1; s > 0; s >>= 1) {
-    if (tid < s) {
-      xyzz29 a = lds[tid];
-      xyzz29 b = lds[tid + s];
-      xyzz29_add(a, b);
-      lds[tid] = a;
+    for (uint32_t g = quad; g < s; g += nquads) {  // writes go to [0, s), the other operand comes from [s, 2s)
+      xyzz29 r = xyzz29_add_quad(lds[g], lds[g + s]);
+      if ((threadIdx.x & 3u) == 0) lds[g] = r;
     }
     __syncthreads();
   }
 }
 
 // bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
-__global__ void __launch_bounds__(256) k_msm_rowcol(const TailBatch tb) {
+__global__ void __launch_bounds__(TAIL_THREADS) k_msm_rowcol(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t logNl = d.logNl, Nh = 1u << d.logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
   if (blk >= Nh + Nl) return;
-  xyzz29 v = xyzz29_identity();
-  if (blk < Nh) {
-    if (tid < Nl) v = part_load(d.dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
-  } else {
-    if (tid < Nh) v = part_load(d.dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
+  if (tid < 256) {
+    xyzz29 v = xyzz29_identity();
+    if (blk < Nh) {
+      if (tid < Nl) v = part_load(d.dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
+    } else {
+      if (tid < Nh) v = part_load(d.dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
+    }
+    lds[tid] = v;
   }
-  lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, max(Nh, Nl));
   if (tid == 0) part_store(d.rc + (size_t)blk * PART_BYTES, lds[0]);
@@ -642,20 +658,22 @@ __global__ void __launch_bounds__(256) k_msm_rowcol(const TailBatch tb) {
 
 // bit-decomposed weights: block beta < logNh sums rows with bit beta of hi set; block logNh + beta sums
 // columns with bit beta of (lo+1) set (beta <= logNl).
-__global__ void __launch_bounds__(256) k_msm_weighted(const TailBatch tb) {
+__global__ void __launch_bounds__(TAIL_THREADS) k_msm_weighted(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t logNh = d.logNh, logNl = d.logNl, Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
   if (blk >= logNh + logNl + 1) return;
-  xyzz29 v = xyzz29_identity();
-  if (blk < logNh) {
-    if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(d.rc + (size_t)tid * PART_BYTES);
-  } else {
-    uint32_t beta = blk - logNh;
-    if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(d.rc + (size_t)(Nh + tid) * PART_BYTES);
+  if (tid < 256) {
+    xyzz29 v = xyzz29_identity();
+    if (blk < logNh) {
+      if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(d.rc + (size_t)tid * PART_BYTES);
+    } else {
+      uint32_t beta = blk - logNh;
+      if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(d.rc + (size_t)(Nh + tid) * PART_BYTES);
+    }
+    lds[tid] = v;
   }
-  lds[tid] = v;
   __syncthreads();
   block_tree_sum(lds, max(Nh, Nl));
   if (tid == 0) part_store(d.g + (size_t)blk * PART_BYTES, lds[0]);
@@ -667,21 +685,22 @@ __global__ void __launch_bounds__(256) k_msm_weighted(const TailBatch tb) {
 // representative (not the group element) can differ between two runs on the same input: callers compare
 // or hash after h2mi_g1_batch_normalize, exactly as the reference's callers do with best_multiexp's result;
 // h2mi_msm_set_canonical(1) trades one field inversion per MSM for reproducible bits.
-__global__ void __launch_bounds__(64) k_msm_final(const TailBatch tb) {
+// One workgroup of 32 quads per MSM: quad g doubles term g its 2^shift times, then a 5-level tree.
+__global__ void __launch_bounds__(128) k_msm_final(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.x];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, quad = tid >> 2;
   const uint32_t logNh = d.logNh, logNl = d.logNl;
-  const uint32_t terms = logNh + logNl + 1;
+  const uint32_t terms = logNh + logNl + 1;  // <= 17
   xyzz29 v = xyzz29_identity();
-  if (tid < terms) {
-    v = part_load(d.g + (size_t)tid * PART_BYTES);
-    uint32_t shift = tid < logNh ? tid + logNl : tid - logNh;
-    for (uint32_t k = 0; k < shift; k++) v = xyzz29_dbl(v);
+  if (quad < terms) {
+    v = part_load(d.g + (size_t)quad * PART_BYTES);
+    uint32_t shift = quad < logNh ? quad + logNl : quad - logNh;
+    for (uint32_t k = 0; k < shift; k++) v = xyzz29_dbl_quad(v);
   }
-  lds[tid] = v;
+  if ((tid & 3u) == 0) lds[quad] = v;
   __syncthreads();
-  block_tree_sum(lds, 32);  // terms <= 17
+  block_tree_sum(lds, 32);
   if (tid == 0) {
     xyzz29 r = lds[0];
     jac j;
@@ -1022,11 +1041,21 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
 // per lane), n / (s0 * S1) if every scalar is the same (slow but correct).  Then the weighted bucket sum.
 static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
                         hipStream_t t) {
-  H2_LAUNCH("k_msm_fold", k_msm_fold, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
-  H2_LAUNCH("k_msm_finish", k_msm_finish, dim3(ceil_div_u32((uint64_t)max_nb * FG, 256), count), 256, 0, t, tb);
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3((1u << max_logNh) + (1u << max_logNl), count), 256, 256 * PART_BYTES, t, tb);
-  H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1, count), 256, 256 * PART_BYTES, t, tb);
-  H2_LAUNCH("k_msm_final", k_msm_final, count, 64, 64 * PART_BYTES, t, tb);
+  // fold / finish: quads (4 lanes per point operation) while the grid stays latency-bound, single lanes beyond
+  const bool force_lane = getenv("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
+  if (!force_lane && (uint64_t)max_tasks1 * count <= 49152) {
+    H2_LAUNCH("k_msm_fold", k_msm_fold<true>, dim3(ceil_div_u32((uint64_t)max_tasks1 * 4, 256), count), 256, 0, t, tb);
+  } else {
+    H2_LAUNCH("k_msm_fold", k_msm_fold<false>, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
+  }
+  if (!force_lane && (uint64_t)max_nb * FG * count <= 65536) {
+    H2_LAUNCH("k_msm_finish", k_msm_finish<true>, dim3(ceil_div_u32((uint64_t)max_nb * FG * 4, 256), count), 256, 0, t, tb);
+  } else {
+    H2_LAUNCH("k_msm_finish", k_msm_finish<false>, dim3(ceil_div_u32((uint64_t)max_nb * FG, 256), count), 256, 0, t, tb);
+  }
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3((1u << max_logNh) + (1u << max_logNl), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1, count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
+  H2_LAUNCH("k_msm_final", k_msm_final, count, 128, 32 * PART_BYTES, t, tb);
   return H2MI_OK;
 }
 
