@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
 // pairs, 67 MB of sorted payloads: 0.3 GB against 0.7 GB + 0.1 GB for key/value radix sorting.
 // The order of the points inside a bucket follows LDS-atomic arrival, so it is not reproducible: see
 // k_msm_final for what that means for the result.
-constexpr uint32_t P1_TS = 1024;       // scalars per partition tile = threads per workgroup
+constexpr uint32_t P1_TS = 768;       // scalars per partition tile = threads per workgroup
 constexpr uint32_t NBINS_MAX = 512;
 constexpr uint32_t P2_THREADS = 512, P2_PER = 16, P2_CH = P2_THREADS * P2_PER;
 
