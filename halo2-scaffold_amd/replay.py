@@ -186,16 +186,20 @@ class ProofReplay:
                 self._to_coeff_and_extended(c, w, e)
         if sh.n_lookups:
             join()
-        # phase 4: permutation products: commit, lagrange_to_coeff, coeff_to_extended per chunk
+        # phases 4-6: commitments of the permutation products, the lookup products and the random polynomial
+        # (coefficient basis) -> challenge y.  All commitments of the phase are queued first and the columns'
+        # transforms behind them: an MSM's partition then runs beside the accumulation of the one before it,
+        # instead of waiting on the library stream behind transforms that are themselves slowed by that
+        # accumulation (measured gain over the interleaved order: 0.1-0.3 ms per proof at k = 20, 4 % at k = 17).
         for c, w, e in perm_we:
             self._msm(c, lagrange=True)
-            self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
-        # phase 5: lookup products
         for i in range(sh.n_lookups):
             self._msm(self.lookup[3 * i + 2], lagrange=True)
-            self._to_coeff_and_extended(*look_we[3 * i + 2])
-        # phase 6: random polynomial commitment (coefficient basis) -> challenge y; instance columns
         self._msm(self.random_poly, lagrange=False)
+        for c, w, e in perm_we:
+            self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
+        for i in range(sh.n_lookups):
+            self._to_coeff_and_extended(*look_we[3 * i + 2])
         for c, w, e in inst_we:
             self._to_coeff_and_extended(c, w, e, coeff_needed=w is self.work[0])
         join()
