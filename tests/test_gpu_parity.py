@@ -326,6 +326,30 @@ def test_msm_vs_c_oracle_large(gpu):
     params.release()
 
 
+def test_msm_hot_buckets_large(gpu):
+    """2^16 points whose scalars fall into a handful of buckets: one partition bin receives everything (many
+    chunks through the per-bin sort), accumulation chunks never or rarely cross a bucket boundary, and the
+    fold level carries thousands of partial sums per bucket (both its lane and quad forms are reached through
+    the two sizes).  Against the C restatement of best_multiexp."""
+    from oracle import cref
+
+    for k in (16, 12):
+        n = 1 << k
+        params = gpu.ParamsKZG.setup(k, 0xFEED + k)
+        bases = params.get_g()
+        rng = np.random.default_rng(k)
+        cases = {
+            "all ones": [1] * n,
+            "three values": [int(v) for v in rng.choice([5, o.R - 5, 1 << 100], n)],
+            "small digits": [int(v) for v in rng.integers(0, 8, n)],
+            "one window only": [int(v) << 48 for v in rng.integers(1, 1 << 16, n)],
+        }
+        for name, vals in cases.items():
+            sc = o.pack(vals, o.R)
+            assert np.array_equal(cref.normalize(params.commit(sc)), cref.normalize(cref.msm(sc, bases, 8))), (k, name)
+        params.release()
+
+
 def test_msm_linearity_full_size(gpu):
     """BASELINE size (k = 20): MSM(a + b) == MSM(a) + MSM(b) and MSM(c * 1) == c * MSM(1) as group elements."""
     from oracle import cref
