@@ -31,9 +31,9 @@
 
 namespace h2 {
 
-constexpr uint32_t S0_MAX = 64;  // points per accumulation task (smaller for small problems: see pick_chunk)
+constexpr uint32_t S0_MAX = 64;  // entries per accumulation chunk (smaller for small problems: see pick_chunk)
 constexpr uint32_t S1 = 8;       // partials per fold task
-constexpr uint32_t FG = 8;       // lanes that cooperate on one bucket in k_msm_finish
+constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
 
 // per-call workspace; several slots per handle so that consecutive MSMs overlap (partition of one beside
 // the accumulation of another) and their bucket reductions can be deferred and run as one batch.
@@ -43,10 +43,9 @@ struct Slot {
   uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
   uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
   void* bin_scan_tmp = nullptr;
-  uint32_t* binseg = nullptr;   // sums of the 65536-cell segments of bincnt
-  uint32_t* hist = nullptr;     // nb
-  uint32_t* off = nullptr;      // nb+1
-  uint32_t* np[2] = {nullptr, nullptr};    // tasks per bucket: accumulation, fold (nb+1 entries, last = 0)
+  uint32_t* binseg = nullptr;   // sums of the SCAN_SEG_BINS-cell segments of bincnt
+  uint32_t* off = nullptr;      // first entry of each bucket in vals[1] (nb+1; last = number of entries)
+  uint32_t* np[2] = {nullptr, nullptr};    // per bucket: partial sums the accumulation leaves, fold tasks (nb+1 entries, last = 0)
   uint32_t* toff[2] = {nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
   void* scan_tmp = nullptr;
   uint8_t* part[2] = {nullptr, nullptr};   // XYZZ partial buffers: accumulation output, fold output
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
 //   exclusive scan     over [bin][tile] -> each tile's write offset in each bin
 //   k_msm_bin_scatter  recomputes the digits, groups the tile's entries by bin in LDS and writes each group as
 //                      one contiguous run: payload (u32) + bucket id within the bin (u8)
-//   k_msm_bin_sort     one workgroup per bin: counts its 2^lb buckets, writes the bucket tables (off, hist,
+//   k_msm_bin_sort     one workgroup per bin: counts its 2^lb buckets, writes the bucket tables (off,
 //                      task counts) and moves the payloads into bucket order, LDS-staged in chunks.
 // HBM traffic per MSM at n = 2^20, W = 16: 2 x 32 MiB scalar reads, 84 MB + 84 MB for the intermediate
 // pairs, 67 MB of sorted payloads: 0.3 GB against 0.7 GB + 0.1 GB for key/value radix sorting.
@@ -275,7 +274,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
 constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 512 bins)
 __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
                                                              uint32_t nbins, uint32_t lb, uint32_t ls0, uint32_t nb, uint32_t* vals_out,
-                                                             uint32_t* off, uint32_t* hist, uint32_t* np0, uint32_t* np1) {
+                                                             uint32_t* off, uint32_t* np0, uint32_t* np1) {
   __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
   __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
   __shared__ uint32_t stage[P2_CH];
@@ -313,7 +312,6 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
       const uint32_t b = (bin << lb) + tid;
       const uint32_t o = start + ex;
       off[b] = o;
-      hist[b] = tot;
       // partial sums the accumulation leaves for this bucket: one, plus one per chunk start inside its run
       uint32_t f0 = tot ? 1u + ((o + tot - 1) >> ls0) - (o >> ls0) : 0u;
       np0[b] = f0;
@@ -785,7 +783,7 @@ static void free_bases(Bases* B) {
   for (Slot& S : B->slot) {
     hipFree(S.vals[0]); hipFree(S.vals[1]);
     hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
-    hipFree(S.hist); hipFree(S.off);
+    hipFree(S.off);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
@@ -841,7 +839,6 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.binbase, bin_cells * 4);
     H2_ALLOC(S.bin_scan_tmp, B->bin_scan_tmp_bytes ? B->bin_scan_tmp_bytes : 16);
     H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
-    H2_ALLOC(S.hist, (size_t)B->nb * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     for (int i = 0; i < 2; i++) {
       H2_ALLOC(S.np[i], (size_t)(B->nb + 1) * 4);
@@ -991,7 +988,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.accum_pending = false;
   S.head_pending = false;
   H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
-            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.hist, S.np[0], S.np[1]);
+            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.np[0], S.np[1]);
   if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
     H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
               (const uint32_t*)nullptr);
