@@ -200,6 +200,23 @@ def main():
         "note": "MSM is 254-bit integer-multiply bound (v_mad_u64_u32), not HBM bound; see DESIGN.md",
     }
 
+    # the binding resource, stated next to the (contractual) HBM roofline: 32-bit integer multiply issue.
+    # One mixed addition = 8 multiplications + 2 squarings in 9 x 29-bit limbs = 1548 v_mad_u64_u32; the peak
+    # is the chip's measured v_mad_u64_u32 rate (tools/ubench.hip: 4.82 cycles per wavefront instruction per
+    # SIMD at 2.4 GHz = 32.6 T lane-multiplies/s).  Other instructions of the loop (masks, shifts, the m = t * p'
+    # products) share the same issue port, so ~0.7 is the practical ceiling of this fraction.
+    MADS_PER_MIXED_ADD, MAD_PEAK = 1548, 32.6e12
+    entries_per_launch = adds_local / max(shape.msm_per_proof, 1)  # bucket insertions (+ reduction adds) per MSM, this rank
+    issue = {
+        "kernel": "k_msm_accum",
+        "bound": "valu (v_mad_u64_u32 issue)",
+        "achieved": round(entries_per_launch * MADS_PER_MIXED_ADD / (accum_ms * 1e-3) / 1e12, 3) if accum_ms else None,
+        "peak": MAD_PEAK / 1e12,
+        "unit": "T mad/s",
+    }
+    if issue["achieved"]:
+        issue["frac"] = round(issue["achieved"] / issue["peak"], 4)
+
     out = {
         "metric": "create_proof() wall-clock + MSM G1-adds/s at k=20 standard_plonk, 1/2/4/8 GPU",
         "value": round(value, 1),
@@ -233,6 +250,7 @@ def main():
         "device_ms_per_step": {"msm": round(msm_ms, 3), "ntt": round(ntt_ms, 3)},
         "kernels": phases,
         "roofline": roofline,
+        "issue_roofline": issue,
     }
 
     if world == 1 and not args.no_cpu_baseline:
