@@ -60,6 +60,7 @@ def _load():
         "h2mi_ntt_bn254_fr": ([vp, vp, C.c_uint32], C.c_int),
         "h2mi_ntt_ext_bn254_fr": ([vp, C.c_uint32, vp, vp, vp], C.c_int),
         "h2mi_ntt_bn254_fr_dev": ([vp, C.c_uint32, vp, vp, vp, vp], C.c_int),
+        "h2mi_ntt_bn254_fr_oop_dev": ([vp, sz, vp, C.c_uint32, vp, vp, vp, vp], C.c_int),
         "h2mi_fr_scale_powers_dev": ([vp, sz, vp, vp, vp], C.c_int),
         "h2mi_fr_eval_poly_dev": ([vp, sz, vp, vp, vp], C.c_int),
         "h2mi_fr_kate_division_dev": ([vp, sz, vp, vp, vp, vp], C.c_int),

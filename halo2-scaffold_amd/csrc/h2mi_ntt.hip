@@ -65,6 +65,8 @@ struct PassParams {
   fe post;        // Mont256 (as passed by the caller)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
   uint32_t remap;         // XCD-aware block remap on/off
+  size_t in_len;          // elements of `in` that exist; indices beyond read as zero (first pass of a
+                          // zero-extending transform: coeff_to_extended without materialising the padding)
 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t m) { return m ? (__brev(x) >> (32 - m)) : 0; }
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), e = o >> logC;
     size_t idx = base + ((size_t)e << logS) + jl0 + c;
-    f29 x = load_unpack(&p.in[idx]);
+    f29 x = idx < p.in_len ? load_unpack(&p.in[idx]) : f29_zero();
     if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
     uint32_t c = o >> m, e = o & ((1u << m) - 1);
     size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
     size_t idx = (rho << m) + e;
-    f29 x = load_unpack(&p.in[idx]);
+    f29 x = idx < p.in_len ? load_unpack(&p.in[idx]) : f29_zero();
     if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
@@ -609,8 +611,15 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   return v ? (uint32_t)atoi(v) : dflt;
 }
 
-static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post, hipStream_t s) {
+// d_src == d_a: in place.  Otherwise the first pass reads d_src (src_len elements, zero beyond) and the last
+// pass writes d_a; d_src is left untouched.
+static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post, hipStream_t s,
+                   const fe* d_src = nullptr, size_t src_len = 0) {
   if (log_n > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  if (!d_src) {
+    d_src = d_a;
+    src_len = (size_t)1 << log_n;
+  }
   Plan pl;
   int rc = get_plan(omega, log_n, s, &pl);
   if (rc) return rc;
@@ -640,7 +649,8 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     PassParams pp;
     memset(&pp, 0, sizeof(pp));
     const bool last = (p == pl.P - 1);
-    pp.in = (p == 0) ? d_a : g_tmp;
+    pp.in = (p == 0) ? d_src : g_tmp;
+    pp.in_len = (p == 0) ? src_len : n;
     pp.out = last ? d_a : g_tmp;
     pp.log_n = log_n;
     pp.log_seg = log_seg;
@@ -702,6 +712,15 @@ int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], co
   if (!d_a || !omega) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   return ntt_dev((fe*)d_a, log_n, omega, pre, post, pick_stream(stream));
+}
+
+int h2mi_ntt_bn254_fr_oop_dev(const void* d_src, size_t src_len, void* d_dst, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre,
+                              const uint64_t* post, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_src || !d_dst || !omega || d_src == d_dst) return H2MI_EINVAL;
+  if (log_n > H2MI_MAX_LOG_N || src_len > ((size_t)1 << log_n)) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return ntt_dev((fe*)d_dst, log_n, omega, pre, post, pick_stream(stream), (const fe*)d_src, src_len);
 }
 
 int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4], const uint64_t* pre, const uint64_t* post) {

@@ -76,6 +76,16 @@ class EvaluationDomain:
         """d_ext holds extended_len() elements: the n coefficients followed by zeros."""
         check(lib.h2mi_ntt_bn254_fr_dev(d_ext.ptr, self.extended_k, self._eomega.ctypes.data, self._zeta.ctypes.data, None, stream), "coset_fft_dev")
 
+    # out-of-place forms: the source column stays intact (the prover still needs it), no clone, no zero padding
+    def lagrange_to_coeff_oop_dev(self, d_lagrange: DevBuf, d_coeff: DevBuf, stream=None):
+        check(lib.h2mi_ntt_bn254_fr_oop_dev(d_lagrange.ptr, self.n, d_coeff.ptr, self.k, self._omega_inv.ctypes.data, None,
+                                            self._ninv.ctypes.data, stream), "ifft_oop_dev")
+
+    def coeff_to_extended_oop_dev(self, d_coeff: DevBuf, d_ext: DevBuf, stream=None):
+        """d_coeff: n coefficients; d_ext receives the extended_len() coset evaluations."""
+        check(lib.h2mi_ntt_bn254_fr_oop_dev(d_coeff.ptr, self.n, d_ext.ptr, self.extended_k, self._eomega.ctypes.data,
+                                            self._zeta.ctypes.data, None, stream), "coset_fft_oop_dev")
+
     def extended_to_coeff_dev(self, d_ext: DevBuf, stream=None):
         check(lib.h2mi_ntt_bn254_fr_dev(d_ext.ptr, self.extended_k, self._eomega_inv.ctypes.data, None, None, stream), "coset_ifft_dev")
         check(

@@ -136,17 +136,15 @@ class ProofReplay:
         return (not self.spread) or (self._leaf % self.world == self.rank)
 
     def _to_coeff_and_extended(self, lagr: DevBuf, w: DevBuf, e: DevBuf, coeff_needed: bool = False):
-        """lagrange_to_coeff then coeff_to_extended (zero padding of e restored at the end of step()).
+        """lagrange_to_coeff then coeff_to_extended, both out of place (lagr -> w -> e: no clones, no zero padding).
         `coeff_needed`: the coefficient form feeds a later commitment, so every rank computes it."""
         n = self.n
         mine = self._mine()
         if mine or coeff_needed:
-            w.copy_from(lagr, n * 32)
-            self.domain.lagrange_to_coeff_dev(w)
+            self.domain.lagrange_to_coeff_oop_dev(lagr, w)
             self.counts["intt_n"] += 1
         if mine:
-            e.copy_from(w, n * 32)
-            self.domain.coeff_to_extended_dev(e)
+            self.domain.coeff_to_extended_oop_dev(w, e)
             self.counts["coset_ntt_ext"] += 1
 
     def step(self, phase_joins: bool = True):
@@ -223,9 +221,6 @@ class ProofReplay:
         self._msm(self.work[0], lagrange=False)
         join()
         assert self._slot == sh.msm_per_proof
-        # restore the zero padding of the extended buffers for the next proof
-        for e in self.ext:
-            check(lib.h2mi_memset_zero(e.ptr + n * 32, (self.domain.extended_len() - n) * 32), "zero")
 
     def finish(self) -> np.ndarray:
         """wait, fetch the partial results, combine across ranks -> (msm_per_proof, 12)."""

@@ -117,6 +117,13 @@ int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4],
 int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4],
                           const uint64_t* pre_scale_base_or_null, const uint64_t* post_scale_or_null,
                           h2mi_stream_t stream);
+/* out-of-place, zero-extending form: reads src_len <= 2^log_n elements from d_src (the rest count as zero),
+ * writes the 2^log_n results to d_dst; d_src is left untouched and must not overlap d_dst.  This is
+ * EvaluationDomain::coeff_to_extended without the clone and the zero padding (src_len = n, log_n =
+ * extended_k, pre = g_coset), and lagrange_to_coeff on a column the prover still needs in Lagrange form. */
+int h2mi_ntt_bn254_fr_oop_dev(const void* d_src, size_t src_len, void* d_dst, uint32_t log_n, const uint64_t omega[4],
+                              const uint64_t* pre_scale_base_or_null, const uint64_t* post_scale_or_null,
+                              h2mi_stream_t stream);
 /* a[i] *= base^i on the device (EvaluationDomain::distribute_powers_zeta after an inverse coset NTT) */
 int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const uint64_t* post_scale_or_null,
                              h2mi_stream_t stream);

@@ -157,6 +157,35 @@ def test_ntt_large_properties(gpu, log_n):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("log_n,src_len", [(3, 8), (3, 5), (10, 512), (11, 1024), (13, 4096), (13, 1), (21, 1 << 20)])
+def test_ntt_out_of_place_zero_extended(gpu, log_n, src_len):
+    """h2mi_ntt_bn254_fr_oop_dev == zero-pad + in-place transform (all pass counts), source left untouched;
+    with the coset pre-scale it is coeff_to_extended."""
+    n = 1 << log_n
+    src = o.random_field_limbs(src_len, 77 + log_n)
+    w = o.pack([o.omega_for(log_n)], o.R)[0]
+    zeta = o.pack([o.FR_ZETA], o.R)[0]
+    d_src, d_dst = gpu.DevBuf.from_numpy(src), gpu.DevBuf(n * 32)
+    padded = np.zeros((n, 4), dtype=np.uint64)
+    padded[:src_len] = src
+    for pre in (None, zeta):
+        ref = gpu.DevBuf.from_numpy(padded)
+        assert gpu.lib.h2mi_ntt_bn254_fr_dev(ref.ptr, log_n, w.ctypes.data, pre.ctypes.data if pre is not None else None, None, None) == 0
+        assert gpu.lib.h2mi_ntt_bn254_fr_oop_dev(d_src.ptr, src_len, d_dst.ptr, log_n, w.ctypes.data,
+                                                 pre.ctypes.data if pre is not None else None, None, None) == 0
+        assert np.array_equal(d_dst.to_numpy(shape=(n, 4)), ref.to_numpy(shape=(n, 4)))
+        assert np.array_equal(d_src.to_numpy(shape=(src_len, 4)), src)
+        ref.free()
+    if log_n <= 11:  # and against the oracle's definition directly
+        vals = o.unpack(src, o.R) + [0] * (n - src_len)
+        assert gpu.lib.h2mi_ntt_bn254_fr_oop_dev(d_src.ptr, src_len, d_dst.ptr, log_n, w.ctypes.data, None, None, None) == 0
+        assert o.unpack(d_dst.to_numpy(shape=(n, 4)), o.R) == o.ntt(vals, o.omega_for(log_n))
+    # argument checks: overlapping buffers, source longer than the transform
+    assert gpu.lib.h2mi_ntt_bn254_fr_oop_dev(d_dst.ptr, n, d_dst.ptr, log_n, w.ctypes.data, None, None, None) == -1
+    assert gpu.lib.h2mi_ntt_bn254_fr_oop_dev(d_src.ptr, n + 1, d_dst.ptr, log_n, w.ctypes.data, None, None, None) == -6
+    d_src.free(); d_dst.free()
+
+
 def test_domain_matches_oracle(gpu):
     k, j = 6, 3
     d = gpu.EvaluationDomain(j, k)
