@@ -379,6 +379,39 @@ def test_msm_hot_buckets_large(gpu):
         params.release()
 
 
+def test_msm_randomised_sizes_and_distributions(gpu):
+    """seeded differential run: odd lengths around the partition tile (768), the scan segments and the chunk
+    sizes, with mixed scalar distributions, repeated and identity bases — against the C restatement."""
+    from oracle import cref
+
+    rng = np.random.default_rng(20251003)
+    kmax = 13
+    params = gpu.ParamsKZG.setup(kmax, 0xD1FF)
+    bases = params.get_g().copy()
+    bases[17] = 0            # an identity base
+    bases[100] = bases[99]   # a repeated base
+    alt = gpu.ParamsKZG.from_bases(kmax, bases)
+    lengths = [1, 2, 63, 64, 65, 767, 768, 769, 1535, 1537, 2048, 4095, 4097, 8191, 8192] + [int(x) for x in rng.integers(1, 8192, 12)]
+    for n in lengths:
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            vals = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]
+        elif kind == 1:
+            vals = [int(v) for v in rng.integers(0, 3, n)]
+        elif kind == 2:
+            vals = [(int.from_bytes(rng.bytes(32), "little") % o.R) if rng.random() < 0.1 else 0 for _ in range(n)]
+        elif kind == 3:
+            vals = [o.R - 1 - int(v) for v in rng.integers(0, 1 << 20, n)]
+        else:
+            vals = [int(v) << int(s) for v, s in zip(rng.integers(1, 1 << 16, n), rng.integers(0, 238, n))]
+        sc = o.pack(vals, o.R)
+        got = alt.commit(sc)
+        want = cref.msm(sc, bases[:n], 4)
+        assert np.array_equal(cref.normalize(got), cref.normalize(want)), (n, kind)
+    alt.release()
+    params.release()
+
+
 def test_msm_linearity_full_size(gpu):
     """BASELINE size (k = 20): MSM(a + b) == MSM(a) + MSM(b) and MSM(c * 1) == c * MSM(1) as group elements."""
     from oracle import cref
