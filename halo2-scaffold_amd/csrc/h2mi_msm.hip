@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
 
 constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 512 bins)
 __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
-                                                             uint32_t nbins, uint32_t lb, uint32_t ls0, uint32_t nb, uint32_t* vals_out,
+                                                             uint32_t nbins, uint32_t lb, uint32_t s0, uint32_t nb, uint32_t* vals_out,
                                                              uint32_t* off, uint32_t* np0, uint32_t* np1) {
   __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
   __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
       const uint32_t o = start + ex;
       off[b] = o;
       // partial sums the accumulation leaves for this bucket: one, plus one per chunk start inside its run
-      uint32_t f0 = tot ? 1u + ((o + tot - 1) >> ls0) - (o >> ls0) : 0u;
+      uint32_t f0 = tot ? 1u + (o + tot - 1) / s0 - o / s0 : 0u;
       np0[b] = f0;
       np1[b] = (f0 + S1 - 1) / S1;
     }
@@ -486,22 +486,22 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
   return lo;
 }
 
-// level 0: the bucket-ordered entry array is cut into chunks of exactly S0 = 2^ls0 entries, one thread per
+// level 0: the bucket-ordered entry array is cut into chunks of exactly s0 entries (any value), one thread per
 // chunk, regardless of bucket boundaries: every lane of a wavefront performs the same number of additions
 // (cutting each bucket into its own tasks left a short remainder task per bucket: ~7 % idle lanes at 512
 // entries per bucket).  A chunk that crosses a bucket boundary closes one partial sum and opens the next;
 // partial sums are numbered in array order, so bucket b owns np0[b] = 1 + (#chunk starts strictly inside
 // its run) consecutive partials starting at toff[b] (the exclusive scan of np0) — the layout the fold
 // expects.  Gathers table points (64 B), mixed additions in the lazy 29-bit-limb representation.
-__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb, uint32_t ls0,
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb, uint32_t s0,
                                                     const uint8_t* table, uint8_t* part) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = off[nb];
-  if (((uint64_t)t << ls0) >= total) return;
-  const uint32_t start = t << ls0;
-  const uint32_t end = min(start + (1u << ls0), total);
+  if ((uint64_t)t * s0 >= total) return;
+  const uint32_t start = t * s0;
+  const uint32_t end = min(start + s0, total);
   uint32_t b = find_bucket(off, nb, start);  // the (non-empty) bucket that holds entry `start`
-  uint32_t pidx = toff[b] + (t - (off[b] >> ls0));
+  uint32_t pidx = toff[b] + (t - off[b] / s0);
   uint32_t bend = off[b + 1];
   xyzz29 acc = xyzz29_identity();
   uint32_t e = entries[start];
@@ -767,15 +767,19 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
-// points per accumulation task: large problems use 64 (few partials per bucket); small ones (a GPU's
-// slice of a multi-GPU MSM) shorter chains so that the task count still fills the 1024 SIMDs.
+// Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
+// 256 threads per CU (see the occupancy cap in msm_dev): 131072 chunks run at once, all of the same length, so
+// the kernel's time is (rounds of 131072 chunks) x (chunk length).  The length is chosen so that the chunks fill
+// a whole number of rounds: with a power-of-two length a 2^18 / 2^19 slice ran 1.06 rounds — a second, nearly
+// empty round of full-length chains (0.45 / 0.88 ms instead of 0.30 / 0.59 ms).
+constexpr size_t ACCUM_RESIDENT_CHUNKS = (size_t)256 * 2 * 256;
 static uint32_t pick_chunk(size_t entries) {
   const char* ev = getenv("H2MI_MSM_S0");
   if (ev && atoi(ev) >= 1 && atoi(ev) <= 64) return (uint32_t)atoi(ev);
-  size_t want = entries / 196608;
-  uint32_t s0 = 8;
-  while (s0 < want && s0 < S0_MAX) s0 <<= 1;
-  return s0;
+  for (size_t rounds = 1;; rounds++) {
+    size_t s0 = (entries + rounds * ACCUM_RESIDENT_CHUNKS - 1) / (rounds * ACCUM_RESIDENT_CHUNKS);
+    if (s0 <= S0_MAX) return (uint32_t)(s0 < 8 ? 8 : s0);
+  }
 }
 
 static void free_bases(Bases* B) {
@@ -816,7 +820,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->logNh = (B->c - 1) - B->logNl;
   if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = n * B->W;
-  B->max_tasks0 = (uint32_t)((nW / S0_MAX > 196608 ? nW / S0_MAX : 196608) + B->nb + 1);  // pick_chunk keeps tasks below this
+  B->max_tasks0 = (uint32_t)((nW + pick_chunk(nW) - 1) / pick_chunk(nW) + ACCUM_RESIDENT_CHUNKS / 8 + B->nb + 1);  // msm_dev keeps tasks below this
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
@@ -910,13 +914,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   //   as: accumulation                   (never blocks s: NTTs queued on s meanwhile run beside it)
   //   tail stream: fold ... final, batched over the MSMs since the last join (flush_tails)
   hipStream_t hs = s, as = s;
-  const uint32_t s0 = pick_chunk(total);
-  uint32_t ls0 = 0;
-  while ((1u << ls0) < s0) ls0++;
+  uint32_t s0 = pick_chunk(total);
   // the partial buffers were sized at registration: never let an override (H2MI_MSM_S0) or a shorter
   // vector produce more tasks than they hold
-  while (ls0 < 6 && (((uint64_t)total + (1u << ls0) - 1) >> ls0) + nb > B->max_tasks0) ls0++;
-  if ((((uint64_t)total + (1u << ls0) - 1) >> ls0) + nb > B->max_tasks0) return H2MI_ERANGE;
+  while (s0 < S0_MAX && ((uint64_t)total + s0 - 1) / s0 + nb > B->max_tasks0) s0++;
+  if (((uint64_t)total + s0 - 1) / s0 + nb > B->max_tasks0) return H2MI_ERANGE;
   if (pipelined) {
     hs = ctx().head_stream;
     as = ctx().accum_stream;
@@ -988,7 +990,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.accum_pending = false;
   S.head_pending = false;
   H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
-            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, ls0, nb, S.vals[1], S.off, S.np[0], S.np[1]);
+            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0, nb, S.vals[1], S.off, S.np[0], S.np[1]);
   if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
     H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
               (const uint32_t*)nullptr);
@@ -996,7 +998,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
   }
-  const uint32_t chunks0 = (uint32_t)(((uint64_t)total + (1u << ls0) - 1) >> ls0);  // upper bound: zero digits leave no entry
+  const uint32_t chunks0 = (uint32_t)(((uint64_t)total + s0 - 1) / s0);  // upper bound: zero digits leave no entry
   const uint32_t tasks0 = chunks0 + nb;                                             // upper bound of the partial sums
   if (pipelined) {
     H2_HIP(hipEventRecord(S.head_done, hs));
@@ -1010,7 +1012,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.toff[0], nb, ls0, (const uint8_t*)B->table, S.part[0]);
+            (const uint32_t*)S.toff[0], nb, s0, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;
   S.tasks1 = tasks0 / S1 + nb;
   if (pipelined) {
