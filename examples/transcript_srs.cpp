@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     in.read((char*)sc.data(), (std::streamsize)ns * 32);
     if (!in) return 65;
 
-    transcript::Blake2bWrite tw;
+    auto tw = transcript::Blake2bWrite::init();
     for (auto& p : pts) tw.write_point(p);
     Fr c1 = tw.squeeze_challenge();
     for (auto& s : sc) tw.write_scalar(s);
@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     print_hex("challenge1", c1.l, 32);
     print_hex("challenge2", c2.l, 32);
 
-    transcript::Blake2bRead tr(proof);
+    auto tr = transcript::Blake2bRead::init(proof);
     bool ok = true;
     for (auto& p : pts) {
       G1Affine q = tr.read_point();

@@ -51,6 +51,11 @@ class Blake2bWrite(_Blake2bTranscript):
         super().__init__()
         self.writer = writer if writer is not None else io.BytesIO()
 
+    @classmethod
+    def init(cls, writer=None) -> "Blake2bWrite":
+        """TranscriptWriterBuffer::init, as the reference calls it: Blake2bWrite::<_, _, Challenge255<_>>::init(vec![])"""
+        return cls(writer)
+
     def write_point(self, affine) -> None:
         self.common_point(affine)
         self.writer.write(serde.g1_to_bytes(np.asarray(affine, dtype=np.uint64).reshape(1, 8)).tobytes())
@@ -67,6 +72,11 @@ class Blake2bRead(_Blake2bTranscript):
     def __init__(self, proof: bytes):
         super().__init__()
         self.reader = io.BytesIO(proof)
+
+    @classmethod
+    def init(cls, proof: bytes) -> "Blake2bRead":
+        """TranscriptReadBuffer::init: Blake2bRead::<_, _, Challenge255<_>>::init(&proof[..])"""
+        return cls(proof)
 
     def _take(self, n: int) -> bytes:
         b = self.reader.read(n)

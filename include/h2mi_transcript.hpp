@@ -145,6 +145,8 @@ class Blake2bBase {
 
 class Blake2bWrite : public Blake2bBase {
  public:
+  // TranscriptWriterBuffer::init — the reference writes Blake2bWrite::<_, _, Challenge255<_>>::init(vec![])
+  static Blake2bWrite init() { return Blake2bWrite(); }
   void write_point(const G1Affine& p) {
     common_point(p);
     auto b = serde::g1_to_bytes(p);
@@ -164,6 +166,8 @@ class Blake2bWrite : public Blake2bBase {
 class Blake2bRead : public Blake2bBase {
  public:
   explicit Blake2bRead(std::vector<uint8_t> proof) : proof_(std::move(proof)) {}
+  // TranscriptReadBuffer::init — Blake2bRead::<_, _, Challenge255<_>>::init(&proof[..])
+  static Blake2bRead init(std::vector<uint8_t> proof) { return Blake2bRead(std::move(proof)); }
   G1Affine read_point() {
     G1Affine p = serde::g1_from_bytes(take());
     common_point(p);

@@ -200,7 +200,7 @@ def test_transcript_write_read_round_trip_matches_oracle(gpu):
 
     pts = _rand_points(6, 3)
     evals = o.unpack(o.random_field_limbs(5, 4), o.R)
-    tw, to = T.Blake2bWrite(), fm.Blake2bTranscript()
+    tw, to = T.Blake2bWrite.init(), fm.Blake2bTranscript()
     chal_w, chal_o = [], []
     for p in pts[:3]:
         tw.write_point(o.pack_points([p])[0]); to.write_point(p)
@@ -214,7 +214,7 @@ def test_transcript_write_read_round_trip_matches_oracle(gpu):
     proof = tw.finalize()
     assert proof == bytes(to.proof) and len(proof) == 6 * 32 + 5 * 32
     assert [o.unpack(c.reshape(1, 4), o.R)[0] for c in chal_w] == chal_o
-    tr = T.Blake2bRead(proof)
+    tr = T.Blake2bRead.init(proof)
     got = [tr.read_point() for _ in range(3)]
     c0 = tr.squeeze_challenge()
     got += [tr.read_point() for _ in range(3)]
