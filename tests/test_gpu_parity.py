@@ -578,10 +578,11 @@ def test_cpp_host_example(gpu, k):
 
 
 def test_pipelined_msm_stress(gpu):
-    """the three-stage MSM pipeline (sort | accumulate | reduce on internal streams, two workspace slots per
-    handle) under an adversarial schedule: many MSMs back to back on two handles with varying lengths,
-    NTTs and scalar overwrites queued in between, joins at random points — every result must equal the
-    non-pipelined, fully synchronous evaluation of the same inputs bit for bit."""
+    """the MSM pipeline (partition | accumulate on internal streams, four workspace slots per handle, bucket
+    reductions deferred and batched at joins / when a slot is reused) under an adversarial schedule: many
+    MSMs back to back on two handles with varying lengths, NTTs and scalar overwrites queued in between,
+    joins at random points — every result must be the same group element as the non-pipelined, fully
+    synchronous evaluation of the same inputs."""
     rng = np.random.default_rng(2024)
     k = 15
     n = 1 << k
