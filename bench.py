@@ -12,8 +12,9 @@ linked (none can be built here), so gate evaluation / transcript / witness gener
 
 N > 1: one process per GPU; the total work is fixed ("strong" scaling): every rank owns a contiguous
 1/N slice of both base sets, runs each MSM on its slice and the 96-byte partial points are combined by
-an RCCL all-gather + fold; NTTs are replayed on every rank (NTT is single-GPU by design).
-Rank 0 prints ONE JSON line.
+an RCCL all-gather + fold; every NTT runs on one GPU (by design): a transform whose output feeds a later
+commitment is replayed by every rank, the others are spread round-robin over the ranks.
+Rank 0 prints ONE JSON line (the contract's fields plus `roofline`, `issue_roofline`, `cpu_baseline`).
 """
 import argparse
 import json
