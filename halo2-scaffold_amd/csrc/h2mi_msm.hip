@@ -66,6 +66,7 @@ struct Bases {
   size_t n = 0;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
+  uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
   size_t scan_tmp_bytes = 0, bin_scan_tmp_bytes = 0;
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
   Slot slot[NSLOT];
@@ -784,6 +785,7 @@ static uint32_t pick_chunk(size_t entries) {
 
 static void free_bases(Bases* B) {
   hipFree(B->table);
+  hipFree(B->host_stage);
   for (Slot& S : B->slot) {
     hipFree(S.vals[0]); hipFree(S.vals[1]);
     hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
@@ -1202,14 +1204,19 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (n > it->second->n) return H2MI_ERANGE;
   hipStream_t s = ctx().stream;
-  uint8_t* d = nullptr;
-  if (hipMalloc(&d, n * 32 + 96) != hipSuccess) rc = H2MI_ENOMEM;
+  Bases* B = it->second;
+  // staging buffer kept with the handle: a prover calls commit() many times per proof, and a device
+  // allocation + free of 32 MB per call costs as much as a tenth of the MSM itself
+  if (!B->host_stage && hipMalloc(&B->host_stage, B->n * 32 + 96) != hipSuccess) {
+    B->host_stage = nullptr;
+    rc = H2MI_ENOMEM;
+  }
+  uint8_t* d = B->host_stage;
   if (!rc && hipMemcpyAsync(d + 96, scalars, n * 32, hipMemcpyHostToDevice, s) != hipSuccess) rc = H2MI_EHIP;
   if (!rc) rc = msm_dev(it->second, d + 96, n, d, s);
   if (!rc) rc = msm_join_all(s);
   if (!rc && hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
   if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
-  if (d) hipFree(d);
   if (handle == 0) h2mi_bases_release(h);
   return rc;
 }

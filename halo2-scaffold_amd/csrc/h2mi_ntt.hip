@@ -730,16 +730,28 @@ int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4], 
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = ctx().stream;
   const size_t bytes = ((size_t)1 << log_n) * 32;
-  fe* d = nullptr;
-  hipError_t e = hipMalloc(&d, bytes);
-  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
-  H2_HIP(e);
+  // device staging kept between calls (grow-only, like the ping-pong scratch): EvaluationDomain calls this
+  // dozens of times per proof with two sizes
+  static fe* stage = nullptr;
+  static size_t stage_bytes = 0;
+  if (stage_bytes < bytes) {
+    if (stage) {
+      H2_HIP(hipStreamSynchronize(s));
+      hipFree(stage);
+      stage = nullptr;
+      stage_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&stage, bytes);
+    if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+    H2_HIP(e);
+    stage_bytes = bytes;
+  }
+  fe* d = stage;
   int rc = H2MI_OK;
   if (hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, s) != hipSuccess) rc = H2MI_EHIP;
   if (!rc) rc = ntt_dev(d, log_n, omega, pre, post, s);
   if (!rc && hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
   if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
-  hipFree(d);
   return rc;
 }
 
