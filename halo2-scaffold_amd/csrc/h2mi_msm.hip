@@ -13,10 +13,10 @@
 //    512 bins -> buckets; see "bucket partition" below) instead of a general key/value radix sort; global
 //    atomics are avoided: on gfx950 a device-scope atomic is a 64-B memory-side transaction (~24 G/s
 //    measured), far slower than staging through LDS;
-//  * bucket accumulation is load-balanced: a bucket's sorted run is cut into tasks of <= 64 points, one
-//    thread per task, mixed additions in XYZZ coordinates on 64-B gathered table points, so a hot
-//    bucket (witness columns full of 0/1) never serialises a wavefront; partial sums are folded by
-//    fixed-depth segmented levels;
+//  * bucket accumulation is load-balanced: the bucket-ordered entry array is cut into equal chunks of <= 128
+//    entries across bucket boundaries, one thread per chunk, mixed additions in XYZZ coordinates on 64-B
+//    gathered table points, so a hot bucket (witness columns full of 0/1) never serialises a wavefront and
+//    every lane does the same work; partial sums are folded by fixed-depth segmented levels;
 //  * the weighted bucket sum  sum_b (b+1) B_b  is done without long serial chains: row/column sums of
 //    the bucket matrix (LDS tree reductions), bit-decomposed weights, then <= 15 doublings.
 // All arithmetic is 254-bit integer work on v_mad_u64_u32; no MFMA (not a dense contraction).
@@ -31,7 +31,7 @@
 
 namespace h2 {
 
-constexpr uint32_t S0_MAX = 64;  // entries per accumulation chunk (smaller for small problems: see pick_chunk)
+constexpr uint32_t S0_MAX = 128;  // entries per accumulation chunk (smaller for small problems: see pick_chunk)
 constexpr uint32_t S1 = 8;       // partials per fold task
 constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
 
@@ -776,7 +776,7 @@ static uint32_t pick_window(size_t n) {
 constexpr size_t ACCUM_RESIDENT_CHUNKS = (size_t)256 * 2 * 256;
 static uint32_t pick_chunk(size_t entries) {
   const char* ev = getenv("H2MI_MSM_S0");
-  if (ev && atoi(ev) >= 1 && atoi(ev) <= 64) return (uint32_t)atoi(ev);
+  if (ev && atoi(ev) >= 1 && atoi(ev) <= (int)S0_MAX) return (uint32_t)atoi(ev);
   for (size_t rounds = 1;; rounds++) {
     size_t s0 = (entries + rounds * ACCUM_RESIDENT_CHUNKS - 1) / (rounds * ACCUM_RESIDENT_CHUNKS);
     if (s0 <= S0_MAX) return (uint32_t)(s0 < 8 ? 8 : s0);
