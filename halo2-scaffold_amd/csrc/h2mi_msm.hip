@@ -1044,7 +1044,7 @@ static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1
                         hipStream_t t) {
   // fold / finish: quads (4 lanes per point operation) while the grid stays latency-bound, single lanes beyond
   const bool force_lane = getenv("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
-  if (!force_lane && (uint64_t)max_tasks1 * count <= 49152) {
+  if (!force_lane && (uint64_t)max_tasks1 * count <= 65536) {
     H2_LAUNCH("k_msm_fold", k_msm_fold<true>, dim3(ceil_div_u32((uint64_t)max_tasks1 * 4, 256), count), 256, 0, t, tb);
   } else {
     H2_LAUNCH("k_msm_fold", k_msm_fold<false>, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
