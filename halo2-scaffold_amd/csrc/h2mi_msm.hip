@@ -31,9 +31,29 @@
 
 namespace h2 {
 
-constexpr uint32_t S0_MAX = 128;  // entries per accumulation chunk (smaller for small problems: see pick_chunk)
+constexpr uint32_t S0_MAX = 128;  // most entries per accumulation chunk (see accum_chunk_len)
 constexpr uint32_t S1 = 8;       // partials per fold task
 constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
+
+// Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
+// 256 threads per CU (the occupancy cap in msm_dev): ACCUM_RESIDENT_CHUNKS chunks run at once, all of the same
+// length, so the kernel's time is (rounds of resident chunks) x (chunk length).  The length is chosen so that the
+// chunks fill a whole number of rounds — with a power-of-two length a 2^18 / 2^19 slice ran 1.06 rounds, a
+// second, nearly empty round of full-length chains (0.45 / 0.88 ms instead of 0.36 / 0.67 ms) — and from the
+// number of entries the partition actually produced (known on the device only): the advice columns of a real
+// witness are mostly zero, and a length derived from n * W would leave a tenth of the threads with 128-entry
+// chains.  Up to 128 entries: at 2^20 one round of 128 costs what two rounds of 64 did and leaves half as many
+// partial sums to fold.
+constexpr uint32_t ACCUM_RESIDENT_CHUNKS = 256 * 2 * 256;
+__host__ __device__ inline uint32_t accum_rounds(uint32_t entries) {
+  const uint32_t per_round = S0_MAX * ACCUM_RESIDENT_CHUNKS;  // 2^24
+  return entries ? (entries + per_round - 1) / per_round : 1;
+}
+__host__ __device__ inline uint32_t accum_chunk_len(uint32_t entries) {
+  const uint32_t slots = accum_rounds(entries) * ACCUM_RESIDENT_CHUNKS;
+  const uint32_t s0 = (entries + slots - 1) / slots;
+  return s0 < 8 ? 8 : s0;
+}
 
 // per-call workspace; several slots per handle so that consecutive MSMs overlap (partition of one beside
 // the accumulation of another) and their bucket reductions can be deferred and run as one batch.
@@ -45,6 +65,7 @@ struct Slot {
   void* bin_scan_tmp = nullptr;
   uint32_t* binseg = nullptr;   // sums of the SCAN_SEG_BINS-cell segments of bincnt
   uint32_t* off = nullptr;      // first entry of each bucket in vals[1] (nb+1; last = number of entries)
+  uint32_t* s0_dev = nullptr;   // chunk length of this MSM's accumulation (chosen by k_msm_bin_sort)
   uint32_t* np[2] = {nullptr, nullptr};    // per bucket: partial sums the accumulation leaves, fold tasks (nb+1 entries, last = 0)
   uint32_t* toff[2] = {nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
   void* scan_tmp = nullptr;
@@ -274,8 +295,8 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
 
 constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 512 bins)
 __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
-                                                             uint32_t nbins, uint32_t lb, uint32_t s0, uint32_t nb, uint32_t* vals_out,
-                                                             uint32_t* off, uint32_t* np0, uint32_t* np1) {
+                                                             uint32_t nbins, uint32_t lb, uint32_t s0_fixed, uint32_t nb, uint32_t* vals_out,
+                                                             uint32_t* off, uint32_t* np0, uint32_t* np1, uint32_t* s0_out) {
   __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
   __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
   __shared__ uint32_t stage[P2_CH];
@@ -283,6 +304,8 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
   const uint32_t tid = threadIdx.x, wave = tid >> 6, bin = blockIdx.x;
   const uint32_t start = base[(size_t)bin * ntiles], end = base[(size_t)(bin + 1) * ntiles];
   const uint32_t nq = 1u << lb;
+  const uint32_t entries = base[(size_t)nbins * ntiles];
+  const uint32_t s0 = s0_fixed ? s0_fixed : accum_chunk_len(entries);  // every workgroup derives the same value
   for (uint32_t j = tid; j < (P2_THREADS / 64) * NQ_MAX; j += P2_THREADS) (&wh[0][0])[j] = 0;
   __syncthreads();
   // 16 keys per load; the buffer is padded so that the aligned window may overhang [start, end)
@@ -319,9 +342,10 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
       np1[b] = (f0 + S1 - 1) / S1;
     }
     if (bin == 0 && tid == 0) {  // entry nb: end of the sorted array; the task scans leave their totals there
-      off[nb] = base[(size_t)nbins * ntiles];
+      off[nb] = entries;
       np0[nb] = 0;
       np1[nb] = 0;
+      *s0_out = s0;
     }
   }
   __syncthreads();
@@ -494,10 +518,11 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
 // partial sums are numbered in array order, so bucket b owns np0[b] = 1 + (#chunk starts strictly inside
 // its run) consecutive partials starting at toff[b] (the exclusive scan of np0) — the layout the fold
 // expects.  Gathers table points (64 B), mixed additions in the lazy 29-bit-limb representation.
-__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb, uint32_t s0,
-                                                    const uint8_t* table, uint8_t* part) {
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb,
+                                                    const uint32_t* s0_dev, const uint8_t* table, uint8_t* part) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = off[nb];
+  const uint32_t s0 = *s0_dev;
   if ((uint64_t)t * s0 >= total) return;
   const uint32_t start = t * s0;
   const uint32_t end = min(start + s0, total);
@@ -768,19 +793,10 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
-// Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
-// 256 threads per CU (see the occupancy cap in msm_dev): 131072 chunks run at once, all of the same length, so
-// the kernel's time is (rounds of 131072 chunks) x (chunk length).  The length is chosen so that the chunks fill
-// a whole number of rounds: with a power-of-two length a 2^18 / 2^19 slice ran 1.06 rounds — a second, nearly
-// empty round of full-length chains (0.45 / 0.88 ms instead of 0.30 / 0.59 ms).
-constexpr size_t ACCUM_RESIDENT_CHUNKS = (size_t)256 * 2 * 256;
-static uint32_t pick_chunk(size_t entries) {
+// H2MI_MSM_S0 fixes the chunk length (tuning / tests); 0 = chosen on the device from the entry count
+static uint32_t chunk_override() {
   const char* ev = getenv("H2MI_MSM_S0");
-  if (ev && atoi(ev) >= 1 && atoi(ev) <= (int)S0_MAX) return (uint32_t)atoi(ev);
-  for (size_t rounds = 1;; rounds++) {
-    size_t s0 = (entries + rounds * ACCUM_RESIDENT_CHUNKS - 1) / (rounds * ACCUM_RESIDENT_CHUNKS);
-    if (s0 <= S0_MAX) return (uint32_t)(s0 < 8 ? 8 : s0);
-  }
+  return (ev && atoi(ev) >= 1 && atoi(ev) <= (int)S0_MAX) ? (uint32_t)atoi(ev) : 0u;
 }
 
 static void free_bases(Bases* B) {
@@ -789,7 +805,7 @@ static void free_bases(Bases* B) {
   for (Slot& S : B->slot) {
     hipFree(S.vals[0]); hipFree(S.vals[1]);
     hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
-    hipFree(S.off);
+    hipFree(S.off); hipFree(S.s0_dev);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.scan_tmp); hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
@@ -822,7 +838,8 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->logNh = (B->c - 1) - B->logNl;
   if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = n * B->W;
-  B->max_tasks0 = (uint32_t)((nW + pick_chunk(nW) - 1) / pick_chunk(nW) + ACCUM_RESIDENT_CHUNKS / 8 + B->nb + 1);  // msm_dev keeps tasks below this
+  // partial sums of one accumulation: one per chunk (at most whole rounds of the resident grid) + one per bucket
+  B->max_tasks0 = accum_rounds((uint32_t)nW) * ACCUM_RESIDENT_CHUNKS + B->nb + 1;
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
@@ -846,6 +863,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.bin_scan_tmp, B->bin_scan_tmp_bytes ? B->bin_scan_tmp_bytes : 16);
     H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
+    H2_ALLOC(S.s0_dev, 4);
     for (int i = 0; i < 2; i++) {
       H2_ALLOC(S.np[i], (size_t)(B->nb + 1) * 4);
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
@@ -916,11 +934,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   //   as: accumulation                   (never blocks s: NTTs queued on s meanwhile run beside it)
   //   tail stream: fold ... final, batched over the MSMs since the last join (flush_tails)
   hipStream_t hs = s, as = s;
-  uint32_t s0 = pick_chunk(total);
-  // the partial buffers were sized at registration: never let an override (H2MI_MSM_S0) or a shorter
-  // vector produce more tasks than they hold
-  while (s0 < S0_MAX && ((uint64_t)total + s0 - 1) / s0 + nb > B->max_tasks0) s0++;
-  if (((uint64_t)total + s0 - 1) / s0 + nb > B->max_tasks0) return H2MI_ERANGE;
+  // chunk length: chosen by k_msm_bin_sort from the entry count unless H2MI_MSM_S0 fixes it; the partial buffers
+  // were sized at registration, so an override must not produce more chunks than they hold
+  uint32_t s0_fixed = chunk_override();
+  while (s0_fixed && s0_fixed < S0_MAX && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) s0_fixed++;
+  if (s0_fixed && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) return H2MI_ERANGE;
   if (pipelined) {
     hs = ctx().head_stream;
     as = ctx().accum_stream;
@@ -992,7 +1010,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.accum_pending = false;
   S.head_pending = false;
   H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
-            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0, nb, S.vals[1], S.off, S.np[0], S.np[1]);
+            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0_fixed, nb, S.vals[1], S.off, S.np[0], S.np[1], S.s0_dev);
   if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
     H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
               (const uint32_t*)nullptr);
@@ -1000,7 +1018,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
     H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
   }
-  const uint32_t chunks0 = (uint32_t)(((uint64_t)total + s0 - 1) / s0);  // upper bound: zero digits leave no entry
+  // upper bound of the chunks (zero digits leave no entry): whole rounds of the resident grid, or total / override
+  const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : accum_rounds(total) * ACCUM_RESIDENT_CHUNKS;
   const uint32_t tasks0 = chunks0 + nb;                                             // upper bound of the partial sums
   if (pipelined) {
     H2_HIP(hipEventRecord(S.head_done, hs));
@@ -1014,7 +1033,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.toff[0], nb, s0, (const uint8_t*)B->table, S.part[0]);
+            (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;
   S.tasks1 = tasks0 / S1 + nb;
   if (pipelined) {
