@@ -34,6 +34,7 @@ namespace h2 {
 constexpr uint32_t S0_MAX = 128;  // most entries per accumulation chunk (see accum_chunk_len)
 constexpr uint32_t S1 = 8;       // partials per fold task
 constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
+constexpr uint32_t HOT_MIN = 64; // a bucket with more folded partials than this gets a whole workgroup (k_msm_finish_hot)
 
 // Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
 // 256 threads per CU (the occupancy cap in msm_dev): ACCUM_RESIDENT_CHUNKS chunks run at once, all of the same
@@ -629,8 +630,11 @@ __global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
   const uint32_t b = worker / FG, l = worker % FG;
   if ((blockIdx.x * blockDim.x >> LW) / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
   xyzz29 acc = xyzz29_identity();
+  bool hot = false;
   if (b < nb) {
     uint32_t cnt = d.np1[b], s = d.toff1[b];
+    hot = cnt > HOT_MIN;  // left to k_msm_finish_hot (8 workers would each chain cnt / 8 additions)
+    if (hot) cnt = 0;
     for (uint32_t k = l; k < cnt; k += FG) {
       xyzz29 p = part_load(d.part1 + (size_t)(s + k) * PART_BYTES);
       if (QUAD) acc = xyzz29_add_quad(acc, p);
@@ -644,7 +648,7 @@ __global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
       else xyzz29_add(acc, o);
     }
   }
-  if (b < nb && l == 0 && (!QUAD || (threadIdx.x & 3u) == 0)) part_store(d.dense + (size_t)b * PART_BYTES, acc);
+  if (b < nb && !hot && l == 0 && (!QUAD || (threadIdx.x & 3u) == 0)) part_store(d.dense + (size_t)b * PART_BYTES, acc);
 }
 
 // block-wide tree sum of up to 256 XYZZ values held in LDS, one quad per pair
@@ -655,6 +659,33 @@ __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2)
       xyzz29 r = xyzz29_add_quad(lds[g], lds[g + s]);
       if ((threadIdx.x & 3u) == 0) lds[g] = r;
     }
+    __syncthreads();
+  }
+}
+
+// hot buckets (the 0 / 1 buckets of sparse witness columns: hundreds of folded partials): a whole workgroup of
+// 64 quads per bucket — each quad chains cnt / 64 additions, then a 6-level tree — instead of 8 workers chaining
+// cnt / 8.  A workgroup scans 256 buckets for hot ones (none in the uniform case: it returns after one load).
+__global__ void __launch_bounds__(256) k_msm_finish_hot(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
+  __shared__ uint32_t hot_list[256], nhot;
+  const uint32_t tid = threadIdx.x, quad = tid >> 2;
+  const uint32_t b = blockIdx.x * 256 + tid;
+  if (tid == 0) nhot = 0;
+  __syncthreads();
+  if (b < d.nb && d.np1[b] > HOT_MIN) hot_list[atomicAdd(&nhot, 1u)] = b;
+  __syncthreads();
+  const uint32_t n_hot = nhot;
+  xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
+  for (uint32_t h = 0; h < n_hot; h++) {
+    const uint32_t hb = hot_list[h];
+    const uint32_t cnt = d.np1[hb], s = d.toff1[hb];
+    xyzz29 acc = xyzz29_identity();
+    for (uint32_t k = quad; k < cnt; k += 64) acc = xyzz29_add_quad(acc, part_load(d.part1 + (size_t)(s + k) * PART_BYTES));
+    if ((tid & 3u) == 0) lds[quad] = acc;
+    __syncthreads();
+    block_tree_sum(lds, 64);
+    if (tid == 0) part_store(d.dense + (size_t)hb * PART_BYTES, lds[0]);
     __syncthreads();
   }
 }
@@ -1073,6 +1104,7 @@ static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1
   } else {
     H2_LAUNCH("k_msm_finish", k_msm_finish<false>, dim3(ceil_div_u32((uint64_t)max_nb * FG, 256), count), 256, 0, t, tb);
   }
+  H2_LAUNCH("k_msm_hot_finish", k_msm_finish_hot, dim3(ceil_div_u32(max_nb, 256), count), 256, 64 * PART_BYTES, t, tb);
   H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3((1u << max_logNh) + (1u << max_logNl), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
   H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1, count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
   H2_LAUNCH("k_msm_final", k_msm_final, count, 128, 32 * PART_BYTES, t, tb);
