@@ -58,10 +58,12 @@ int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int h2mi_memset_zero(void* d_ptr, size_t bytes); /* asynchronous on the library's stream */
 int h2mi_sync(void); /* wait for all work queued on the library's streams */
-/* device-side join: later work on the library's stream waits for every MSM queued so far to be complete
- * (MSMs on the library's stream run their bucket-reduction tail concurrently with the next call; results
- * are complete after h2mi_join / h2mi_sync / h2mi_memcpy_d2h).  A prover calls it where the transcript
- * needs the commitments of a phase. */
+/* device-side join: later work on the library's stream waits for every MSM queued so far to be complete.
+ * An MSM queued on the library's stream (h2mi_msm_bn254_g1_dev with stream = NULL) only runs its bucket
+ * partition and accumulation at once; the latency-bound bucket reduction is deferred and run for all MSMs
+ * queued since the last join as one batch, so the 96-byte results are written only by h2mi_join / h2mi_sync /
+ * h2mi_memcpy_d2h (or when eight reductions are pending).  A prover calls h2mi_join where the transcript
+ * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream. */
 int h2mi_join(void);
 
 /* ---- bases (the KZG SRS): ParamsKZG::{g, g_lagrange}, SURVEY.md 8a row a5 ------------------------
