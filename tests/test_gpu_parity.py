@@ -741,8 +741,9 @@ def test_no_device_memory_leak(gpu):
 
 
 def test_bench_world2_rehearsal_matches_single_gpu(gpu):
-    """the N > 1 path of bench.py (slice registration, per-rank replay, all-gather + fold) with two ranks sharing
-    this GPU over gloo: the proof's commitments must hash to the same digest as the single-process run."""
+    """the N > 1 path of bench.py (slice registration, per-rank replay, all-gather + fold) with two and with four
+    ranks sharing this GPU over gloo: the proof's commitments must hash to the same digest as the single-process
+    run; then the same code path over RCCL with a single rank."""
     import json
     import socket
     import subprocess
@@ -765,6 +766,17 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm-slice2" and two["scaling"] == "strong"
     assert two["commitments_sha256"] == one["commitments_sha256"]
+    # four ranks (slices of a quarter, leaf transforms spread over four owners): 4 + this process stay below the
+    # box's limit of 6 GPU processes
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port4 = s.getsockname()[1]
+    cmd4 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+            "--master-port", str(port4)] + common + ["--gpus", "4"]
+    r4 = subprocess.run(cmd4, cwd=root, capture_output=True, text=True, timeout=900, env=env2)
+    assert r4.returncode == 0, r4.stdout[-1000:] + r4.stderr[-2000:]
+    four = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert four["n_gpus"] == 4 and four["commitments_sha256"] == one["commitments_sha256"]
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert key in two and key in one
     # the same code path over RCCL ("nccl" backend) with a single rank: process group on the GPU, device
