@@ -169,8 +169,11 @@ int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affi
 /* out[i] = base^i for i < n (the powers-of-s vector of ParamsKZG::setup), Montgomery in and out */
 int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_stream_t stream);
 
-/* ---- wire encodings: what create_proof writes to the transcript and what
- * ParamsKZG::{write,read} keep on disk.  Conventions restated from halo2curves 0.3.x [RECALL, see
+/* ---- wire encodings: what create_proof writes to the transcript (reference call sites:
+ * Blake2bWrite::init / finalize around create_proof, examples/standard_plonk.rs:40-50 and src/scaffold.rs:190-200,
+ * 321-332; Blake2bRead::init for verify_proof, examples/standard_plonk.rs:56, src/scaffold.rs:221,352) and what
+ * ParamsKZG::{write,read} keep on disk (the SRS the scaffold obtains through gen_srs, src/scaffold.rs:119,174,271,
+ * cached under params/, .gitignore:17-18).  Conventions restated from halo2curves 0.3.x [RECALL, see
  * csrc/h2mi_serde.hip]: field elements as 32 little-endian canonical bytes (Fr::to_repr); G1Affine as 32
  * bytes = x with flags in byte 31 (0x40: y odd, 0x80: point at infinity).  field: 0 = Fq, 1 = Fr.
  * The *_from_* / decompress forms report the number of invalid encodings (>= modulus, not on the curve,
