@@ -279,4 +279,47 @@ __device__ __noinline__ fe fe_inv(const fe& a) {
   return r;
 }
 
+// a^-1 by the binary extended Euclidean algorithm: ~2 * 254 shift / subtract rounds of 256-bit integer work
+// instead of ~380 dependent multiplications — for the places where ONE inversion sits on a latency-critical
+// path (a lone lane: ~50 us against ~500 us for fe_inv).  Montgomery in and out; inv(0) = 0.  Not constant time.
+template <class F>
+__device__ __noinline__ fe fe_inv_gcd(const fe& a_mont) {
+  if (fe_is_zero(a_mont)) return a_mont;
+  const fe p = fe_const<F>(F::MOD);
+  auto is_one = [](const fe& x) {
+    uint32_t o = x.v[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; i++) o |= x.v[i];
+    return o == 0;
+  };
+  auto shr1 = [](fe& x, uint32_t top) {  // x = (top : x) >> 1
+#pragma unroll
+    for (int i = 0; i < 7; i++) x.v[i] = (x.v[i] >> 1) | (x.v[i + 1] << 31);
+    x.v[7] = (x.v[7] >> 1) | (top << 31);
+  };
+  auto halve_mod = [&](fe& x) {  // x / 2 mod p for x < p
+    uint32_t carry = 0;
+    if (x.v[0] & 1u) x = raw_add(x, p, carry);
+    shr1(x, carry);
+  };
+  fe u = a_mont, v = p, x1 = fe_zero(), x2 = fe_zero();
+  x1.v[0] = 1;
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u.v[0] & 1u)) { shr1(u, 0); halve_mod(x1); }
+    while (!(v.v[0] & 1u)) { shr1(v, 0); halve_mod(x2); }
+    uint32_t borrow;
+    fe d = raw_sub(u, v, borrow);
+    if (!borrow) {  // u >= v
+      u = d;
+      x1 = fe_sub<F>(x1, x2);
+    } else {
+      v = raw_sub(v, u, borrow);
+      x2 = fe_sub<F>(x2, x1);
+    }
+  }
+  fe r = is_one(u) ? x1 : x2;  // (a R)^-1 as a plain integer: a^-1 R^-1
+  const fe r2 = fe_const<F>(F::R2);
+  return fe_mul<F>(fe_mul<F>(r, r2), r2);  // * R^2 -> a^-1 R
+}
+
 }  // namespace h2

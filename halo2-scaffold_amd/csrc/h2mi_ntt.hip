@@ -478,6 +478,124 @@ static hipEvent_t g_tmp_event = nullptr;
 static hipStream_t g_tmp_stream = nullptr;
 static bool g_tmp_used = false;
 
+// ---- permutation argument: the grand-product column z -------------------------------------
+// create_proof builds, per chunk of columns, z[0] = start, z[i+1] = z[i] * prod_j (v_j[i] + beta delta^j omega^i
+// + gamma) / prod_j (v_j[i] + beta sigma_j[i] + gamma) over the usable rows (plonk/permutation/prover.rs
+// [RECALL], restated in oracle/plonk.py).  On the device: numerators / denominators per row, ONE field inversion
+// for the whole column (prefix and suffix products of the denominators), then a prefix product of the ratios.
+// Multiplicative scans over Fr in tiles of 1024 (local scan, scan of the tile totals, apply), forward or reverse.
+constexpr uint32_t MS_TILE = 1024;
+__global__ void __launch_bounds__(256) k_mulscan_local(const fe* in, size_t n, int reverse, fe* local, fe* totals) {
+  __shared__ fe tile[MS_TILE];
+  __shared__ fe tprod[256];
+  const uint32_t tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * MS_TILE;
+  for (uint32_t r = 0; r < 4; r++) {  // logical position j; physical index n-1-j for a suffix scan
+    size_t j = base + tid + 256 * r;
+    tile[tid + 256 * r] = j < n ? fe_load(&in[reverse ? n - 1 - j : j]) : fe_one<Fr>();
+  }
+  __syncthreads();
+  fe p0 = tile[4 * tid], p1 = fe_mul<Fr>(p0, tile[4 * tid + 1]), p2 = fe_mul<Fr>(p1, tile[4 * tid + 2]), p3 = fe_mul<Fr>(p2, tile[4 * tid + 3]);
+  tprod[tid] = p3;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan of the 256 thread products (Hillis-Steele)
+    fe v = fe_one<Fr>();
+    if (tid >= d) v = tprod[tid - d];
+    __syncthreads();
+    tprod[tid] = fe_mul<Fr>(tprod[tid], v);
+    __syncthreads();
+  }
+  const fe left = tid ? tprod[tid - 1] : fe_one<Fr>();
+  __syncthreads();
+  tile[4 * tid] = fe_mul<Fr>(left, p0);
+  tile[4 * tid + 1] = fe_mul<Fr>(left, p1);
+  tile[4 * tid + 2] = fe_mul<Fr>(left, p2);
+  tile[4 * tid + 3] = fe_mul<Fr>(left, p3);
+  __syncthreads();
+  for (uint32_t r = 0; r < 4; r++) {
+    size_t j = base + tid + 256 * r;
+    if (j < n) fe_store(&local[reverse ? n - 1 - j : j], tile[tid + 256 * r]);
+  }
+  if (tid == 255) fe_store(&totals[blockIdx.x], tile[MS_TILE - 1]);
+}
+// exclusive scan of the tile totals (single workgroup, chunks of 256 with a running carry)
+__global__ void __launch_bounds__(256) k_mulscan_offsets(const fe* totals, uint32_t nblocks, fe* offsets) {
+  __shared__ fe tprod[256];
+  const uint32_t tid = threadIdx.x;
+  fe carry = fe_one<Fr>();
+  for (uint32_t c0 = 0; c0 < nblocks; c0 += 256) {
+    const uint32_t b = c0 + tid;
+    const fe mine = b < nblocks ? fe_load(&totals[b]) : fe_one<Fr>();
+    tprod[tid] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      fe v = fe_one<Fr>();
+      if (tid >= d) v = tprod[tid - d];
+      __syncthreads();
+      tprod[tid] = fe_mul<Fr>(tprod[tid], v);
+      __syncthreads();
+    }
+    const fe excl = fe_mul<Fr>(carry, tid ? tprod[tid - 1] : fe_one<Fr>());
+    if (b < nblocks) fe_store(&offsets[b], excl);
+    carry = fe_mul<Fr>(carry, tprod[255]);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_mulscan_apply(fe* local, const fe* offsets, size_t n, int reverse) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || j < MS_TILE) return;  // the first tile has offset one
+  fe* p = &local[reverse ? n - 1 - j : j];
+  fe_store(p, fe_mul<Fr>(fe_load(p), fe_load(&offsets[j / MS_TILE])));
+}
+
+struct PermArgs {
+  const fe* value[8];
+  const fe* sigma[8];
+  fe beta_delta[8];  // beta * delta^(column index), Mont256
+  fe beta, gamma;
+  uint32_t m;
+};
+// rows i < u: num = prod_j (v_j + beta delta^j omega^i + gamma), den = prod_j (v_j + beta sigma_j + gamma); one beyond
+__global__ void __launch_bounds__(256) k_perm_numden(PermArgs a, size_t n, uint32_t u, const fe* wlo, const fe* whi, uint32_t wh, fe* num, fe* den) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe pn = fe_one<Fr>(), pd = fe_one<Fr>();
+  if (i < u) {
+    const f29 w = pow2tab(wlo, whi, wh, (uint32_t)i);  // omega^i (Mont261)
+    for (uint32_t j = 0; j < a.m; j++) {
+      const fe v = fe_load(&a.value[j][i]);
+      fe idt;
+      f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_unpack(a.beta_delta[j].v), w)), idt.v);  // beta delta^j omega^i (Mont256)
+      const fe vg = fe_add<Fr>(v, a.gamma);
+      pn = fe_mul<Fr>(pn, fe_add<Fr>(vg, idt));
+      pd = fe_mul<Fr>(pd, fe_add<Fr>(vg, fe_mul<Fr>(a.beta, fe_load(&a.sigma[j][i]))));
+    }
+  }
+  fe_store(&num[i], pn);
+  fe_store(&den[i], pd);
+}
+__global__ void k_fr_inv_one(const fe* in, fe* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(out, fe_inv_gcd<Fr>(fe_load(in)));  // one inversion on the critical path
+}
+// ratio_i = num_i / den_i = num_i * P_(i-1) * S_(i+1) / P_(n-1)   (P, S: prefix / suffix products of den)
+__global__ void __launch_bounds__(256) k_perm_ratio(const fe* num, const fe* P, const fe* S, const fe* inv_total, size_t n, fe* ratio) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe r = fe_mul<Fr>(fe_load(&num[i]), fe_load(inv_total));
+  if (i) r = fe_mul<Fr>(r, fe_load(&P[i - 1]));
+  if (i + 1 < n) r = fe_mul<Fr>(r, fe_load(&S[i + 1]));
+  fe_store(&ratio[i], r);
+}
+// z[0] = start, z[i+1] = start * R_i for i < u (R: inclusive prefix products of the ratios); rows beyond u untouched
+__global__ void __launch_bounds__(256) k_perm_write(const fe* R, const fe* start_or_null, uint32_t u, fe* z, fe* last_or_null) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > u) return;
+  const fe st = start_or_null ? fe_load(start_or_null) : fe_one<Fr>();
+  const fe v = i ? fe_mul<Fr>(st, fe_load(&R[i - 1])) : st;
+  fe_store(&z[i], v);
+  if (i == u && last_or_null) fe_store(last_or_null, v);
+}
+
 static fe host_fe(const uint64_t w[4]) {
   fe r;
   memcpy(r.v, w, 32);
@@ -854,6 +972,66 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, siz
   return H2MI_OK;
 }
 
+
+// inclusive multiplicative scan of n elements, in place in `data` (forward prefix or reverse suffix)
+static int mulscan(fe* data, size_t n, int reverse, fe* totals, fe* offsets, hipStream_t s) {
+  const uint32_t nblocks = ceil_div_u32(n, MS_TILE);
+  H2_LAUNCH("k_mulscan_local", k_mulscan_local, nblocks, 256, 0, s, (const fe*)data, n, reverse, data, totals);
+  if (nblocks > 1) {
+    H2_LAUNCH("k_mulscan_offsets", k_mulscan_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
+    H2_LAUNCH("k_mulscan_apply", k_mulscan_apply, ceil_div_u32(n, 256), 256, 0, s, data, (const fe*)offsets, n, reverse);
+  }
+  return H2MI_OK;
+}
+
+int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t k, uint32_t usable_rows,
+                                       const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows, const uint64_t omega[4],
+                                       const void* d_start_or_null, void* d_z, void* d_last_or_null, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8) return H2MI_EINVAL;
+  if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  const size_t n = (size_t)1 << k;
+  PermArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = m;
+  a.beta = host_fe(beta);
+  a.gamma = host_fe(gamma);
+  for (uint32_t j = 0; j < m; j++) {
+    if (!d_values[j] || !d_sigmas[j]) return H2MI_EINVAL;
+    a.value[j] = (const fe*)d_values[j];
+    a.sigma[j] = (const fe*)d_sigmas[j];
+    a.beta_delta[j] = host_fe(beta_delta_pows + 4 * j);
+  }
+  PowTab pw;
+  int rc = get_powtab(omega, k, s, &pw);
+  if (rc) return rc;
+  // scratch (the transforms' shared, stream-ordered buffer): num, P (prefix of den), S (suffix of den), tile
+  // totals / offsets, the inverse of the total
+  const uint32_t nblocks = ceil_div_u32(n, MS_TILE);
+  rc = ensure_tmp(3 * n + 2 * (size_t)nblocks + 2, s);
+  if (rc) return rc;
+  fe* num = g_tmp;
+  fe* P = num + n;
+  fe* S = P + n;
+  fe* totals = S + n;
+  fe* offsets = totals + nblocks;
+  fe* inv_total = offsets + nblocks;
+  H2_LAUNCH("k_perm_numden", k_perm_numden, ceil_div_u32(n, 256), 256, 0, s, a, n, usable_rows, (const fe*)pw.lo, (const fe*)pw.hi, pw.h, num, P);
+  H2_HIP(hipMemcpyAsync(S, P, n * 32, hipMemcpyDeviceToDevice, s));
+  rc = mulscan(P, n, 0, totals, offsets, s);
+  if (!rc) rc = mulscan(S, n, 1, totals, offsets, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_fr_inv_one", k_fr_inv_one, 1, 64, 0, s, (const fe*)(P + (n - 1)), inv_total);
+  // the ratios overwrite num; their prefix products then give z
+  H2_LAUNCH("k_perm_ratio", k_perm_ratio, ceil_div_u32(n, 256), 256, 0, s, (const fe*)num, (const fe*)P, (const fe*)S, (const fe*)inv_total, n, num);
+  rc = mulscan(num, n, 0, totals, offsets, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_perm_write", k_perm_write, ceil_div_u32((uint64_t)usable_rows + 1, 256), 256, 0, s, (const fe*)num, (const fe*)d_start_or_null, usable_rows,
+            (fe*)d_z, (fe*)d_last_or_null);
+  return release_tmp(s);
+}
 
 int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,
                                        const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4],

@@ -51,3 +51,22 @@ def evaluate_h(domain: EvaluationDomain, advice, fixed, sigma, z, l0: DevBuf, l_
     args = [m(beta), m(gamma), m(y), m(FR_DELTA), m(domain.g_coset), m(domain.extended_omega)]
     check(lib.h2mi_plonk_evaluate_h_standard_dev(C.byref(cs), domain.k, domain.extended_k, BLINDING_FACTORS, *[a.ctypes.data for a in args],
                                                  t_inv.ctypes.data, out.ptr, stream), "evaluate_h")
+
+
+def permutation_product(k: int, values, sigmas, column_indices, beta: int, gamma: int, usable_rows: int, d_z: DevBuf,
+                        d_start: DevBuf = None, d_last: DevBuf = None) -> None:
+    """One chunk of the permutation argument's grand product on the device (plonk/permutation/prover.rs): fills
+    d_z[0 .. usable_rows] from the chunk's columns (`values`, Lagrange basis) and their permutation columns
+    (`sigmas`); `column_indices[j]` is column j's position in the argument (its identity image is
+    delta^index * omega^row).  The blinding rows of d_z are left as the caller set them."""
+    m = len(values)
+    assert m == len(sigmas) == len(column_indices) and 1 <= m <= 8
+    r = F.FR_MODULUS
+    vp = (C.c_void_p * m)(*[b.ptr for b in values])
+    sp = (C.c_void_p * m)(*[b.ptr for b in sigmas])
+    bd = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(beta * pow(FR_DELTA, int(c), r) % r) for c in column_indices]))
+    b_, g_ = F.fr_to_mont_limbs(beta), F.fr_to_mont_limbs(gamma)
+    w = F.fr_to_mont_limbs(F.omega_for(k))
+    check(lib.h2mi_plonk_permutation_product_dev(vp, sp, m, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data, w.ctypes.data,
+                                                 d_start.ptr if d_start is not None else None, d_z.ptr,
+                                                 d_last.ptr if d_last is not None else None, None), "permutation_product")

@@ -162,6 +162,18 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* cosets,
                                        const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
                                        void* d_h_out, h2mi_stream_t stream);
 
+/* the permutation argument's grand-product column for one chunk of m <= 8 columns (plonk/permutation/prover.rs,
+ * the z vectors are produced where they are consumed): z[0] = start (one if NULL),
+ *   z[i+1] = z[i] * prod_j (v_j[i] + beta delta^(c_j) omega^i + gamma) / prod_j (v_j[i] + beta sigma_j[i] + gamma),  i < usable_rows;
+ * rows usable_rows+1 .. 2^k-1 of d_z (the blinding rows) are left untouched; z[usable_rows] also goes to d_last
+ * (32 B, device) as the next chunk's start.  beta_delta_pows[j] = beta * delta^(index of column j in the argument).
+ * One field inversion per call (prefix / suffix products of the denominators); a zero denominator makes the
+ * result meaningless, where the crate would panic.  Asynchronous on `stream`. */
+int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t k,
+                                       uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4],
+                                       const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4],
+                                       const void* d_start_or_null, void* d_z, void* d_last_or_null, h2mi_stream_t stream);
+
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
  * generator (1, 2) with on-device normalisation. */

@@ -700,6 +700,71 @@ def test_evaluate_h_standard_plonk(gpu, k):
     assert P.check_quotient_identity(inst, zs, hc[: inst.n * (P.CS_DEGREE - 1)], beta, gamma, y, x)
 
 
+@pytest.mark.parametrize("k", [4, 7, 11, 13])
+def test_permutation_product_matches_oracle(gpu, k):
+    """the grand-product columns z_0, z_1, z_2 of the StandardPlonk permutation argument (chunks of one column,
+    each starting where the previous one ended) against the oracle's row-by-row construction; blinding rows
+    are the caller's and stay untouched; then a chunk of two columns against the big-integer formula."""
+    from oracle import plonk as P
+    from halo2_scaffold_amd import plonk as gp
+
+    inst = P.StandardPlonkInstance(k, 0x1234 + k, seed=k)
+    beta, gamma = 0xBE7A + k, 0x6A33A
+    zs = inst.permutation_products(beta, gamma)
+    n, u = inst.n, inst.u
+    adv = [gpu.DevBuf.from_numpy(o.pack(c, o.R)) for c in inst.advice]
+    sig = [gpu.DevBuf.from_numpy(o.pack(c, o.R)) for c in inst.sigma]
+    last = gpu.DevBuf(32)
+    for mcol in range(3):
+        init = list(zs[mcol])
+        for i in range(u + 1):
+            init[i] = 0xDEAD  # must be overwritten
+        dz = gpu.DevBuf.from_numpy(o.pack(init, o.R))
+        gp.permutation_product(k, [adv[mcol]], [sig[mcol]], [mcol], beta, gamma, u, dz, d_start=last if mcol else None, d_last=last)
+        assert o.unpack(dz.to_numpy(shape=(n, 4)), o.R) == zs[mcol]
+        assert o.unpack(last.to_numpy(shape=(1, 4)), o.R) == [zs[mcol][u]]
+        dz.free()
+    # two columns in one chunk (a constraint system of higher degree): direct formula
+    dz = gpu.DevBuf.from_numpy(np.zeros((n, 4), dtype=np.uint64))
+    gp.permutation_product(k, adv[:2], sig[:2], [0, 1], beta, gamma, u, dz)
+    z = [1]
+    for i in range(u):
+        num = den = 1
+        for j in range(2):
+            v = inst.advice[j][i]
+            num = num * ((v + beta * pow(P.FR_DELTA, j, o.R) * inst.omega_pows[i] + gamma) % o.R) % o.R
+            den = den * ((v + beta * inst.sigma[j][i] + gamma) % o.R) % o.R
+        z.append(z[-1] * num % o.R * pow(den, -1, o.R) % o.R)
+    assert o.unpack(dz.to_numpy(shape=(n, 4)), o.R)[: u + 1] == z
+    for b in adv + sig + [last, dz]:
+        b.free()
+
+
+def test_permutation_product_telescopes_at_2pow16(gpu):
+    """size-independent property: for a witness that satisfies its copy constraints the grand product over all
+    permutation columns returns to one at the last usable row (what the l_last (z^2 - z) gate checks)."""
+    from oracle import plonk as P
+    from halo2_scaffold_amd import plonk as gp
+
+    k = 16
+    inst = P.StandardPlonkInstance(k, 0xABCDEF, seed=3)
+    beta, gamma = 0x1234567, 0x7654321
+    adv = [gpu.DevBuf.from_numpy(o.pack(c, o.R)) for c in inst.advice]
+    sig = [gpu.DevBuf.from_numpy(o.pack(c, o.R)) for c in inst.sigma]
+    last, dz = gpu.DevBuf(32), gpu.DevBuf(inst.n * 32)
+    for mcol in range(3):
+        gp.permutation_product(k, [adv[mcol]], [sig[mcol]], [mcol], beta, gamma, inst.u, dz, d_start=last if mcol else None, d_last=last)
+    assert o.unpack(last.to_numpy(shape=(1, 4)), o.R) == [1]
+    # and it does not when a copy constraint is violated
+    bad = list(inst.advice[1]); bad[1] = (bad[1] + 1) % o.R
+    adv[1].upload(o.pack(bad, o.R))
+    for mcol in range(3):
+        gp.permutation_product(k, [adv[mcol]], [sig[mcol]], [mcol], beta, gamma, inst.u, dz, d_start=last if mcol else None, d_last=last)
+    assert o.unpack(last.to_numpy(shape=(1, 4)), o.R) != [1]
+    for b in adv + sig + [last, dz]:
+        b.free()
+
+
 def test_task_size_override_is_clamped_to_buffer_capacity(gpu):
     """H2MI_MSM_S0 asks for more accumulation tasks than the registered workspace holds: the library must
     clamp the task size (never overrun its partial buffers) and still return the right point."""

@@ -34,3 +34,12 @@ for k in [16, 20]:
     algo = ext * 32 * 18
     print(f"k={k}: evaluate_h(standard_plonk) on 2^{dom.extended_k}: {te*1e6:8.1f} us ({algo/te/8e12*100:4.1f}% of HBM roofline, 18 x 32 B per point)", flush=True)
     for b in bufs + [out]: b.free()
+
+# permutation grand product of one column (chunk of 1): 2 columns in, z out (+ 3n scratch)
+for k in [16, 20]:
+    n = 1 << k
+    v, sg, z = (h2.DevBuf.from_numpy(synth.uniform_fr(n, 400 + i)) for i in range(3))
+    fn = lambda: gp.permutation_product(k, [v], [sg], [0], 0x1234567, 0x7654321, n - 6, z)
+    tp = t(fn, R=10)
+    print(f"k={k}: permutation_product (1 column): {tp*1e6:8.1f} us ({96*n/tp/8e12*100:4.1f}% of HBM roofline, 96 B per row algorithmic)", flush=True)
+    for b in (v, sg, z): b.free()
