@@ -40,6 +40,7 @@ class PartialPointCombiner:
         self.group = group
         self.device = device
         self.world = dist.get_world_size(group)
+        self._gathered = None
 
     def __call__(self, partial: np.ndarray) -> np.ndarray:
         import torch
@@ -50,7 +51,8 @@ class PartialPointCombiner:
         t = torch.from_numpy(partial.view(np.int64).copy())
         if self.device is not None:
             t = t.to(self.device)
-        gathered = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(gathered, t, group=self.group)
-        allp = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])  # (world, k, 12)
+        if self._gathered is None or self._gathered[0].shape != t.shape or self._gathered[0].device != t.device:
+            self._gathered = [torch.empty_like(t) for _ in range(self.world)]  # reused: one step = one tiny all-gather
+        self.dist.all_gather(self._gathered, t, group=self.group)
+        allp = torch.stack(self._gathered).cpu().numpy().view(np.uint64)  # (world, k, 12): one copy back, not `world`
         return self.fold(allp)
