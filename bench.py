@@ -53,8 +53,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     # rehearsal knobs (not used by the driver): H2MI_DIST_BACKEND=gloo runs the N > 1 path with CPU
     # collectives, H2MI_DEVICE=<i> pins every rank to one GPU so a 1-GPU box can exercise world_size 2
@@ -181,13 +180,18 @@ def main():
 
     algo_bytes = 96 * R.n_local  # 32 B scalar + 64 B affine base per pair, read once
     achieved = algo_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and world == 1 and args.k == 20:
-        try:
-            traffic = json.load(open(tpath)).get("k_msm_accum_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM traffic of the kernel comes from rocprofv3 PMC counters, which cannot be collected from inside this
+    # process: the field carries the figure of the latest committed counter run of this same workload and says so
+    traffic, traffic_source = None, None
+    for tname in ("r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath) and world == 1 and args.k == 20 and args.shape == "standard_plonk":
+            try:
+                traffic = json.load(open(tpath)).get("k_msm_accum_hbm_bytes_per_launch")
+                traffic_source = f"profiles/{tname} (separate rocprofv3 --pmc run of this command, not measured in this run)"
+                break
+            except Exception:
+                traffic = None
     roofline = {
         "kernel": "k_msm_accum",
         "bound": "hbm",
@@ -196,6 +200,7 @@ def main():
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 6),
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": algo_bytes,
         "avg_launch_ms": round(accum_ms, 4),
         "note": "MSM is 254-bit integer-multiply bound (v_mad_u64_u32), not HBM bound; see DESIGN.md",

@@ -57,6 +57,12 @@ def _load():
         "h2mi_g1_sum_jacobian": ([vp, sz, vp], C.c_int),
         "h2mi_g1_fold_groups": ([vp, sz, sz, vp], C.c_int),
         "h2mi_g1_batch_normalize": ([vp, sz, vp], C.c_int),
+        "h2mi_g1_fold_groups_dev": ([vp, sz, sz, vp, vp], C.c_int),
+        "h2mi_g1_batch_normalize_dev": ([vp, sz, vp, vp], C.c_int),
+        "h2mi_library_stream": ([C.POINTER(vp)], C.c_int),
+        "h2mi_fr_add_head_dev": ([vp, vp, sz, vp], C.c_int),
+        "h2mi_fr_fill_dev": ([vp, sz, vp, vp], C.c_int),
+        "h2mi_fr_random_dev": ([vp, sz, C.c_uint64, C.c_uint64, vp], C.c_int),
         "h2mi_ntt_bn254_fr": ([vp, vp, C.c_uint32], C.c_int),
         "h2mi_ntt_ext_bn254_fr": ([vp, C.c_uint32, vp, vp, vp], C.c_int),
         "h2mi_ntt_bn254_fr_dev": ([vp, C.c_uint32, vp, vp, vp, vp], C.c_int),

@@ -90,7 +90,7 @@ def lincomb(polys, scalars) -> np.ndarray:
 
     polys = [_fr_array(p) for p in polys]
     n = len(polys[0])
-    assert all(len(p) == n for p in polys) and 1 <= len(polys) <= 16
+    assert all(len(p) == n for p in polys) and 1 <= len(polys) <= 24
     sc = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.uint64) for s in scalars]))
     bufs = [DevBuf.from_numpy(p) for p in polys]
     ptrs = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])

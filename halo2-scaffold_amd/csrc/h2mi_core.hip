@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) k_g1_fold_groups(const uint8_t* pts, size_
   jac_store(out + j * 96, xyzz_to_jac(acc));
 }
 
-__global__ void __launch_bounds__(256) k_g1_normalize(const uint8_t* pts, size_t k, uint8_t* out) {
+__global__ void k_g1_normalize(const uint8_t* pts, size_t k, uint8_t* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   xyzz p = jac_to_xyzz(jac_load(pts + i * 96));
@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const fe* scalars, size_
 }
 
 static uint8_t* g_fixed_table = nullptr;
+static Built g_fixed_built;
 
 }  // namespace h2
 
@@ -170,7 +171,7 @@ void h2mi_shutdown(void) {
   if (!ctx().inited) return;
   msm_join_all(ctx().stream);
   hipStreamSynchronize(ctx().stream);
-  if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; }
+  if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; g_fixed_built.destroy(); }
   hipDeviceSynchronize();
   hipStreamDestroy(ctx().head_stream);
   hipStreamDestroy(ctx().accum_stream);
@@ -370,6 +371,31 @@ int h2mi_g1_fold_groups(const uint64_t* points, size_t world, size_t k, uint64_t
 }
 
 
+int h2mi_g1_fold_groups_dev(const void* d_points, size_t world, size_t k, void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_points || !d_out || world == 0 || k == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  H2_LAUNCH("k_g1_fold_groups", k_g1_fold_groups, ceil_div_u32(k, 64), 64, 0, s, (const uint8_t*)d_points, world, k, (uint8_t*)d_out);
+  return H2MI_OK;
+}
+
+int h2mi_g1_batch_normalize_dev(const void* d_jac, size_t k, void* d_affine_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_jac || !d_affine_out || k == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  H2_LAUNCH("k_g1_normalize", k_g1_normalize, ceil_div_u32(k, 64), 64, 0, s, (const uint8_t*)d_jac, k, (uint8_t*)d_affine_out);
+  return H2MI_OK;
+}
+
+int h2mi_library_stream(void** stream_out) {
+  H2_REQUIRE_INIT();
+  if (!stream_out) return H2MI_EINVAL;
+  *stream_out = (void*)ctx().stream;
+  return H2MI_OK;
+}
+
 int h2mi_g1_batch_normalize(const uint64_t* jacp, size_t k, uint64_t* affine_out) {
   H2_REQUIRE_INIT();
   if (!jacp || !affine_out || k == 0) return H2MI_EINVAL;
@@ -394,7 +420,9 @@ int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affi
   if (!g_fixed_table) {
     H2_HIP(hipMalloc(&g_fixed_table, 32 * 256 * 64));
     H2_LAUNCH("k_fixed_base_table", k_fixed_base_table, 32, 256, 0, s, g_fixed_table);
+    H2_HIP(g_fixed_built.mark(s));
   }
+  H2_HIP(g_fixed_built.use(s));
   H2_LAUNCH("k_fixed_base_mul", k_fixed_base_mul, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_scalars, n,
             (const uint8_t*)g_fixed_table, (uint8_t*)d_out_affine);
   return H2MI_OK;

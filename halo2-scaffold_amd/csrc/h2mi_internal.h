@@ -78,6 +78,26 @@ struct DevMem {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// A device table built by kernels on one stream and read by kernels on any stream: the builder records an
+// event, a consumer on another stream waits for it (same stream: in order, no wait needed).
+struct Built {
+  hipEvent_t ev = nullptr;
+  hipStream_t on = nullptr;
+  hipError_t mark(hipStream_t s) {
+    if (!ev) {
+      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    on = s;
+    return hipEventRecord(ev, s);
+  }
+  hipError_t use(hipStream_t s) const { return (ev && s != on) ? hipStreamWaitEvent(s, ev, 0) : hipSuccess; }
+  void destroy() {
+    if (ev) hipEventDestroy(ev);
+    ev = nullptr;
+  }
+};
+
 // h2mi_msm.hip: make `s` wait for all outstanding MSM tails
 int msm_join_all(hipStream_t s);
 

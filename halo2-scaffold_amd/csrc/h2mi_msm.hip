@@ -20,7 +20,6 @@
 //  * the weighted bucket sum  sum_b (b+1) B_b  is done without long serial chains: row/column sums of
 //    the bucket matrix (LDS tree reductions), bit-decomposed weights, then <= 15 doublings.
 // All arithmetic is 254-bit integer work on v_mad_u64_u32; no MFMA (not a dense contraction).
-#include <hipcub/hipcub.hpp>
 
 #include <map>
 
@@ -63,13 +62,11 @@ struct Slot {
   uint8_t* bkeys = nullptr;     // partition intermediate: bucket id within the bin, bin-major
   uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
   uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
-  void* bin_scan_tmp = nullptr;
   uint32_t* binseg = nullptr;   // sums of the SCAN_SEG_BINS-cell segments of bincnt
   uint32_t* off = nullptr;      // first entry of each bucket in vals[1] (nb+1; last = number of entries)
   uint32_t* s0_dev = nullptr;   // chunk length of this MSM's accumulation (chosen by k_msm_bin_sort)
   uint32_t* np[2] = {nullptr, nullptr};    // per bucket: partial sums the accumulation leaves, fold tasks (nb+1 entries, last = 0)
   uint32_t* toff[2] = {nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
-  void* scan_tmp = nullptr;
   uint8_t* part[2] = {nullptr, nullptr};   // XYZZ partial buffers: accumulation output, fold output
   uint8_t* dense = nullptr;                // one XYZZ sum per bucket
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
@@ -77,6 +74,8 @@ struct Slot {
   uint64_t* stats = nullptr;                        // [0] = insertions
   hipEvent_t input_ready = nullptr, head_done = nullptr, accum_done = nullptr, tail_done = nullptr;
   bool tail_pending = false, accum_pending = false, head_pending = false;
+  bool tail_ever = false, accum_ever = false, head_ever = false;  // the events have been recorded at least once
+  hipStream_t last_stream = nullptr;  // stream the slot's previous MSM was issued on
   bool tail_deferred = false;   // accumulation queued, bucket reduction not yet launched (see flush_tails)
   void* d_out = nullptr;        // where that reduction will write the result
   uint32_t tasks1 = 0;          // its fold grid bound
@@ -89,7 +88,6 @@ struct Bases {
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
   uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
-  size_t scan_tmp_bytes = 0, bin_scan_tmp_bytes = 0;
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
   Slot slot[NSLOT];
   int next_slot = 0, last_slot = 0;
@@ -835,10 +833,10 @@ static void free_bases(Bases* B) {
   hipFree(B->host_stage);
   for (Slot& S : B->slot) {
     hipFree(S.vals[0]); hipFree(S.vals[1]);
-    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.bin_scan_tmp); hipFree(S.binseg);
+    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.binseg);
     hipFree(S.off); hipFree(S.s0_dev);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
-    hipFree(S.scan_tmp); hipFree(S.dense);
+    hipFree(S.dense);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
     if (S.input_ready) hipEventDestroy(S.input_ready);
     if (S.head_done) hipEventDestroy(S.head_done);
@@ -878,20 +876,14 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   const size_t ntiles_max = (n + P1_TS - 1) / P1_TS;
   const size_t bin_cells = (size_t)B->nbins * ntiles_max + 1;
   if (bin_cells >= ((size_t)1 << 31)) { free_bases(B); return H2MI_ERANGE; }
-  if (hipcub::DeviceScan::ExclusiveSum(nullptr, B->bin_scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)bin_cells, s) != hipSuccess) {
-    free_bases(B);
-    return H2MI_EHIP;
-  }
-  if (hipcub::DeviceScan::ExclusiveSum(nullptr, B->scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(B->nb + 1), s) != hipSuccess) {
-    free_bases(B);
-    return H2MI_EHIP;
-  }
+  // the own scans (k_scan_seg) take 16-byte vectors: the [bin][tile] matrix has 512 rows and the task arrays
+  // 2^(c-1) >= 1024 entries for every window width pick_window() can return
+  if ((B->nbins & 3u) || B->nb < 4 || B->nb > SCAN_SEG_TASKS) { free_bases(B); return H2MI_ERANGE; }
   for (Slot& S : B->slot) {
     for (int i = 0; i < 2; i++) H2_ALLOC(S.vals[i], nW * 4);
     H2_ALLOC(S.bkeys, nW + 16);
     H2_ALLOC(S.bincnt, bin_cells * 4);
     H2_ALLOC(S.binbase, bin_cells * 4);
-    H2_ALLOC(S.bin_scan_tmp, B->bin_scan_tmp_bytes ? B->bin_scan_tmp_bytes : 16);
     H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     H2_ALLOC(S.s0_dev, 4);
@@ -899,7 +891,6 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
       H2_ALLOC(S.np[i], (size_t)(B->nb + 1) * 4);
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
     }
-    H2_ALLOC(S.scan_tmp, B->scan_tmp_bytes ? B->scan_tmp_bytes : 16);
     H2_ALLOC(S.dense, (size_t)B->nb * PART_BYTES);
     H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * PART_BYTES);
     H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * PART_BYTES);
@@ -976,10 +967,16 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     // the first partition level (count, scan, scatter) is the only reader of the caller's scalars and stays
     // on s.  It writes bincnt/binbase/bkeys/vals[0], last read by this slot's previous k_msm_bin_sort.
     if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+    // the slot's previous MSM ran start to end on a caller's stream: its last kernel recorded tail_done there
+    if (S.tail_pending && S.last_stream != s) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
   } else {
-    if (S.tail_pending) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
-    if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
+    // a caller's stream is ordered against nothing the library did on its own streams (h2mi_join only makes the
+    // library stream wait), so it waits for every event this slot has ever recorded; a completed event is free
+    if (S.head_ever) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+    if (S.accum_ever) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
+    if (S.tail_ever) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
   }
+  S.last_stream = s;
   const uint32_t ntiles = ceil_div_u32(n, P1_TS);
   static bool attr_set = false;
   if ((size_t)P1_TS * W * 6 > 150 * 1024) return H2MI_ERANGE;
@@ -1006,19 +1003,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 17: H2_BIN_COUNT(17); break;
       default: H2_BIN_COUNT(0); break;
     }
-    const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 unless nbins < 4 (tiny H2MI_MSM_C)
-    if ((cells & 3) == 0) {
-      const uint32_t nseg = ceil_div_u32(cells, SCAN_SEG_BINS);
-      if (nseg > 1) H2_LAUNCH("k_scan_segsum", k_scan_segsum<SCAN_SEG_BINS>, nseg, 1024, 0, s, (const uint32_t*)S.bincnt, cells, S.binseg);
-      H2_LAUNCH("k_scan_seg_bins", k_scan_seg<SCAN_SEG_BINS>, dim3(nseg, 1), 1024, 0, s, (const uint32_t*)S.bincnt, S.binbase, (const uint32_t*)nullptr,
-                (uint32_t*)nullptr, cells, (const uint32_t*)S.binseg);
-    } else {
-      const bool prof_ = prof_on("binscan_hipcub");
-      if (prof_) prof_begin("binscan_hipcub", s);
-      hipError_t e = hipcub::DeviceScan::ExclusiveSum(S.bin_scan_tmp, B->bin_scan_tmp_bytes, S.bincnt, S.binbase, (int)(cells + 1), s);
-      if (prof_) prof_end(s);
-      H2_HIP(e);
-    }
+    const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 (checked at registration)
+    const uint32_t nseg = ceil_div_u32(cells, SCAN_SEG_BINS);
+    if (nseg > 1) H2_LAUNCH("k_scan_segsum", k_scan_segsum<SCAN_SEG_BINS>, nseg, 1024, 0, s, (const uint32_t*)S.bincnt, cells, S.binseg);
+    H2_LAUNCH("k_scan_seg_bins", k_scan_seg<SCAN_SEG_BINS>, dim3(nseg, 1), 1024, 0, s, (const uint32_t*)S.bincnt, S.binbase, (const uint32_t*)nullptr,
+              (uint32_t*)nullptr, cells, (const uint32_t*)S.binseg);
     switch (B->c) {
       case 13: H2_BIN_SCATTER(13); break;
       case 15: H2_BIN_SCATTER(15); break;
@@ -1042,13 +1031,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.head_pending = false;
   H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
             (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0_fixed, nb, S.vals[1], S.off, S.np[0], S.np[1], S.s0_dev);
-  if (nb >= 4 && nb <= SCAN_SEG_TASKS) {
-    H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
-              (const uint32_t*)nullptr);
-  } else {
-    H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[0], S.toff[0], (int)(nb + 1), hs));
-    H2_HIP(hipcub::DeviceScan::ExclusiveSum(S.scan_tmp, B->scan_tmp_bytes, S.np[1], S.toff[1], (int)(nb + 1), hs));
-  }
+  H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
+            (const uint32_t*)nullptr);
   // upper bound of the chunks (zero digits leave no entry): whole rounds of the resident grid, or total / override
   const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : accum_rounds(total) * ACCUM_RESIDENT_CHUNKS;
   const uint32_t tasks0 = chunks0 + nb;                                             // upper bound of the partial sums
@@ -1056,6 +1040,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipEventRecord(S.head_done, hs));
     H2_HIP(hipStreamWaitEvent(as, S.head_done, 0));
     S.head_pending = true;
+    S.head_ever = true;
   }
   // Occupancy cap: the accumulation runs as fast with 2 wavefronts per SIMD as with 4 (it is bound by VALU
   // issue, not latency), but at 4 it owns every VGPR of the chip and the short kernels of the neighbouring
@@ -1071,6 +1056,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     // the bucket reduction is deferred: flush_tails() runs it for every MSM queued since the last join
     H2_HIP(hipEventRecord(S.accum_done, as));
     S.accum_pending = true;
+    S.accum_ever = true;
     S.tail_deferred = true;
     g_deferred.push_back({B, &S});
     static const bool eager = getenv("H2MI_MSM_EAGER_TAIL") != nullptr;  // A/B: one reduction per MSM, at once
@@ -1083,6 +1069,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   if (rc) return rc;
   H2_HIP(hipEventRecord(S.tail_done, s));
   S.tail_pending = true;
+  S.tail_ever = true;
   return H2MI_OK;
 }
 
@@ -1146,6 +1133,7 @@ static int flush_tails() {
       Slot& S = *g_deferred[j].S;
       H2_HIP(hipEventRecord(S.tail_done, t));
       S.tail_pending = true;
+      S.tail_ever = true;
       S.tail_deferred = false;
     }
   }
@@ -1161,7 +1149,7 @@ int msm_join_all(hipStream_t s) {
     for (Slot& S : kv.second->slot)
       if (S.tail_pending) {
         H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
-        S.tail_pending = false;
+        if (s == ctx().stream) S.tail_pending = false;  // only the library stream's later work is now ordered behind it
       }
   return H2MI_OK;
 }

@@ -15,6 +15,7 @@
 // the last pass's store, so EvaluationDomain's extra sweeps over memory disappear.
 // Twiddles: w^e for the inter-pass factors comes from two small tables (e = hi*2^h + lo, one extra
 // field mul) instead of an n-entry table, so all twiddle data stays L2/LDS resident.
+#include <algorithm>
 #include <map>
 
 #include "f29.cuh"
@@ -373,9 +374,10 @@ __global__ void __launch_bounds__(256) k_kate_finish(const fe* local, const fe* 
 }
 
 // out[i] = sum_k scalar_k * poly_k[i]
+constexpr uint32_t LINCOMB_MAX = 24;
 struct LincombArgs {
-  const fe* poly[16];
-  fe scalar[16];  // Mont256
+  const fe* poly[LINCOMB_MAX];
+  fe scalar[LINCOMB_MAX];  // Mont256
   uint32_t count;
 };
 __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe* out) {
@@ -385,10 +387,46 @@ __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe*
   for (uint32_t k = 0; k < args.count; k++) {
     f29 s = f29_from_mont256<F9>(args.scalar[k].v);  // uniform: evaluated on the scalar unit
     f29 t = f29_mul<F9>(load_unpack(&args.poly[k][i]), s);
-    acc = f29_normalize(f29_add(acc, t));            // < 16 * 1.01p, far below the 169p capacity
+    acc = f29_normalize(f29_add(acc, t));            // < 24 * 1.01p, far below the 169p capacity
   }
   f29 r = f29_mul<F9>(acc, f29_const<F9>(F9::ONE));  // back below 2p
   pack_store(&out[i], r);
+}
+
+// out[i] = value
+__global__ void __launch_bounds__(256) k_fr_fill(fe* out, size_t n, fe value) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fe_store(&out[i], value);
+}
+// poly[i] += head[i], i < count <= 16 (the low-degree remainder terms of the opening argument)
+struct HeadArgs {
+  fe c[16];
+};
+__global__ void k_fr_add_head(fe* poly, HeadArgs h, uint32_t count) {
+  uint32_t i = threadIdx.x;
+  if (i < count) fe_store(&poly[i], fe_add<Fr>(fe_load(&poly[i]), h.c[i]));
+}
+// counter-based SplitMix64 field elements (the seeded stand-in for the prover's `Scalar::random(rng)` sweeps:
+// blinding rows, the vanishing argument's random polynomial).  Element i = limbs splitmix64(seed << 32 | 4 i + j),
+// j = 0..3, top limb masked to 62 bits, one conditional subtraction of r; the limbs are the Montgomery form.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_fr_random(fe* out, size_t n, uint64_t seed, uint64_t start) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint64_t w = splitmix64((seed << 32) + 4 * (start + i) + j);
+    if (j == 3) w &= (1ull << 62) - 1;
+    x.v[2 * j] = (uint32_t)w;
+    x.v[2 * j + 1] = (uint32_t)(w >> 32);
+  }
+  fe_store(&out[i], fe_reduce_once<Fr>(x));
 }
 
 // ---- quotient numerator of the reference's StandardPlonk circuit -------------------------
@@ -397,6 +435,9 @@ __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe*
 // Horner in y; result already divided by X^n - 1 (its inverse on the coset repeats with period 2^(ext_k-k)).
 // Element-wise over the extended domain; all vectors stay in HBM.  Montgomery-2^256 throughout (fp.cuh):
 // products of two data values need one closed domain.
+struct TInv {  // (X^n - 1)^-1 on the extended coset: 2^(extended_k - k) <= 16 distinct values
+  fe v[16];
+};
 struct PlonkCosets {
   const fe* advice[3];
   const fe* fixed[5];
@@ -408,7 +449,7 @@ struct PlonkCosets {
 };
 __global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma,
                                                                     fe y, fe delta, fe zeta, const fe* xlo, const fe* xhi, uint32_t xh,
-                                                                    const fe* t_inv, fe* out) {
+                                                                    TInv t_inv, fe* out) {
   const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
   uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= size) return;
@@ -439,7 +480,7 @@ __global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c
     cur = fe_mul<Fr>(cur, delta);
     v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la));
   }
-  v = fe_mul<Fr>(v, fe_load(&t_inv[idx & (rot - 1)]));
+  v = fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]);
   fe_store(&out[idx], v);
 }
 
@@ -460,12 +501,16 @@ struct PowTab {  // base^i split as hi/lo for i < 2^log_n; full: lo holds every 
   uint32_t h = 0;
   bool full = false;
   size_t bytes = 0;
+  Built built;            // build kernels' completion: consumers on other streams wait for it
+  uint64_t last_use = 0;  // call epoch of the last user (entries of the running call are never evicted)
 };
 struct Plan {
   int P = 0;
   uint32_t m[3] = {0, 0, 0};
   PowTab tw;
   fe* loc[3] = {nullptr, nullptr, nullptr};
+  Built built;
+  uint64_t last_use = 0;
 };
 
 static std::map<Key, PowTab> g_powtabs;
@@ -604,8 +649,65 @@ static fe host_fe(const uint64_t w[4]) {
 
 // `full`: one table entry per power (32 B x 2^log_n) so that a kernel fetches base^e instead of multiplying
 // two table entries: for the bases that live as long as a domain (omega, the coset generator), up to 2^22.
+//
+// Cache policy.  Tables are keyed by (base, size); per-domain bases (omega, zeta) are hit by every proof,
+// per-challenge bases (evaluation points, their inverses) only by one.  The cache is bounded; when it is full
+// the least recently used entries are dropped, never an entry the running call has already been handed
+// (`g_epoch` counts ABI calls; an entry touched in this epoch is pinned), and only after the whole device is
+// idle, since tables may be in use on any stream.
 constexpr uint32_t FULL_TABLE_MAX_LOG = 22;
+constexpr size_t POWTAB_MAX_ENTRIES = 64, POWTAB_KEEP_ENTRIES = 32;
+constexpr size_t POWTAB_MAX_BYTES = (size_t)3 << 30, POWTAB_KEEP_BYTES = (size_t)3 << 29;
 static size_t g_powtab_bytes = 0;
+static uint64_t g_epoch = 1, g_evictions = 0;
+struct CallScope {  // one per ABI call that uses cached tables
+  CallScope() { g_epoch++; }
+};
+
+static void free_plan(Plan& pl) {
+  for (int i = 0; i < 3; i++) {
+    fe* p = pl.loc[i];
+    if (!p) continue;
+    for (int j = i + 1; j < 3; j++)  // passes of equal size share one table
+      if (pl.loc[j] == p) pl.loc[j] = nullptr;
+    hipFree(p);
+    pl.loc[i] = nullptr;
+  }
+  pl.built.destroy();
+}
+
+static int evict_tables() {
+  H2_HIP(hipDeviceSynchronize());  // every stream: a table may be read by kernels the caller queued elsewhere
+  // plans first (they hold raw copies of their twiddle table's pointers), then unreferenced tables, oldest first
+  for (auto it = g_plans.begin(); it != g_plans.end();) {
+    if (it->second.last_use < g_epoch) {
+      free_plan(it->second);
+      it = g_plans.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  std::vector<std::pair<uint64_t, Key>> order;
+  for (auto& kv : g_powtabs) {
+    if (kv.second.last_use >= g_epoch) continue;  // handed out during this call
+    bool referenced = false;
+    for (auto& pk : g_plans) referenced = referenced || pk.second.tw.lo == kv.second.lo;
+    if (!referenced) order.push_back({kv.second.last_use, kv.first});
+  }
+  std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, Key>& a, const std::pair<uint64_t, Key>& b) { return a.first < b.first; });
+  for (auto& e : order) {
+    if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES) break;
+    auto it = g_powtabs.find(e.second);
+    hipFree(it->second.lo);
+    hipFree(it->second.hi);
+    it->second.built.destroy();
+    g_powtab_bytes -= it->second.bytes;
+    g_powtabs.erase(it);
+  }
+  g_evictions++;
+  return H2MI_OK;
+}
+
 static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, PowTab* out, bool full = false) {
   full = full && log_n <= FULL_TABLE_MAX_LOG && !getenv("H2MI_NTT_NO_FULL_TABLES");
   Key k;
@@ -614,38 +716,32 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
   k.full = full;
   auto it = g_powtabs.find(k);
   if (it != g_powtabs.end()) {
+    it->second.last_use = g_epoch;
+    H2_HIP(it->second.built.use(s));
     *out = it->second;
     return H2MI_OK;
   }
-  if (g_powtabs.size() > 64 || g_powtab_bytes > ((size_t)3 << 30)) {  // bounded cache: drop everything (cheap to rebuild)
-    H2_HIP(hipStreamSynchronize(s));
-    for (auto& kv : g_powtabs) {
-      hipFree(kv.second.lo);
-      hipFree(kv.second.hi);
-    }
-    g_powtabs.clear();
-    g_powtab_bytes = 0;
-    for (auto& kv : g_plans)
-      for (int i = 0; i < 3; i++) {
-        fe* p = kv.second.loc[i];
-        if (!p) continue;
-        for (int j = i + 1; j < 3; j++)  // passes of equal size share one table
-          if (kv.second.loc[j] == p) kv.second.loc[j] = nullptr;
-        hipFree(p);
-      }
-    g_plans.clear();
+  static const size_t max_entries = getenv("H2MI_POWTAB_MAX") ? (size_t)atoi(getenv("H2MI_POWTAB_MAX")) : POWTAB_MAX_ENTRIES;
+  if (g_powtabs.size() >= max_entries || g_powtab_bytes > POWTAB_MAX_BYTES) {
+    int rc = evict_tables();
+    if (rc) return rc;
   }
   PowTab t;
   t.full = full;
   t.h = full ? log_n : (log_n + 1) / 2;
   uint32_t nlo = 1u << t.h, nhi = 1u << (log_n - t.h);
   t.bytes = ((size_t)nlo + nhi) * 32;
-  g_powtab_bytes += t.bytes;
   H2_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
-  H2_HIP(hipMalloc(&t.hi, (size_t)nhi * 32));
+  if (hipMalloc(&t.hi, (size_t)nhi * 32) != hipSuccess) {
+    hipFree(t.lo);
+    return H2MI_ENOMEM;
+  }
   fe b = host_fe(base);
   H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nlo, 256), 256, 0, s, t.lo, nlo, b, 0u);
   H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nhi, 256), 256, 0, s, t.hi, nhi, b, t.h);
+  H2_HIP(t.built.mark(s));
+  t.last_use = g_epoch;
+  g_powtab_bytes += t.bytes;
   g_powtabs[k] = t;
   *out = t;
   return H2MI_OK;
@@ -674,7 +770,13 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
   k.log_n = log_n;
   auto it = g_plans.find(k);
   if (it != g_plans.end()) {
-    *out = it->second;
+    Plan& pl = it->second;
+    pl.last_use = g_epoch;
+    H2_HIP(pl.built.use(s));
+    PowTab tw;  // refresh the twiddle table's pin and stream dependency
+    int rc = get_powtab(omega, log_n, s, &tw, /*full=*/pl.P > 1);
+    if (rc) return rc;
+    *out = pl;
     return H2MI_OK;
   }
   Plan pl;
@@ -690,10 +792,16 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
       if (pl.m[q] == m) pl.loc[p] = pl.loc[q];
     if (pl.loc[p]) continue;
     uint32_t cnt = 1u << (m - 1);
-    H2_HIP(hipMalloc(&pl.loc[p], (size_t)cnt * 32));
+    if (hipMalloc(&pl.loc[p], (size_t)cnt * 32) != hipSuccess) {
+      pl.loc[p] = nullptr;
+      free_plan(pl);
+      return H2MI_ENOMEM;
+    }
     // w_loc = omega^(n / 2^m): order 2^m
     H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m);
   }
+  H2_HIP(pl.built.mark(s));
+  pl.last_use = g_epoch;
   g_plans[k] = pl;
   *out = pl;
   return H2MI_OK;
@@ -829,6 +937,7 @@ int h2mi_ntt_bn254_fr_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], co
   H2_REQUIRE_INIT();
   if (!d_a || !omega) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   return ntt_dev((fe*)d_a, log_n, omega, pre, post, pick_stream(stream));
 }
 
@@ -838,6 +947,7 @@ int h2mi_ntt_bn254_fr_oop_dev(const void* d_src, size_t src_len, void* d_dst, ui
   if (!d_src || !d_dst || !omega || d_src == d_dst) return H2MI_EINVAL;
   if (log_n > H2MI_MAX_LOG_N || src_len > ((size_t)1 << log_n)) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   return ntt_dev((fe*)d_dst, log_n, omega, pre, post, pick_stream(stream), (const fe*)d_src, src_len);
 }
 
@@ -846,6 +956,7 @@ int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4], 
   if (!a || !omega) return H2MI_EINVAL;
   if (log_n > H2MI_MAX_LOG_N) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = ctx().stream;
   const size_t bytes = ((size_t)1 << log_n) * 32;
   // device staging kept between calls (grow-only, like the ping-pong scratch): EvaluationDomain calls this
@@ -881,6 +992,7 @@ int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const 
   H2_REQUIRE_INIT();
   if (!d_a || !base || n == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
@@ -898,6 +1010,7 @@ int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_strea
   H2_REQUIRE_INIT();
   if (!d_out || !base || n == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
@@ -914,6 +1027,7 @@ int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4],
   H2_REQUIRE_INIT();
   if (!d_poly || !point || !d_out || n == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
@@ -934,6 +1048,7 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   H2_REQUIRE_INIT();
   if (!d_poly || !b || !b_inv || !d_out || n < 2) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
@@ -957,8 +1072,9 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
 
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, size_t count, size_t n, void* d_out, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
-  if (!d_polys || !scalars || !d_out || n == 0 || count == 0 || count > 16) return H2MI_EINVAL;
+  if (!d_polys || !scalars || !d_out || n == 0 || count == 0 || count > LINCOMB_MAX) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   LincombArgs args;
   memset(&args, 0, sizeof(args));
@@ -972,6 +1088,36 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, siz
   return H2MI_OK;
 }
 
+
+int h2mi_fr_fill_dev(void* d_out, size_t n, const uint64_t value[4], h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_out || !value || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  H2_LAUNCH("k_fr_fill", k_fr_fill, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, host_fe(value));
+  return H2MI_OK;
+}
+
+int h2mi_fr_add_head_dev(void* d_poly, const uint64_t* head, size_t count, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_poly || !head || count == 0 || count > 16) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  HeadArgs h;
+  memset(&h, 0, sizeof(h));
+  for (size_t i = 0; i < count; i++) h.c[i] = host_fe(head + 4 * i);
+  H2_LAUNCH("k_fr_add_head", k_fr_add_head, 1, 64, 0, s, (fe*)d_poly, h, (uint32_t)count);
+  return H2MI_OK;
+}
+
+int h2mi_fr_random_dev(void* d_out, size_t n, uint64_t seed, uint64_t start, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_out || n == 0 || seed >> 32) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  H2_LAUNCH("k_fr_random", k_fr_random, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, seed, start);
+  return H2MI_OK;
+}
 
 // inclusive multiplicative scan of n elements, in place in `data` (forward prefix or reverse suffix)
 static int mulscan(fe* data, size_t n, int reverse, fe* totals, fe* offsets, hipStream_t s) {
@@ -991,6 +1137,7 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
   if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8) return H2MI_EINVAL;
   if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   const size_t n = (size_t)1 << k;
   PermArgs a;
@@ -1041,6 +1188,7 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint
   if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
   if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
   hipStream_t s = pick_stream(stream);
   PlonkCosets pc;
   for (int i = 0; i < 3; i++) { pc.advice[i] = (const fe*)c->advice[i]; pc.sigma[i] = (const fe*)c->sigma[i]; pc.z[i] = (const fe*)c->z[i]; }
@@ -1053,12 +1201,12 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint
   int rc = get_powtab(extended_omega, extended_k, s, &px);
   if (rc) return rc;
   const uint32_t rot = 1u << (extended_k - k);
-  static fe* d_tinv = nullptr;  // 16 entries, reused: copies and kernels on one stream are ordered
-  if (!d_tinv) H2_HIP(hipMalloc(&d_tinv, 16 * 32));
-  H2_HIP(hipMemcpyAsync(d_tinv, t_inv, rot * 32, hipMemcpyHostToDevice, s));
+  TInv tinv;  // <= 16 values, passed by value: no staging buffer shared between streams
+  memset(&tinv, 0, sizeof(tinv));
+  for (uint32_t i = 0; i < rot; i++) tinv.v[i] = host_fe(t_inv + 4 * i);
   const uint32_t size = 1u << extended_k;
   H2_LAUNCH("k_evaluate_h_standard_plonk", k_evaluate_h_standard_plonk, ceil_div_u32(size, 256), 256, 0, s, pc, extended_k, k, blinding_factors + 1,
-            host_fe(beta), host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, (const fe*)d_tinv,
+            host_fe(beta), host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, tinv,
             (fe*)d_h_out);
   return H2MI_OK;
 }

@@ -65,6 +65,9 @@ int h2mi_sync(void); /* wait for all work queued on the library's streams */
  * h2mi_memcpy_d2h (or when eight reductions are pending).  A prover calls h2mi_join where the transcript
  * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream. */
 int h2mi_join(void);
+/* the library's own stream (a hipStream_t), so that a host can order foreign work — an RCCL collective, its own
+ * kernels — against the library's without a host synchronisation */
+int h2mi_library_stream(void** stream_out);
 
 /* ---- bases (the KZG SRS): ParamsKZG::{g, g_lagrange}, SURVEY.md 8a row a5 ------------------------
  * Replaces the `&params.g` / `&params.g_lagrange` slices that ParamsKZG::commit / commit_lagrange pass
@@ -102,8 +105,12 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
 int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]);
 /* the same fold for k MSMs at once: points[r*k + j] is rank r's partial result of MSM j -> out[j] */
 int h2mi_g1_fold_groups(const uint64_t* points /* world*k*12 */, size_t world, size_t k, uint64_t* out /* k*12 */);
+/* the same fold on device-resident points (e.g. the buffer an RCCL all-gather filled), asynchronous on `stream`:
+ * the per-phase combine of a sliced multi-GPU prover never leaves HBM */
+int h2mi_g1_fold_groups_dev(const void* d_points /* world*k*96 B */, size_t world, size_t k, void* d_out /* k*96 B */, h2mi_stream_t stream);
 /* batch Jacobian -> affine (G1::batch_normalize, used by create_proof before transcript writes) */
 int h2mi_g1_batch_normalize(const uint64_t* jac /* k*12 */, size_t k, uint64_t* affine_out /* k*8 */);
+int h2mi_g1_batch_normalize_dev(const void* d_jac /* k*96 B */, size_t k, void* d_affine_out /* k*64 B */, h2mi_stream_t stream);
 
 /* ---- NTT: halo2_proofs::arithmetic::best_fft(a, omega, log_n) ------------------------------------
  * Replaces best_fft for G = bn256::Fr: in-place DFT out[i] = sum_j a[j] *
@@ -137,9 +144,21 @@ int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4],
  * (the remainder a(b) is dropped, as in the crate).  The caller passes b^-1 (one CPU inversion). */
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out,
                               h2mi_stream_t stream);
-/* out[i] = sum_k scalars[k] * polys[k][i], count <= 16 (the challenge-weighted sums of SHPLONK) */
+/* out[i] = sum_k scalars[k] * polys[k][i], count <= 24 (the challenge-weighted sums of SHPLONK) */
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars /* count*4 */, size_t count, size_t n, void* d_out,
                         h2mi_stream_t stream);
+
+/* poly[i] += head[i] for i < count <= 16: the low-degree remainder terms R(X) / r = R(u) that SHPLONK subtracts
+ * from a (linear combination of) opened polynomial(s) — poly/kzg/multiopen/shplonk/prover.rs
+ * `quotient_contribution` / `linearisation_contribution`. */
+int h2mi_fr_add_head_dev(void* d_poly, const uint64_t* head /* count*4 */, size_t count, h2mi_stream_t stream);
+/* out[i] = value for i < n (Lagrange vectors such as l_active of keygen_pk) */
+int h2mi_fr_fill_dev(void* d_out, size_t n, const uint64_t value[4], h2mi_stream_t stream);
+/* Seeded stand-in for the prover's sweeps of `Scalar::random(rng)` (blinding rows; the vanishing argument's random
+ * polynomial, plonk/vanishing/prover.rs `Argument::commit`; the reference passes OsRng, examples/standard_plonk.rs:48,
+ * so its bytes are not reproducible — SURVEY.md 0).  Counter-based SplitMix64: element i has limbs
+ * splitmix64(seed << 32 | 4 (start + i) + j), j = 0..3, top limb masked to 62 bits, reduced once; seed < 2^32. */
+int h2mi_fr_random_dev(void* d_out, size_t n, uint64_t seed, uint64_t start, h2mi_stream_t stream);
 
 /* ---- quotient numerator for the reference's StandardPlonk circuit -------------------------
  * halo2_proofs plonk/evaluation.rs `evaluate_h` + vanishing division, specialised to the circuit of reference

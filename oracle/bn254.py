@@ -123,6 +123,19 @@ def unpack_jacobian(arr) -> tuple | None:
     return jac_to_affine((X, Y, Z))
 
 
+def pack_jacobian(p, z: int = 1) -> np.ndarray:
+    """affine point (None = identity) -> 12 u64 Montgomery limbs of the Jacobian representative (x z^2, y z^3, z)."""
+    out = np.zeros(12, dtype=np.uint64)
+    if p is None:
+        out[4:8] = int_to_limbs(to_mont(1, Q))
+        return out
+    z %= Q
+    out[0:4] = int_to_limbs(to_mont(p[0] * z * z % Q, Q))
+    out[4:8] = int_to_limbs(to_mont(p[1] * z * z * z % Q, Q))
+    out[8:12] = int_to_limbs(to_mont(z, Q))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # G1: y^2 = x^3 + 3 over Fq.  Affine points are (x, y) tuples, None = identity.
 # ---------------------------------------------------------------------------
