@@ -11,8 +11,8 @@ linked (none can be built here), so gate evaluation / transcript / witness gener
       bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; the total work is fixed ("strong" scaling): every rank owns a contiguous
-1/N slice of both base sets, runs each MSM on its slice and the 96-byte partial points are combined by
-an RCCL all-gather + fold; every NTT runs on one GPU (by design): a transform whose output feeds a later
+1/N slice of both base sets, runs each MSM on its slice and the 96-byte partial points are combined at every
+transcript join (five per StandardPlonk proof) by an RCCL all-gather + device fold, all in HBM; every NTT runs on one GPU (by design): a transform whose output feeds a later
 commitment is replayed by every rank, the others are spread round-robin over the ranks.
 Rank 0 prints ONE JSON line (the contract's fields plus `roofline`, `issue_roofline`, `cpu_baseline`).
 """
@@ -82,13 +82,12 @@ def main():
 
     h2 = _load_pkg.load()
     from halo2_scaffold_amd import replay as rp
-    from halo2_scaffold_amd.dist import PartialPointCombiner
 
     h2.init(local_rank)
     lib = h2.lib
-    combine = PartialPointCombiner(device=coll_dev) if dist is not None else None
     shape = rp.SHAPES[args.shape]
-    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine=combine, spread_leaf_ntts=not args.replicate_all_ntts,
+    R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine_backend=backend if dist is not None else None,
+                       torch_device=torch.device("cuda", local_rank), spread_leaf_ntts=not args.replicate_all_ntts,
                        with_evaluate_h=args.with_evaluate_h)
     n = R.n
 
@@ -114,7 +113,7 @@ def main():
         probes.append((True, R.lookup[0], 3 * shape.n_lookups))
     for lagrange, buf, mult in probes:
         handle = R.params.g_lagrange_handle if lagrange else R.params.g_handle
-        h2._lib.check(lib.h2mi_msm_bn254_g1_dev(handle, buf.ptr + R.lo * 32, R.n_local, R.out.ptr, None), "msm")
+        h2._lib.check(lib.h2mi_msm_bn254_g1_dev(handle, buf.ptr + R.lo * 32, R.n_local, R.probe_out.ptr, None), "msm")
         ba, ra = C.c_uint64(), C.c_uint64()
         h2._lib.check(lib.h2mi_msm_last_stats(handle, C.byref(ba), C.byref(ra)), "stats")
         adds_local += (ba.value + ra.value) * mult  # vectors of one kind share a distribution
@@ -245,6 +244,9 @@ def main():
             "msm_windows": W.value,
             "msm_buckets": nb.value,
             "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
+            "combines_per_step": (R.combiner.combines // max(args.warmup + args.steps + 1, 1)) if R.combiner is not None else 0,
+            "combine": (("RCCL all-gather + device fold at every transcript join, device-resident" if backend == "nccl" else
+                         "gloo all-gather (host) + device fold at every transcript join") if R.combiner is not None else "none (single GPU)"),
             "what_is_timed": ("MSM + NTT + evaluate_h kernels on HBM-resident vectors; not transcript / witness generation" if R.with_evaluate_h else
                               "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation"),
         },

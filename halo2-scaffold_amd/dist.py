@@ -5,9 +5,20 @@ This is the partition halo2_proofs::arithmetic::best_multiexp applies per CPU th
 chunks, partial results folded by addition) lifted to GPUs.  RCCL has no user-defined reduction, so
 the "all-reduce of EC points" is an all-gather of world x 96 B over xGMI followed by world-1 point
 additions on every rank (latency-bound: < 1 KB payload).
-`fold` ((world, k, 12) -> (k, 12)) defaults to the device kernel (h2mi_g1_fold_groups); tests inject a
-CPU fold to exercise the collective plumbing over gloo without a GPU.
+
+A prover needs the commitments of a phase before it can draw the next challenge (the joins of
+create_proof: theta, beta/gamma, y, x, SHPLONK's v and u), so the combine happens at EVERY join, not once
+per proof: `PhaseCombiner.combine(first_slot, count)`.
+
+  device path (backend nccl = RCCL): the partial points are written by the library straight into a torch CUDA
+      tensor; the all-gather is issued under the library's own stream (torch.cuda.ExternalStream around
+      h2mi_library_stream), so it is ordered after the MSM reductions of the phase and before the fold
+      (h2mi_g1_fold_groups_dev, also on the library stream) without any host synchronisation; nothing leaves HBM.
+  host path (backend gloo: CPU rehearsal and the world-size-2 tests): device -> host copy of the phase's points,
+      CPU all-gather, host -> device, the same device fold — or an injected CPU fold when there is no GPU at all.
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -19,7 +30,7 @@ def slice_bounds(n: int, rank: int, world: int):
 
 
 def device_fold(allp: np.ndarray) -> np.ndarray:
-    """(world, k, 12) partial Jacobian points -> (k, 12): one device launch folds all k MSMs."""
+    """(world, k, 12) partial Jacobian points on the host -> (k, 12): one device launch folds all k MSMs."""
     from ._lib import check, lib
 
     allp = np.ascontiguousarray(allp, dtype=np.uint64)
@@ -30,7 +41,7 @@ def device_fold(allp: np.ndarray) -> np.ndarray:
 
 
 class PartialPointCombiner:
-    """all-gather (k,12)-limb partial Jacobian points from every rank and fold them per slot."""
+    """host-array form: all-gather (k,12)-limb partial Jacobian points from every rank and fold them per slot."""
 
     def __init__(self, fold=device_fold, device=None, group=None):
         import torch.distributed as dist
@@ -46,13 +57,100 @@ class PartialPointCombiner:
         import torch
 
         partial = np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1, 12)
-        k = len(partial)
         # uint64 has no NCCL dtype: ship the limbs as int64 bit patterns
         t = torch.from_numpy(partial.view(np.int64).copy())
         if self.device is not None:
             t = t.to(self.device)
         if self._gathered is None or self._gathered[0].shape != t.shape or self._gathered[0].device != t.device:
-            self._gathered = [torch.empty_like(t) for _ in range(self.world)]  # reused: one step = one tiny all-gather
+            self._gathered = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(self._gathered, t, group=self.group)
-        allp = torch.stack(self._gathered).cpu().numpy().view(np.uint64)  # (world, k, 12): one copy back, not `world`
+        allp = torch.stack(self._gathered).cpu().numpy().view(np.uint64)  # (world, k, 12)
         return self.fold(allp)
+
+
+class PhaseCombiner:
+    """Per-phase combine of the partial MSM results of a sliced multi-GPU prover.
+
+    `partial_ptr` is where this rank's MSMs write their 96-byte results (slot i at partial_ptr + 96 i);
+    `combine(first, count)` makes slots [first, first + count) of `combined_ptr` hold the sums over all ranks.
+    """
+
+    def __init__(self, slots: int, backend: str, torch_device=None, group=None, host_arrays=None):
+        """host_arrays = (partial, combined, fold): numpy (slots, 12) arrays standing in for the two device buffers
+        and a CPU fold ((world, count, 12) -> (count, 12)) — lets the world-size-2 CPU test drive the same
+        phase / slot arithmetic and collective calls without a GPU (never used by the product)."""
+        import torch
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+        from .device import DevBuf
+
+        self.lib, self.check, self.dist, self.torch = lib, check, dist, torch
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.slots = slots
+        self.on_device = backend == "nccl"
+        self.combines = 0
+        self.host_arrays = host_arrays
+        if host_arrays is not None:
+            self.on_device = False
+            self.partial_ptr = None
+            return
+        self.combined = DevBuf(96 * slots)
+        if self.on_device:
+            sp = C.c_void_p()
+            check(lib.h2mi_library_stream(C.byref(sp)), "library_stream")
+            self.stream = torch.cuda.ExternalStream(sp.value, device=torch_device)
+            # torch owns the two exchange buffers (RCCL wants registered torch storage); the library writes and
+            # reads them through their raw pointers
+            self.partial_t = torch.zeros(12 * slots, dtype=torch.int64, device=torch_device)
+            self.gathered_t = torch.zeros(12 * slots * self.world, dtype=torch.int64, device=torch_device)
+            torch.cuda.synchronize(torch_device)
+            self.partial_ptr = self.partial_t.data_ptr()
+        else:
+            self._partial = DevBuf(96 * slots)
+            self._gathered = DevBuf(96 * slots * self.world)
+            self.partial_ptr = self._partial.ptr
+
+    def combine(self, first: int, count: int) -> None:
+        """all-gather + fold of slots [first, first + count); call after h2mi_join()."""
+        if count == 0:
+            return
+        lib, check = self.lib, self.check
+        self.combines += 1
+        if self.on_device:
+            torch = self.torch
+            with torch.cuda.stream(self.stream):  # ordered on the library's stream: after the join, before the fold
+                self.dist.all_gather_into_tensor(self.gathered_t[: 12 * count * self.world], self.partial_t[12 * first : 12 * (first + count)],
+                                                 group=self.group)
+            check(lib.h2mi_g1_fold_groups_dev(self.gathered_t.data_ptr(), self.world, count, self.combined.ptr + 96 * first, None), "fold")
+            return
+        torch = self.torch
+        part = np.empty((count, 12), dtype=np.int64)
+        if self.host_arrays is not None:
+            part[:] = self.host_arrays[0][first : first + count].view(np.int64)
+        else:
+            check(lib.h2mi_memcpy_d2h(part.ctypes.data, self.partial_ptr + 96 * first, 96 * count), "d2h")
+        gathered = [torch.empty(count * 12, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(gathered, torch.from_numpy(part.reshape(-1)), group=self.group)
+        allp = np.ascontiguousarray(torch.stack(gathered).numpy())
+        if self.host_arrays is not None:
+            _, combined, fold = self.host_arrays
+            combined[first : first + count] = fold(allp.view(np.uint64).reshape(self.world, count, 12))
+            return
+        check(lib.h2mi_memcpy_h2d(self._gathered.ptr, allp.ctypes.data, allp.nbytes), "h2d")
+        check(lib.h2mi_g1_fold_groups_dev(self._gathered.ptr, self.world, count, self.combined.ptr + 96 * first, None), "fold")
+
+    def result(self) -> np.ndarray:
+        """(slots, 12) combined Jacobian points (synchronises)."""
+        if self.host_arrays is not None:
+            return self.host_arrays[1]
+        return self.combined.to_numpy(shape=(self.slots, 12))
+
+    def release(self):
+        if self.host_arrays is not None:
+            return
+        self.combined.free()
+        if not self.on_device:
+            self._partial.free()
+            self._gathered.free()

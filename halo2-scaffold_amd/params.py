@@ -30,7 +30,9 @@ class ParamsKZG:
         self.s_g2_bytes = None
 
     @classmethod
-    def setup(cls, k: int, s: int) -> "ParamsKZG":
+    def setup(cls, k: int, s: int, register: bool = True) -> "ParamsKZG":
+        """register=False: generate the SRS on the device but build no MSM tables (a multi-GPU rank registers only
+        its slice, see register_slice)."""
         p = cls(k)
         n = p.n
         p.g2_bytes = G2.to_bytes(G2.G2_GENERATOR)
@@ -48,7 +50,23 @@ class ParamsKZG:
         check(lib.h2mi_g1_fixed_base_mul_dev(pw.ptr, n, p._gl_dev.ptr, None), "g_lagrange")
         check(lib.h2mi_sync(), "sync")
         pw.free()
-        p._register()
+        if register:
+            p._register()
+        return p
+
+    def register_slice(self, lo: int, hi: int) -> "ParamsKZG":
+        """ParamsKZG over bases [lo, hi) of both sets: the slice one rank of a sliced multi-GPU MSM owns
+        (SURVEY.md 8e).  The window tables are built straight from this SRS's device-resident points."""
+        assert 0 <= lo < hi <= self.n and self._gl_dev is not None
+        p = ParamsKZG(self.k)
+        p.n = hi - lo
+        p.g2_bytes, p.s_g2_bytes = self.g2_bytes, self.s_g2_bytes
+        h = C.c_uint64()
+        check(lib.h2mi_bases_register_dev(self._g_dev.ptr + lo * 64, p.n, C.byref(h)), "register g slice")
+        p.g_handle = h.value
+        h2 = C.c_uint64()
+        check(lib.h2mi_bases_register_dev(self._gl_dev.ptr + lo * 64, p.n, C.byref(h2)), "register g_lagrange slice")
+        p.g_lagrange_handle = h2.value
         return p
 
     @classmethod

@@ -15,7 +15,8 @@ Shapes:
                   lookup-advice column and one lookup argument => constraint degree 4, extended domain 4n.
 
 Multi-GPU: every rank owns one contiguous slice of every base set; each MSM runs on the slice and the
-96-byte partial points are combined once per proof by `combine` (all-gather + fold, see dist.py).  Every
+96-byte partial points are combined at EVERY transcript join (all-gather + device fold, dist.PhaseCombiner): a
+prover cannot draw the next challenge before it holds the phase's full commitments.  Every
 NTT runs on ONE GPU (NTT is single-GPU by design): a transform whose output feeds a later
 commitment (h(X), the polynomials opened by SHPLONK) is replayed by every rank, which then reads its own
 slice with no exchange; the independent "leaf" transforms (coefficient / extended forms that only feed
@@ -70,7 +71,9 @@ NTT_PER_PROOF = STANDARD_PLONK.ntt_per_proof
 
 class ProofReplay:
     def __init__(self, shape: ProofShape, k: int, rank: int = 0, world: int = 1, srs_secret: int = 0x5EC2E7 + 0x48324D49, dist="uniform",
-                 combine=None, spread_leaf_ntts: bool = True, with_evaluate_h: bool = False):
+                 combine_backend=None, torch_device=None, spread_leaf_ntts: bool = True, with_evaluate_h: bool = False):
+        """combine_backend: None (single GPU), "nccl" (RCCL all-gather from / to device memory on the library's
+        stream) or "gloo" (host all-gather: CPU rehearsal of the N > 1 schedule)."""
         self.shape = shape
         # optional: compute h(X) from the extended forms with the device evaluate_h (StandardPlonk only; the
         # proving-key cosets - fixed, sigma, l_0, l_last, l_active - are synthetic dense vectors)
@@ -78,25 +81,19 @@ class ProofReplay:
         self.spread = spread_leaf_ntts and world > 1
         self.k, self.n = k, 1 << k
         self.rank, self.world = rank, world
-        self.combine = combine
         self.domain = EvaluationDomain(shape.cs_degree, k)
         n = self.n
         assert n % world == 0
         self.lo, self.hi = rank * n // world, (rank + 1) * n // world
         self.n_local = self.hi - self.lo
         # SRS: every rank generates the full g / g_lagrange on its GPU, registers only its slice
-        full = ParamsKZG.setup(k, srs_secret)
+        # (the slice's window tables are built straight from the device-resident SRS: no host round trip)
+        full = ParamsKZG.setup(k, srs_secret, register=world == 1)
         if world == 1:
             self.params = full
         else:
-            g = full.get_g()[self.lo : self.hi]
-            gl = full.get_g_lagrange()[self.lo : self.hi]
+            self.params = full.register_slice(self.lo, self.hi)
             full.release()
-            self.params = ParamsKZG(k)
-            self.params.n = self.n_local
-            self.params._g_dev = DevBuf.from_numpy(g)
-            self.params._gl_dev = DevBuf.from_numpy(gl)
-            self.params._register()
         gen = {"witness": synth.witness_like_fr, "circuit": synth.circuit_like_fr}.get(dist, synth.uniform_fr)
         sh = shape
         # Lagrange-basis vectors: advice, lookup (A', S', z) triples, permutation products, instance
@@ -111,7 +108,17 @@ class ProofReplay:
         ext = self.domain.extended_len()
         self.ext = [DevBuf(ext * 32) for _ in range(npoly)]
         self.h = DevBuf(ext * 32)
-        self.out = DevBuf(96 * sh.msm_per_proof)
+        self.combiner = None
+        if combine_backend is not None:
+            from .dist import PhaseCombiner
+
+            self.combiner = PhaseCombiner(sh.msm_per_proof, combine_backend, torch_device)
+            self.out = None
+            self.out_ptr = self.combiner.partial_ptr
+        else:
+            self.out = DevBuf(96 * sh.msm_per_proof)
+            self.out_ptr = self.out.ptr
+        self.probe_out = DevBuf(96)  # result slot for stats probes outside a step
         for e in self.ext:
             check(lib.h2mi_memset_zero(e.ptr, ext * 32), "zero")
         self.h.upload(synth.uniform_fr(ext, synth.SEED + 30))
@@ -126,7 +133,7 @@ class ProofReplay:
     def _msm(self, buf: DevBuf, lagrange: bool, offset_elems: int = 0):
         h = self.params.g_lagrange_handle if lagrange else self.params.g_handle
         src = buf.ptr + (offset_elems + self.lo) * 32
-        check(lib.h2mi_msm_bn254_g1_dev(h, src, self.n_local, self.out.ptr + 96 * self._slot, None), "msm")
+        check(lib.h2mi_msm_bn254_g1_dev(h, src, self.n_local, self.out_ptr + 96 * self._slot, None), "msm")
         self._slot += 1
         self.counts["msm"] += 1
 
@@ -155,8 +162,19 @@ class ProofReplay:
         replay joins the MSM pipeline (`h2mi_join`), so no overlap is claimed that a prover could not have;
         a column's transforms are queued as soon as the column exists (see below)."""
         sh, d, n = self.shape, self.domain, self.n
-        join = (lambda: check(lib.h2mi_join(), "join")) if phase_joins else (lambda: None)
         self._slot = 0
+        self._phase_start = 0
+
+        def join():
+            """transcript join: the phase's commitments must exist in full — on every rank — before the next
+            challenge: device-side join of the MSM pipeline, then (N > 1) all-gather + fold of the phase's partial points"""
+            if not phase_joins:
+                return
+            check(lib.h2mi_join(), "join")
+            if self.combiner is not None:
+                self.combiner.combine(self._phase_start, self._slot - self._phase_start)
+            self._phase_start = self._slot
+
         self._leaf = -1
         # buffers are handed out in create_proof's order of use (instance, permutation products, advice, lookups)
         w_it, e_it = iter(self.work), iter(self.ext)
@@ -223,17 +241,25 @@ class ProofReplay:
         assert self._slot == sh.msm_per_proof
 
     def finish(self) -> np.ndarray:
-        """wait, fetch the partial results, combine across ranks -> (msm_per_proof, 12)."""
+        """wait and fetch the proof's commitments -> (msm_per_proof, 12); N > 1: the per-phase combined points."""
+        if self.combiner is not None:
+            if self._phase_start < self._slot:  # step(phase_joins=False): one combine for the whole proof
+                check(lib.h2mi_join(), "join")
+                self.combiner.combine(self._phase_start, self._slot - self._phase_start)
+                self._phase_start = self._slot
+            check(lib.h2mi_sync(), "sync")
+            return self.combiner.result()
         check(lib.h2mi_sync(), "sync")
-        part = self.out.to_numpy(shape=(self.shape.msm_per_proof, 12))
-        if self.combine is not None:  # N > 1 (or a forced single-rank rehearsal of the collective path)
-            return self.combine(part)
-        return part
+        return self.out.to_numpy(shape=(self.shape.msm_per_proof, 12))
 
     def release(self):
         self.params.release()
-        for b in self.advice + self.lookup + self.perm_z + self.instance + self.work + self.ext + [self.h, self._h_src, self.out, self.random_poly]:
+        for b in self.advice + self.lookup + self.perm_z + self.instance + self.work + self.ext + [self.h, self._h_src, self.probe_out, self.random_poly]:
             b.free()
+        if self.out is not None:
+            self.out.free()
+        if self.combiner is not None:
+            self.combiner.release()
 
 
 class StandardPlonkReplay(ProofReplay):

@@ -857,6 +857,8 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm-slice2" and two["scaling"] == "strong"
     assert two["commitments_sha256"] == one["commitments_sha256"]
+    # the partial points are combined at every transcript join (five per StandardPlonk proof), not once per proof
+    assert two["config"]["combines_per_step"] == 5 and one["config"]["combines_per_step"] == 0
     # four ranks (slices of a quarter, leaf transforms spread over four owners): 4 + this process stay below the
     # box's limit of 6 GPU processes
     with socket.socket() as s:
@@ -867,7 +869,7 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     r4 = subprocess.run(cmd4, cwd=root, capture_output=True, text=True, timeout=900, env=env2)
     assert r4.returncode == 0, r4.stdout[-1000:] + r4.stderr[-2000:]
     four = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
-    assert four["n_gpus"] == 4 and four["commitments_sha256"] == one["commitments_sha256"]
+    assert four["n_gpus"] == 4 and four["commitments_sha256"] == one["commitments_sha256"] and four["config"]["combines_per_step"] == 5
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert key in two and key in one
     # the same code path over RCCL ("nccl" backend) with a single rank: process group on the GPU, device
@@ -880,3 +882,4 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     assert r3.returncode == 0, r3.stdout[-1000:] + r3.stderr[-2000:]
     rccl = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
     assert rccl["commitments_sha256"] == one["commitments_sha256"] and rccl["n_gpus"] == 1
+    assert rccl["config"]["combines_per_step"] == 5 and "device-resident" in rccl["config"]["combine"]

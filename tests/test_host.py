@@ -138,6 +138,60 @@ def test_sliced_msm_combine_gloo_world2(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+_PHASE_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import _load_pkg
+h2 = _load_pkg.load()
+from halo2_scaffold_amd.dist import PhaseCombiner, slice_bounds
+from halo2_scaffold_amd import replay
+from oracle import bn254 as o, cref
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 64
+slots = replay.STANDARD_PLONK.msm_per_proof                      # 11 commitments ...
+phases = [3, 4, 2, 1, 1]                                         # ... in the five transcript phases of create_proof
+assert sum(phases) == slots
+bases = cref.g1_mul_gen(o.random_field_limbs(n, 5), 1)
+lo, hi = slice_bounds(n, rank, world)
+partial = np.zeros((slots, 12), dtype=np.uint64)
+combined = np.zeros((slots, 12), dtype=np.uint64)
+fold = lambda allp: np.stack([cref.g1_sum(allp[:, i]) for i in range(allp.shape[1])])
+pc = PhaseCombiner(slots, "gloo", host_arrays=(partial, combined, fold))
+first = 0
+for cnt in phases:
+    for s in range(first, first + cnt):                          # the phase's MSMs on this rank's slice
+        partial[s] = cref.msm(o.random_field_limbs(n, 100 + s)[lo:hi], bases[lo:hi], 1)
+    pc.combine(first, cnt)                                       # the transcript join: all-gather + fold of THIS phase
+    for s in range(first, first + cnt):                          # full commitments exist before the next phase starts
+        want = o.unpack_jacobian(cref.msm(o.random_field_limbs(n, 100 + s), bases, 1))
+        assert o.unpack_jacobian(pc.result()[s]) == want, (rank, s)
+    assert not pc.result()[first + cnt:].any()                   # nothing of a later phase has been touched
+    first += cnt
+assert pc.combines == 5
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join({outdir!r}, "rank%d.ok" % rank), "w").write("ok")
+"""
+
+
+def test_per_phase_combine_gloo_world2(tmp_path):
+    """world_size 2 over gloo: the partial points are combined at every transcript join (five per StandardPlonk
+    proof), and after each join the phase's commitments equal the single-process MSMs."""
+    script = tmp_path / "worker.py"
+    script.write_text(_PHASE_WORKER.format(root=ROOT, outdir=str(tmp_path)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
 def test_cpp_host_example_builds_and_fails_loudly_without_gpu(h2):
     """examples/standard_plonk.cpp (the C++ mirror of the reference example over include/h2mi.hpp) links against
     libh2mi.so; without a GPU it must exit with the library's error, never compute on the CPU."""
