@@ -1,0 +1,204 @@
+"""create_proof for the reference's StandardPlonk circuit with every vector resident in HBM.
+
+Mirror of halo2_proofs::plonk::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK, Challenge255, _, Blake2bWrite, _>
+as the reference calls it (examples/standard_plonk.rs:41-49: one circuit, no instances) — plonk/prover.rs restated
+from memory of v2023_02_02, in its order:
+
+  vk hashed into the transcript; advice columns (witness cells + blinding rows) committed in the Lagrange basis;
+  theta; beta, gamma; the three permutation grand products (device scans), committed; the vanishing argument's random
+  polynomial, committed; y; coefficient and extended-coset forms (iNTT, coset NTT); evaluate_h + division by X^n - 1
+  (one element-wise kernel over the pk's cosets); coset iNTT; the two h pieces committed; x; every query evaluated
+  (device Horner) and written; ProverSHPLONK (shplonk.py).
+
+The host does what the crate's single-threaded control flow does — witness cells, Blake2b, challenge arithmetic on
+single field elements, launch order; every pass over a length-n (or 2n) vector is a HIP kernel behind the C ABI, and
+the only device -> host traffic is the 64-byte commitments and 32-byte evaluations the transcript absorbs.
+
+rng: the reference passes OsRng (its proofs are not reproducible); here `seed` drives counter-based SplitMix64 streams
+(seed+1 advice blinding rows, seed+2 permutation-product blinding rows, seed+3 the random polynomial — generated on
+the device by h2mi_fr_random_dev), the same streams oracle/prover.py draws, so proofs can be compared byte for byte.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import field as F
+from . import plonk as gp
+from . import synth
+from ._lib import check, lib
+from .device import DevBuf
+from .keygen import ProvingKey, _m, _patch
+from .params import ParamsKZG
+from .shplonk import ProverSHPLONK
+from .transcript import Blake2bWrite
+
+R = F.FR_MODULUS
+
+
+class ProverWorkspace:
+    """device buffers of one prover, reused from proof to proof (the reference's examples prove repeatedly against
+    one pk: examples/linear_regression.rs:178-185)"""
+
+    def __init__(self, params: ParamsKZG, pk: ProvingKey):
+        d = pk.vk.domain
+        n, ext = d.n, d.extended_len()
+        na = pk.circuit.N_ADVICE
+        nz = len(pk.circuit.PERMUTATION_COLUMNS)  # chunk length cs_degree - 2 = 1: one product per column
+        self.advice = [DevBuf(n * 32) for _ in range(na)]
+        self.advice_polys = [DevBuf(n * 32) for _ in range(na)]
+        self.advice_cosets = [DevBuf(ext * 32) for _ in range(na)]
+        self.z = [DevBuf(n * 32) for _ in range(nz)]
+        self.z_polys = [DevBuf(n * 32) for _ in range(nz)]
+        self.z_cosets = [DevBuf(ext * 32) for _ in range(nz)]
+        self.z_last = DevBuf(32)
+        self.random_poly = DevBuf(n * 32)
+        self.h = DevBuf(ext * 32)
+        self.h_poly = DevBuf(n * 32)
+        self.points = DevBuf(96 * 4)     # Jacobian results of the commitments of one phase
+        self.affine = DevBuf(64 * 4)
+        self.evals = DevBuf(32 * 32)
+        self.shplonk = ProverSHPLONK(params)
+
+    def release(self):
+        for b in (self.advice + self.advice_polys + self.advice_cosets + self.z + self.z_polys + self.z_cosets +
+                  [self.z_last, self.random_poly, self.h, self.h_poly, self.points, self.affine, self.evals]):
+            b.free()
+        self.shplonk.release()
+
+
+def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, lagrange: bool):
+    """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join), normalise on
+    the device (G1::batch_normalize), fetch the affine points and write them to the transcript"""
+    k = len(columns)
+    for i, (buf, offset_elems) in enumerate(columns):
+        h = params.g_lagrange_handle if lagrange else params.g_handle
+        check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + offset_elems * 32, params.n, ws.points.ptr + 96 * i, None), "commit")
+    check(lib.h2mi_join(), "join")
+    check(lib.h2mi_g1_batch_normalize_dev(ws.points.ptr, k, ws.affine.ptr, None), "normalize")
+    pts = ws.affine.to_numpy(shape=(4, 8), nbytes=64 * 4)[:k]
+    for p in pts:
+        transcript.write_point(p)
+    return pts
+
+
+def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcript: Blake2bWrite = None, ws: ProverWorkspace = None,
+                 trace: dict = None) -> bytes:
+    """-> proof bytes (transcript.finalize()).  `trace`, if given, receives the challenges and device buffers of the
+    intermediate polynomials (tests evaluate the quotient identity on them)."""
+    own_ws = ws is None
+    ws = ws or ProverWorkspace(params, pk)
+    transcript = transcript or Blake2bWrite.init()
+    cs = pk.circuit
+    d = pk.vk.domain
+    n, ext = d.n, d.extended_len()
+    bf = cs.BLINDING_FACTORS
+    u = n - (bf + 1)  # unusable_rows_start; also the l_last row
+    sq = lambda: F.fr_from_mont_limbs(transcript.squeeze_challenge())
+
+    transcript.common_scalar(_m(pk.vk.transcript_repr))  # vk.hash_into
+
+    # ---- advice: witness cells (host, a handful) + blinding rows, committed in the Lagrange basis ----------------
+    syn = circuit.synthesize()
+    blind = synth.uniform_fr(cs.N_ADVICE * (bf + 1), seed + 1)
+    for j, col in enumerate(ws.advice):
+        check(lib.h2mi_memset_zero(col.ptr, n * 32), "zero")
+        rows = sorted(syn.advice[j])
+        if rows:  # assigned cells are contiguous at the top for this circuit: one upload per column
+            lo, hi = rows[0], rows[-1] + 1
+            cells = np.zeros((hi - lo, 4), dtype=np.uint64)
+            for r in rows:
+                cells[r - lo] = _m(syn.advice[j][r])
+            col.upload(cells, offset=lo * 32)
+        col.upload(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
+    _commit_phase(params, ws, transcript, [(c, 0) for c in ws.advice], lagrange=True)
+    # the coefficient / extended forms depend on the columns only: queue them now, they run while the host hashes
+    for col, p, e in zip(ws.advice, ws.advice_polys, ws.advice_cosets):
+        d.lagrange_to_coeff_oop_dev(col, p)
+        d.coeff_to_extended_oop_dev(p, e)
+    theta = sq()  # drawn even without lookups
+    beta, gamma = sq(), sq()
+
+    # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1) -----------------
+    zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
+    for m, z in enumerate(ws.z):
+        gp.permutation_product(d.k, [ws.advice[cs.PERMUTATION_COLUMNS[m]]], [pk.permutation.values[m]], [m], beta, gamma, u, z,
+                               d_start=ws.z_last if m else None, d_last=ws.z_last)
+        z.upload(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
+    # ---- vanishing argument: random polynomial (n coefficients from the prover's rng) ------------------------------
+    check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
+    for i, z in enumerate(ws.z):
+        check(lib.h2mi_msm_bn254_g1_dev(params.g_lagrange_handle, z.ptr, n, ws.points.ptr + 96 * i, None), "commit z")
+    check(lib.h2mi_msm_bn254_g1_dev(params.g_handle, ws.random_poly.ptr, n, ws.points.ptr + 96 * len(ws.z), None), "commit random")
+    for z, p, e in zip(ws.z, ws.z_polys, ws.z_cosets):
+        d.lagrange_to_coeff_oop_dev(z, p)
+        d.coeff_to_extended_oop_dev(p, e)
+    k = len(ws.z) + 1
+    check(lib.h2mi_join(), "join")
+    check(lib.h2mi_g1_batch_normalize_dev(ws.points.ptr, k, ws.affine.ptr, None), "normalize")
+    for p in ws.affine.to_numpy(shape=(4, 8), nbytes=256)[:k]:
+        transcript.write_point(p)
+    y = sq()
+
+    # ---- quotient: evaluate_h on the extended coset, divide by X^n - 1, back to coefficients, commit the pieces ----
+    gp.evaluate_h(d, ws.advice_cosets, pk.fixed.cosets, pk.permutation.cosets, ws.z_cosets, pk.l0, pk.l_last, pk.l_active, beta, gamma, y, ws.h)
+    d.extended_to_coeff_dev(ws.h)
+    pieces = d.quotient_poly_degree
+    _commit_phase(params, ws, transcript, [(ws.h, i * n) for i in range(pieces)], lagrange=False)
+    x = sq()
+    xn = pow(x, n, R)
+
+    # ---- evaluations: every (column, rotation) query at x, in the order create_proof writes them -------------------
+    rot = lambda r: x * pow(d.omega, r % n, R) % R
+    x_next, x_last = rot(1), rot(-(bf + 1))
+    # h(X) = sum_i xn^i h_i(X): the polynomial vanishing.open() queries
+    ptrs = (C.c_void_p * pieces)(*[ws.h.ptr + i * n * 32 for i in range(pieces)])
+    sc = np.ascontiguousarray(np.stack([_m(pow(xn, i, R)) for i in range(pieces)]))
+    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, pieces, n, ws.h_poly.ptr, None), "h_poly")
+    written = []  # (poly, point) whose evaluation goes to the transcript, in order
+    for c, r in cs.ADVICE_QUERIES:
+        written.append((ws.advice_polys[c], rot(r)))
+    for c, r in cs.FIXED_QUERIES:
+        written.append((pk.fixed.polys[c], rot(r)))
+    written.append((ws.random_poly, x))
+    for sp in pk.permutation.polys:
+        written.append((sp, x))
+    for i, zp in enumerate(ws.z_polys):
+        written += [(zp, x), (zp, x_next)]
+        if i + 1 < len(ws.z_polys):
+            written.append((zp, x_last))
+    extra = [(ws.h_poly, x)]  # opened but not written (the verifier recomputes it)
+    for i, (poly, pt) in enumerate(written + extra):
+        pt_l = _m(pt)  # named: the array must outlive the call that reads its memory
+        check(lib.h2mi_fr_eval_poly_dev(poly.ptr, n, pt_l.ctypes.data, ws.evals.ptr + 32 * i, None), "eval")
+    ev = ws.evals.to_numpy(shape=(32, 4))
+    for i in range(len(written)):
+        transcript.write_scalar(ev[i])
+    value = {(id(poly), pt): F.fr_from_mont_limbs(ev[i]) for i, (poly, pt) in enumerate(written + extra)}
+
+    # ---- queries in create_proof's order, then SHPLONK ---------------------------------------------------------------
+    queries = []
+    q = lambda poly, pt: queries.append((poly, pt, value[(id(poly), pt)]))
+    for c, r in cs.ADVICE_QUERIES:
+        q(ws.advice_polys[c], rot(r))
+    for zp in ws.z_polys:  # permutation.open: every set at x and omega x ...
+        q(zp, x)
+        q(zp, x_next)
+    for zp in reversed(ws.z_polys[:-1]):  # ... then all but the last at omega^last x, in reverse
+        q(zp, x_last)
+    for c, r in cs.FIXED_QUERIES:
+        q(pk.fixed.polys[c], rot(r))
+    for sp in pk.permutation.polys:
+        q(sp, x)
+    q(ws.h_poly, x)
+    q(ws.random_poly, x)
+
+    def commit_and_write(poly: DevBuf):
+        _commit_phase(params, ws, transcript, [(poly, 0)], lagrange=False)
+
+    ws.shplonk.create_proof(transcript, queries, commit_and_write)
+    if trace is not None:
+        trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x, ws=ws)
+    proof = transcript.finalize()
+    if own_ws and trace is None:
+        ws.release()
+    return proof

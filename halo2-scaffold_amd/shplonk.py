@@ -1,0 +1,165 @@
+"""ProverSHPLONK: the multi-open argument of create_proof on device-resident polynomials.
+
+Mirror of halo2_proofs::poly::kzg::multiopen::ProverSHPLONK::create_proof as the reference selects it
+(examples/standard_plonk.rs:41-49, src/scaffold.rs:191-199,322-331) — poly/kzg/multiopen/shplonk.rs
+`construct_intermediate_sets` and shplonk/prover.rs [restated from memory of v2023_02_02]:
+
+  queries (polynomial, point, eval) are grouped by polynomial into point sets and polynomials with the same point
+  set form a rotation set; y, v are drawn; per set i:   N_i(X) = sum_j y^j (P_ij(X) - R_ij(X)),  Q_i = N_i / Z_i;
+  h(X) = sum_i v^i Q_i is committed; u is drawn;  L(X) = sum_i v^i Z_{T\\i}(u) sum_j y^j (P_ij(X) - R_ij(u))
+  - Z_T(u) h(X);  L(X) / (X - u), scaled by 1 / Z_{T\\0}(u), is committed.
+
+The bookkeeping (sets, the low-degree remainders R_ij from <= 3 evaluations, scalar coefficients) is host work on a
+handful of field elements; every operation on a polynomial is a device kernel over HBM-resident vectors:
+h2mi_fr_lincomb_dev, h2mi_fr_add_head_dev, h2mi_fr_kate_division_dev and the two commitments (MSM).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import field as F
+from ._lib import check, lib
+from .device import DevBuf
+
+R = F.FR_MODULUS
+_m = F.fr_to_mont_limbs
+
+
+def _interpolate(points, evals):
+    """coefficients (low to high) of the polynomial of degree < len(points) through the given values"""
+    k = len(points)
+    out = [0] * k
+    for j in range(k):
+        num, den = [1], 1
+        for m in range(k):
+            if m == j:
+                continue
+            nxt = [0] * (len(num) + 1)
+            for i, c in enumerate(num):  # num *= (X - points[m])
+                nxt[i + 1] = (nxt[i + 1] + c) % R
+                nxt[i] = (nxt[i] - c * points[m]) % R
+            num = nxt
+            den = den * (points[j] - points[m]) % R
+        scale = evals[j] * pow(den, -1, R) % R
+        for i, c in enumerate(num):
+            out[i] = (out[i] + c * scale) % R
+    return out
+
+
+def _horner(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R
+    return acc
+
+
+def _vanishing_at(roots, z):
+    acc = 1
+    for r in roots:
+        acc = acc * (z - r) % R
+    return acc
+
+
+class RotationSet:
+    def __init__(self, points):
+        self.points = sorted(points)  # BTreeSet<Fr> order: increasing canonical value
+        self.members = []             # (poly DevBuf, [eval at each point])
+
+
+def construct_intermediate_sets(queries):
+    """queries: [(DevBuf poly, point int, eval int)] in create_proof's order -> (rotation sets, super point set)"""
+    by_poly = []  # (poly, {point: eval}) in first-appearance order; polynomials are identified by their buffer
+    for poly, pt, ev in queries:
+        for entry in by_poly:
+            if entry[0] is poly:
+                entry[1].setdefault(pt, ev)
+                break
+        else:
+            by_poly.append((poly, {pt: ev}))
+    sets = []
+    for poly, evs in by_poly:
+        key = frozenset(evs)
+        rs = next((s for s in sets if frozenset(s.points) == key), None)
+        if rs is None:
+            rs = RotationSet(key)
+            sets.append(rs)
+        rs.members.append((poly, [evs[p] for p in rs.points]))
+    return sets, sorted({pt for _, pt, _ in queries})
+
+
+def _lincomb(polys, scalars, n, out: DevBuf):
+    assert len(polys) == len(scalars) <= 24
+    ptrs = (C.c_void_p * len(polys))(*[p.ptr for p in polys])
+    sc = np.ascontiguousarray(np.stack([_m(s) for s in scalars]))
+    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, len(polys), n, out.ptr, None), "lincomb")
+
+
+def _add_head(poly: DevBuf, coeffs):
+    hd = np.ascontiguousarray(np.stack([_m(c) for c in coeffs]))
+    check(lib.h2mi_fr_add_head_dev(poly.ptr, hd.ctypes.data, len(coeffs), None), "add_head")
+
+
+def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf):
+    """out = src / prod (X - root), zero-padded to n coefficients; src is clobbered when there are >= 2 roots"""
+    check(lib.h2mi_memset_zero(out.ptr, n * 32), "zero")
+    cur, length = src, n
+    bufs = [tmp, src]
+    for i, root in enumerate(roots):
+        last = i == len(roots) - 1
+        dst = out if last else bufs[i % 2]
+        b, b_inv = _m(root), _m(pow(root, -1, R))  # named: the arrays must outlive the call that reads their memory
+        check(lib.h2mi_fr_kate_division_dev(cur.ptr, length, b.ctypes.data, b_inv.ctypes.data, dst.ptr, None), "kate_division")
+        cur, length = dst, length - 1
+
+
+class ProverSHPLONK:
+    def __init__(self, params):
+        self.params = params
+        n = params.n
+        self.n = n
+        self._nx, self._tmp, self._q = DevBuf(n * 32), DevBuf(n * 32), [DevBuf(n * 32) for _ in range(4)]
+        self.h_x, self.l_x, self.h2_x = DevBuf(n * 32), DevBuf(n * 32), DevBuf(n * 32)
+
+    def release(self):
+        for b in [self._nx, self._tmp, self.h_x, self.l_x, self.h2_x] + self._q:
+            b.free()
+
+    def create_proof(self, transcript, queries, commit_and_write) -> None:
+        """`commit_and_write(d_poly)` commits a coefficient vector (ParamsKZG::commit), writes the point to the
+        transcript (the caller owns the join / device-to-host step) and returns nothing."""
+        n = self.n
+        y = F.fr_from_mont_limbs(transcript.squeeze_challenge())
+        sets, super_points = construct_intermediate_sets(queries)
+        assert len(sets) <= len(self._q)
+        v = F.fr_from_mont_limbs(transcript.squeeze_challenge())
+        # quotient contributions Q_i = (sum_j y^j (P_ij - R_ij)) / Z_i
+        for i, rs in enumerate(sets):
+            ypow = [pow(y, j, R) for j in range(len(rs.members))]
+            _lincomb([p for p, _ in rs.members], ypow, n, self._nx)
+            rsum = [0] * len(rs.points)
+            for (_, evals), yp in zip(rs.members, ypow):
+                for t, c in enumerate(_interpolate(rs.points, evals)):
+                    rsum[t] = (rsum[t] - yp * c) % R
+            _add_head(self._nx, rsum)
+            _kate_chain(self._nx, n, rs.points, self._tmp, self._q[i])
+        _lincomb(self._q[: len(sets)], [pow(v, i, R) for i in range(len(sets))], n, self.h_x)
+        commit_and_write(self.h_x)
+        u = F.fr_from_mont_limbs(transcript.squeeze_challenge())
+        # linearisation: one linear combination over every opened polynomial and h(X), one constant, one division
+        zt_eval = _vanishing_at(super_points, u)
+        z_diffs = [_vanishing_at([p for p in super_points if p not in rs.points], u) for rs in sets]
+        norm = pow(z_diffs[0], -1, R)  # "normalize coefficients by the coefficient of the first polynomial"
+        polys, scalars, const = [], [], 0
+        for i, rs in enumerate(sets):
+            w = pow(v, i, R) * z_diffs[i] % R * norm % R
+            for j, (poly, evals) in enumerate(rs.members):
+                sc = w * pow(y, j, R) % R
+                polys.append(poly)
+                scalars.append(sc)
+                const = (const - sc * _horner(_interpolate(rs.points, evals), u)) % R
+        polys.append(self.h_x)
+        scalars.append((-zt_eval * norm) % R)
+        _lincomb(polys, scalars, n, self.l_x)
+        _add_head(self.l_x, [const])
+        _kate_chain(self.l_x, n, [u], self._tmp, self.h2_x)
+        commit_and_write(self.h2_x)

@@ -33,13 +33,16 @@ class _Blake2bTranscript:
         self.state.update(PREFIX_CHALLENGE)
         return serde.fr_from_bytes_wide(self.state.copy().digest())
 
-    def common_point(self, affine) -> None:
+    def common_point(self, affine) -> tuple:
+        """absorbs x || y; returns their 32-byte encodings (the writer derives the compressed form from them)"""
         a = np.asarray(affine, dtype=np.uint64).reshape(8)
         if not a.any():
             raise ValueError("cannot write points at infinity to the transcript")
+        xr, yr = _fq_repr(a[:4]), _fq_repr(a[4:])
         self.state.update(PREFIX_POINT)
-        self.state.update(_fq_repr(a[:4]))
-        self.state.update(_fq_repr(a[4:]))
+        self.state.update(xr)
+        self.state.update(yr)
+        return xr, yr
 
     def common_scalar(self, limbs) -> None:
         self.state.update(PREFIX_SCALAR)
@@ -57,8 +60,9 @@ class Blake2bWrite(_Blake2bTranscript):
         return cls(writer)
 
     def write_point(self, affine) -> None:
-        self.common_point(affine)
-        self.writer.write(serde.g1_to_bytes(np.asarray(affine, dtype=np.uint64).reshape(1, 8)).tobytes())
+        # G1Affine::to_bytes on the host (a proof holds eleven points): x with the sign of y in bit 6 of the last byte
+        xr, yr = self.common_point(affine)
+        self.writer.write(xr[:31] + bytes([xr[31] | ((yr[0] & 1) << 6)]))
 
     def write_scalar(self, limbs) -> None:
         self.common_scalar(limbs)

@@ -11,6 +11,11 @@ Conventions restated:
   columns: advice a, b, c (equality enabled in that order), fixed q_a, q_b, q_c, q_ab, constant
   gate: q_a*a + q_b*b + q_c*c + q_ab*a*b + constant = 0 on every row
   blinding_factors = 5, usable rows u = n - 6, last_rotation = -6, permutation chunk length = degree - 2 = 1
+  advice rows u .. n-1 (six rows: `unusable_rows_start = n - (blinding_factors + 1)`) and rows u+1 .. n-1 of every
+  permutation product (five rows) hold the prover's random blinding values
+  copy constraints: permutation/keygen.rs `Assembly::copy` (cycles merged smaller-into-larger, then the two
+  mapping entries swapped), fed by the reference's four `copy_advice` calls in their order
+  (src/circuits/standard_plonk.rs:91-92,100-101): constrain_equal(new cell, x's cell (a, 0))
   identity permutation of column j at row i: DELTA^j * omega^i, DELTA = 7^(2^28)
   terms of h(X), combined by Horner in y in this order: gate; l_0 (1 - z_0); l_last (z_2^2 - z_2);
   l_0 (z_m - z_{m-1}(omega^last X)) for m = 1, 2; for every column m:
@@ -26,6 +31,37 @@ BLINDING_FACTORS = 5
 CS_DEGREE = 3
 
 
+class Assembly:
+    """permutation/keygen.rs Assembly: mapping[col][row] = the next cell of the cycle; sigma_col(omega^row) =
+    DELTA^col' omega^row' for (col', row') = mapping[col][row]."""
+
+    def __init__(self, n_columns: int, n: int):
+        self.mapping = [[(c, r) for r in range(n)] for c in range(n_columns)]
+        self.aux = [[(c, r) for r in range(n)] for c in range(n_columns)]
+        self.sizes = [[1] * n for _ in range(n_columns)]
+
+    def copy(self, left, right):
+        (lc, lr), (rc, rr) = left, right
+        left_cycle, right_cycle = self.aux[lc][lr], self.aux[rc][rr]
+        if left_cycle == right_cycle:
+            return
+        if self.sizes[left_cycle[0]][left_cycle[1]] < self.sizes[right_cycle[0]][right_cycle[1]]:
+            left_cycle, right_cycle = right_cycle, left_cycle
+        self.sizes[left_cycle[0]][left_cycle[1]] += self.sizes[right_cycle[0]][right_cycle[1]]
+        i = right_cycle
+        while True:
+            self.aux[i[0]][i[1]] = left_cycle
+            i = self.mapping[i[0]][i[1]]
+            if i == right_cycle:
+                break
+        self.mapping[lc][lr], self.mapping[rc][rr] = self.mapping[rc][rr], self.mapping[lc][lr]
+
+
+# the reference's synthesize(): x.copy_advice(.., a, 1), (.., b, 1), (.., a, 2), (.., b, 2) — each is
+# constrain_equal(newly assigned cell, x's cell) with x assigned at (a, 0)
+STANDARD_PLONK_COPIES = [((0, 1), (0, 0)), ((1, 1), (0, 0)), ((0, 2), (0, 0)), ((1, 2), (0, 0))]
+
+
 class StandardPlonkInstance:
     """the circuit at 2^k rows with witness x (rows 0..2 as the reference assigns them) and seeded blinding."""
 
@@ -35,32 +71,40 @@ class StandardPlonkInstance:
         assert n >= 16
         self.u = n - (BLINDING_FACTORS + 1)  # index of the l_last row
         self.dom = o.Domain(k, CS_DEGREE)
-        rnd = o.unpack(o.random_field_limbs(8 * n, seed), R)
-        it = iter(rnd)
+        self.seed = seed
+        # seeded stand-ins for the prover's rng (the reference passes OsRng): stream seed+1 = advice blinding
+        # (column-major, six rows each), seed+2 = permutation-product blinding (set-major, five rows each),
+        # seed+3 = the vanishing argument's random polynomial
+        nb = BLINDING_FACTORS + 1
+        rnd = o.unpack(o.random_field_limbs(3 * nb, seed + 1), R)
         # advice (reference src/circuits/standard_plonk.rs:83-108)
         a, b, c = [0] * n, [0] * n, [0] * n
         a[0] = x
         a[1], b[1], c[1] = x, x, x * x % R
         a[2], b[2], c[2] = x, x, (x * x + 72) % R
-        for col in (a, b, c):  # blinding rows
-            for r in range(self.u + 1, n):
-                col[r] = next(it)
+        for j, col in enumerate((a, b, c)):  # rows unusable_rows_start .. n-1
+            for t in range(nb):
+                col[self.u + t] = rnd[j * nb + t]
         self.advice = [a, b, c]
         q_a, q_b, q_c, q_ab, const = ([0] * n for _ in range(5))
         q_c[1], q_ab[1] = R - 1, 1
         q_c[2], q_ab[2], const[2] = R - 1, 1, 72
         self.fixed = [q_a, q_b, q_c, q_ab, const]
-        # copy constraints: a0 = a1 = b1 = a2 = b2 (x.copy_advice): one cycle over cells (col, row)
-        cycle = [(0, 0), (0, 1), (1, 1), (0, 2), (1, 2)]
+        # copy constraints: a0 = a1 = b1 = a2 = b2, merged as Assembly::copy merges them
         w = self.dom.omega
-        self.omega_pows = [pow(w, i, R) for i in range(n)]
-        ident = lambda j, i: pow(FR_DELTA, j, R) * self.omega_pows[i] % R
+        self.omega_pows = [1] * n
+        for i in range(1, n):
+            self.omega_pows[i] = self.omega_pows[i - 1] * w % R
+        dpow = [pow(FR_DELTA, j, R) for j in range(3)]
+        ident = lambda j, i: dpow[j] * self.omega_pows[i] % R
         sigma = [[ident(j, i) for i in range(n)] for j in range(3)]
-        for idx, cell in enumerate(cycle):
-            nxt = cycle[(idx + 1) % len(cycle)]
-            sigma[cell[0]][cell[1]] = ident(*nxt)
+        asm = Assembly(3, 8)  # only the first rows take part
+        for left, right in STANDARD_PLONK_COPIES:
+            asm.copy(left, right)
+        self.copy_mapping = {(c, r): asm.mapping[c][r] for c in range(3) for r in range(8) if asm.mapping[c][r] != (c, r)}
+        for (c_, r_), nxt in self.copy_mapping.items():
+            sigma[c_][r_] = ident(*nxt)
         self.sigma = sigma
-        self._rand = it
         # Lagrange helpers
         self.l0 = [1] + [0] * (n - 1)
         self.l_last = [0] * n
@@ -71,6 +115,7 @@ class StandardPlonkInstance:
         n, u = self.n, self.u
         zs = []
         start = 1
+        zblind = iter(o.unpack(o.random_field_limbs(3 * BLINDING_FACTORS, self.seed + 2), R))
         for m in range(3):
             z = [0] * n
             z[0] = start
@@ -80,7 +125,7 @@ class StandardPlonkInstance:
                 den = (v + beta * self.sigma[m][i] + gamma) % R
                 z[i + 1] = z[i] * num % R * pow(den, -1, R) % R
             for r in range(u + 1, n):
-                z[r] = next(self._rand)
+                z[r] = next(zblind)
             start = z[u]
             zs.append(z)
         return zs

@@ -55,7 +55,8 @@ def test_random_fill_add_head_match_host(gpu):
         assert np.array_equal(d.to_numpy(shape=(n, 4)), synth.uniform_fr(n, seed, start))
     assert lib.h2mi_fr_random_dev(d.ptr, n, 1 << 32, 0, None) == h2.lib.h2mi_fr_random_dev(d.ptr, 0, 1, 0, None) == -1
     v = 0x1234567890ABCDEF1234567890ABCDEF % o.R
-    assert lib.h2mi_fr_fill_dev(d.ptr, n, _fr(h2, v).ctypes.data, None) == 0
+    vl = _fr(h2, v)
+    assert lib.h2mi_fr_fill_dev(d.ptr, n, vl.ctypes.data, None) == 0
     assert o.unpack(d.to_numpy(shape=(n, 4)), o.R) == [v] * n
     head = [o.R - 1, 5, 0, o.R - v]
     hl = np.ascontiguousarray(np.stack([_fr(h2, x) for x in head]))
@@ -132,7 +133,8 @@ def test_caller_streams_interleaved_with_library_stream(gpu):
             s2 = sp[(i + rnd + 1) % 3]
             if rnd == 0:
                 assert lib.h2mi_ntt_bn254_fr_dev(d_ntt[i].ptr, k, wl.ctypes.data, None, None, s2) == 0
-            assert lib.h2mi_fr_eval_poly_dev(d_scal[i].ptr, n, _fr(h2, pt + i).ctypes.data, d_ev.ptr + 32 * i, s2) == 0
+            pl = _fr(h2, pt + i)
+            assert lib.h2mi_fr_eval_poly_dev(d_scal[i].ptr, n, pl.ctypes.data, d_ev.ptr + 32 * i, s2) == 0
         for s in streams[1:]:
             s.synchronize()
         assert lib.h2mi_sync() == 0
