@@ -90,6 +90,24 @@ def test_create_proof_bytes_match_oracle(gpu, k):
     params.release()
 
 
+def test_device_proofs_equal_committed_golden_bytes(gpu):
+    """tests/golden/standard_plonk_proofs.json (k = 5: the reference's own size; k = 8: BASELINE configs[0])"""
+    import json
+    import os
+
+    from halo2_scaffold_amd import circuits, prover
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "standard_plonk_proofs.json")))
+    assert int(gold["srs_secret"], 16) == SRS_SECRET
+    for case in gold["cases"]:
+        params, vk, pk = _setup(gpu, case["k"])
+        assert vk.to_bytes().hex() == case["vk_bytes"]
+        proof = prover.create_proof(params, pk, circuits.StandardPlonk(int(case["witness_x"], 16)), case["seed"])
+        assert proof.hex() == case["proof"]
+        pk.release()
+        params.release()
+
+
 def test_unsatisfied_witness_is_rejected(gpu):
     """a witness that breaks the gate (c_1 != x^2) gives a quotient with a remainder: the oracle verifier rejects"""
     from halo2_scaffold_amd import circuits, prover
