@@ -321,6 +321,9 @@ def time_create_proof(h2, R, args):
         lib.h2mi_profile_query(name.encode(), C.byref(t_), C.byref(c_))
         kernels[name] = {"ms": round(t_.value, 4), "launches": c_.value}
     lib.h2mi_profile_reset()
+    tr = {}
+    prover.create_proof(R.params, pk, circuits.StandardPlonk(8), 8, ws=ws, trace=tr)  # host-side phase boundaries (each ends in a device sync)
+    phase_ms = tr.get("phase_ms")
     ws.release()
     pk.release()
     times.sort()
@@ -334,6 +337,7 @@ def time_create_proof(h2, R, args):
         "device_kernel_ms_sum": round(tot.value, 3),
         "kernel_launches": cnt.value,
         "kernels_ms": kernels,
+        "phase_ms": phase_ms,
         "what": ("create_proof() of the reference's StandardPlonk circuit at 2^%d rows: real witness and copy constraints, keygen'd proving key, "
                  "Blake2b transcript on the host, 11 MSM + 13 NTT + permutation products + evaluate_h + 21 evaluations + SHPLONK on the device; "
                  "wall-clock, host-inclusive; rng = seeded SplitMix64 (the reference uses OsRng); verified by tests/test_gpu_prover.py, not here" % args.k),

@@ -33,6 +33,7 @@ namespace h2 {
 constexpr uint32_t S0_MAX = 128;  // most entries per accumulation chunk (see accum_chunk_len)
 constexpr uint32_t S1 = 8;       // partials per fold task
 constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
+constexpr size_t SHIFT_MIN_N = 4096;  // base sets below this never use the dominant-value shift
 constexpr uint32_t HOT_MIN = 64; // a bucket with more folded partials than this gets a whole workgroup (k_msm_finish_hot)
 
 // Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
@@ -72,6 +73,7 @@ struct Slot {
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
   uint8_t* g = nullptr;                             // weighted partials (<= 32)
   uint64_t* stats = nullptr;                        // [0] = insertions
+  fe* shift = nullptr;                              // the dominant scalar value this MSM subtracts (k_msm_pick_shift), Montgomery
   hipEvent_t input_ready = nullptr, head_done = nullptr, accum_done = nullptr, tail_done = nullptr;
   bool tail_pending = false, accum_pending = false, head_pending = false;
   bool tail_ever = false, accum_ever = false, head_ever = false;  // the events have been recorded at least once
@@ -85,6 +87,8 @@ constexpr int NSLOT = 4;
 
 struct Bases {
   size_t n = 0;
+  size_t stride = 0;            // table row length: n + 1 (slot n = the sum of all n bases, see k_msm_pick_shift)
+  bool has_sum = false;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
   uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
@@ -129,6 +133,33 @@ __global__ void __launch_bounds__(256) k_msm_table_next(const uint8_t* prev, uin
   f29_pack(x, q.x.v);
   f29_pack(y, q.y.v);
   affine_store(next + i * 64, q);
+}
+
+// table slot n of every window: 2^(c*w) * B for B = the sum of the n bases (a Jacobian Montgomery-2^256 point, the
+// result of an all-ones MSM at registration); thread w does its c*w doublings and one inversion
+__global__ void __launch_bounds__(64) k_msm_table_sum_point(const uint8_t* sum_jac, uint8_t* table, size_t stride, size_t n, uint32_t W, uint32_t c) {
+  const uint32_t w = threadIdx.x;
+  if (w >= W) return;
+  const jac j = jac_load(sum_jac);
+  affine out;
+  out.x = fe_zero();
+  out.y = fe_zero();
+  if (!fe_is_zero(j.z)) {
+    const affine a = xyzz_to_affine(jac_to_xyzz(j));  // Montgomery-2^256
+    f29 x = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.x.v)), y = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.y.v));
+    if (w) {
+      xyzz29 acc = xyzz29_dbl_affine(x, y);
+      for (uint32_t k = 1; k < c * w; k++) acc = xyzz29_dbl(acc);
+      xyzz29_to_affine(acc, x, y);
+    }
+    f29_pack(x, out.x.v);
+    f29_pack(y, out.y.v);
+  }
+  affine_store(table + ((size_t)w * stride + n) * 64, out);
+}
+__global__ void __launch_bounds__(256) k_msm_fill_one(fe* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fe_store(&out[i], fe_one<FrP>());
 }
 
 // ---- per call -------------------------------------------------------------------------------------
@@ -191,16 +222,45 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
   return x;
 }
 
+// Dominant-value shift.  Real prover columns are often one value repeated (a permutation grand product is constant
+// wherever a row takes no part in a copy constraint — almost everywhere in a padded circuit — and selector-like
+// columns are runs of one constant): every window of such a scalar lands in ONE bucket, and the whole MSM in W
+// buckets.  With B = sum_i P_i registered as an extra base (table slot n),
+//     sum_i s_i P_i = sum_i (s_i - v) P_i + v B,
+// so subtracting the majority value v turns the column into a sparse one (zero digits are never materialised) plus
+// one more scalar.  k_msm_pick_shift samples 64 evenly spaced scalars and takes v = the value held by >= 40 of them,
+// else 0 (uniform data: nothing changes).  Only for MSMs over all registered bases (B is their sum).
+__global__ void __launch_bounds__(64) k_msm_pick_shift(const fe* scalars, size_t n, fe* shift_out) {
+  __shared__ fe smp[64];
+  const uint32_t lane = threadIdx.x;
+  size_t idx = (n / 64) * lane + n / 128;
+  if (idx >= n) idx = n - 1;
+  const fe v = fe_load(&scalars[idx]);
+  smp[lane] = v;
+  __syncthreads();
+  uint32_t same = 0;
+  for (uint32_t j = 0; j < 64; j++) same += fe_eq(v, smp[j]) ? 1u : 0u;
+  const uint64_t winners = __ballot(same >= 40);
+  if (lane == 0) fe_store(shift_out, winners ? smp[__ffsll((unsigned long long)winners) - 1] : fe_zero());
+}
+// scalar i of an MSM over n (+ 1) points as canonical integer: s_i - shift for the caller's scalars, shift itself for
+// the sum point
+__device__ __forceinline__ fe msm_scalar(const fe* scalars, size_t i, size_t n, const fe* shift) {
+  if (!shift) return fe_from_mont<FrP>(fe_load(&scalars[i]));
+  const fe v = fe_load(shift);
+  return fe_from_mont<FrP>(i < n ? fe_sub<FrP>(fe_load(&scalars[i]), v) : v);
+}
+
 template <uint32_t CT>
-__global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, uint32_t c, uint32_t W, uint32_t lb, uint32_t nbins,
-                                                         uint32_t ntiles, uint32_t* cnt_out) {
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb,
+                                                         uint32_t nbins, uint32_t ntiles, uint32_t* cnt_out) {
   __shared__ uint32_t cnt[NBINS_MAX];
   const uint32_t tid = threadIdx.x;
   if (tid < NBINS_MAX) cnt[tid] = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * P1_TS + tid;
-  if (i < n) {
-    fe s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+  if (i < n + (shift ? 1 : 0)) {
+    fe s = msm_scalar(scalars, i, n, shift);
     for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> lb], 1u); });
   }
   __syncthreads();
@@ -211,8 +271,8 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size
 extern __shared__ uint4 h2_msm_smem[];
 
 template <uint32_t CT>
-__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
-                                                           uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W,
+                                                           uint32_t lb, uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
                                                            uint8_t* keys_out) {
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
   uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);             // P1_TS * W payloads
@@ -226,7 +286,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   __syncthreads();
   size_t i = (size_t)tile * P1_TS + tid;
   fe s;
-  const bool live = i < n;
+  const bool live = i < n + (shift ? 1 : 0);
   // compile-time windows: the rank each entry drew from its bin counter is kept in registers, so the digits
   // are walked once; run-time c walks them twice (count, then place) to stay out of scratch arrays
   constexpr uint32_t WK = CT ? (255 + CT - 1) / CT : 1;
@@ -234,7 +294,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
 #pragma unroll
   for (uint32_t w = 0; w < WK; w++) ent[w] = 0xFFFFFFFFu;
   if (live) {
-    s = fe_from_mont<FrP>(fe_load(&scalars[i]));
+    s = msm_scalar(scalars, i, n, shift);
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
       uint32_t r = atomicAdd(&cnt[bucket >> lb], 1u);
       if (CT) {
@@ -837,7 +897,7 @@ static void free_bases(Bases* B) {
     hipFree(S.off); hipFree(S.s0_dev);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.dense);
-    hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats);
+    hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats); hipFree(S.shift);
     if (S.input_ready) hipEventDestroy(S.input_ready);
     if (S.head_done) hipEventDestroy(S.head_done);
     if (S.accum_done) hipEventDestroy(S.accum_done);
@@ -856,24 +916,27 @@ static void free_bases(Bases* B) {
     }                                                          \
   } while (0)
 
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
+
 static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s) {
   if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
   Bases* B = new Bases();
   B->n = n;
+  B->stride = n + 1;
   B->c = pick_window(n);
   B->W = (255 + B->c - 1) / B->c;
   B->nb = 1u << (B->c - 1);
   B->logNl = (B->c - 1 + 1) / 2;
   B->logNh = (B->c - 1) - B->logNl;
-  if ((uint64_t)n * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
-  const size_t nW = n * B->W;
+  if ((uint64_t)B->stride * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
+  const size_t nW = B->stride * B->W;
   // partial sums of one accumulation: one per chunk (at most whole rounds of the resident grid) + one per bucket
   B->max_tasks0 = accum_rounds((uint32_t)nW) * ACCUM_RESIDENT_CHUNKS + B->nb + 1;
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
   B->nbins = B->nb >> B->lb;  // <= NBINS_MAX
-  const size_t ntiles_max = (n + P1_TS - 1) / P1_TS;
+  const size_t ntiles_max = (B->stride + P1_TS - 1) / P1_TS;
   const size_t bin_cells = (size_t)B->nbins * ntiles_max + 1;
   if (bin_cells >= ((size_t)1 << 31)) { free_bases(B); return H2MI_ERANGE; }
   // the own scans (k_scan_seg) take 16-byte vectors: the [bin][tile] matrix has 512 rows and the task arrays
@@ -897,6 +960,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * PART_BYTES);
     H2_ALLOC(S.g, (size_t)64 * PART_BYTES);
     H2_ALLOC(S.stats, 64);
+    H2_ALLOC(S.shift, 32);
     if (hipEventCreateWithFlags(&S.input_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&S.head_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&S.accum_done, hipEventDisableTiming) != hipSuccess ||
@@ -914,13 +978,42 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   for (uint32_t w = 1; w < B->W; w++) {
     const bool prof_ = prof_on("k_msm_table_next");
     if (prof_) prof_begin("k_msm_table_next", s);
-    hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * n * 64),
-                       B->table + (size_t)w * n * 64, n, B->c);
+    hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, (const uint8_t*)(B->table + (size_t)(w - 1) * B->stride * 64),
+                       B->table + (size_t)w * B->stride * 64, n, B->c);
     if (prof_) prof_end(s);
   }
+  // slot n of every window stays the identity until the sum point is known
+  for (uint32_t w = 0; w < B->W; w++)
+    if (hipMemsetAsync(B->table + ((size_t)w * B->stride + n) * 64, 0, 64, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
-  uint64_t h = g_next_handle++;
-  g_bases[h] = B;
+  // B = sum of the bases, by an all-ones MSM through the pipeline just built (the shift is off while has_sum is
+  // false), then its own table column.  Small base sets never use the shift (k_msm_pick_shift samples 64 scalars).
+  const uint64_t h = g_next_handle++;
+  g_bases[h] = B;  // msm_join_all walks the registered handles
+  if (n >= SHIFT_MIN_N && !getenv("H2MI_MSM_NO_SHIFT")) {
+    fe* ones = nullptr;
+    uint8_t* sum = nullptr;
+    int rc = H2MI_OK;
+    if (hipMalloc((void**)&ones, n * 32) != hipSuccess || hipMalloc((void**)&sum, 96) != hipSuccess) rc = H2MI_ENOMEM;
+    if (!rc) {
+      hipLaunchKernelGGL(k_msm_fill_one, dim3(ceil_div_u32(n, 256)), dim3(256), 0, s, ones, n);
+      rc = msm_dev(B, ones, n, sum, s);
+    }
+    if (!rc) rc = msm_join_all(s);
+    if (!rc) {
+      hipLaunchKernelGGL(k_msm_table_sum_point, dim3(1), dim3(64), 0, s, (const uint8_t*)sum, B->table, B->stride, n, B->W, B->c);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = H2MI_EHIP;
+    }
+    hipFree(ones);
+    hipFree(sum);
+    if (rc) {
+      hipDeviceSynchronize();
+      g_bases.erase(h);
+      free_bases(B);
+      return rc;
+    }
+    B->has_sum = true;
+  }
   *handle_out = h;
   return H2MI_OK;
 }
@@ -941,7 +1034,10 @@ static TailDesc tail_desc(const Bases* B, const Slot& S);
 // On a caller-provided stream everything runs in order on that stream.
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   const uint32_t nb = B->nb, W = B->W;
-  const uint32_t total = (uint32_t)(n * W);
+  // dominant-value shift: only when the MSM covers every registered base (the extra base is their sum)
+  const bool shifted = B->has_sum && n == B->n;
+  const size_t n_eff = n + (shifted ? 1 : 0);
+  const uint32_t total = (uint32_t)(n_eff * W);
   const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
@@ -977,7 +1073,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     if (S.tail_ever) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
   }
   S.last_stream = s;
-  const uint32_t ntiles = ceil_div_u32(n, P1_TS);
+  const uint32_t ntiles = ceil_div_u32(n_eff, P1_TS);
+  const fe* shift = shifted ? S.shift : nullptr;
   static bool attr_set = false;
   if ((size_t)P1_TS * W * 6 > 150 * 1024) return H2MI_ERANGE;
   if (!attr_set) {  // the scatter kernel stages up to 144 KiB of pairs in LDS (W = 24; 90 KiB at W = 15)
@@ -992,10 +1089,11 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     // the partition's first level reads the scalars twice (count, scatter): both stay on s, so work queued
     // on s after this call may overwrite them
 #define H2_BIN_COUNT(CT) \
-  H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
-#define H2_BIN_SCATTER(CT)                                                                                                              \
-  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 6, s, (const fe*)d_scalars, n, B->n, B->c, W, \
+  H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, shift, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
+#define H2_BIN_SCATTER(CT)                                                                                                                        \
+  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 6, s, (const fe*)d_scalars, n, shift, B->stride, B->c, W, \
             B->lb, B->nbins, ntiles, (const uint32_t*)S.binbase, S.vals[0], S.bkeys)
+    if (shifted) H2_LAUNCH("k_msm_pick_shift", k_msm_pick_shift, 1, 64, 0, s, (const fe*)d_scalars, n, S.shift);
     switch (B->c) {
       case 13: H2_BIN_COUNT(13); break;
       case 15: H2_BIN_COUNT(15); break;

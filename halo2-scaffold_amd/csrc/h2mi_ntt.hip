@@ -267,8 +267,12 @@ __global__ void __launch_bounds__(256) k_powers(fe* out, size_t n, const fe* lo,
 
 // Horner in y = x^T over the interleaved coefficient classes i = t (mod T): coalesced loads, one
 // multiplication per coefficient; thread t contributes x^t * P_t(y); block sums go to `partial`.
-__global__ void __launch_bounds__(256) k_eval_poly(const fe* poly, size_t n, uint32_t logT, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
+struct PolyList {
+  const fe* p[24];
+};
+__global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uint32_t logT, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
   __shared__ fe red[256];
+  const fe* poly = polys.p[blockIdx.y];
   const uint32_t T = 1u << logT, t = blockIdx.x * blockDim.x + threadIdx.x;
   f29 y = f29_mul<F9>(pow2tab(lo, hi, h, T - 1), pow2tab(lo, hi, h, 1));  // x^T (Mont261)
   f29 acc = f29_zero();
@@ -283,11 +287,12 @@ __global__ void __launch_bounds__(256) k_eval_poly(const fe* poly, size_t n, uin
     if (threadIdx.x < s) red[threadIdx.x] = fe_add<Fr>(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) fe_store(&partial[blockIdx.x], red[0]);
+  if (threadIdx.x == 0) fe_store(&partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x], red[0]);
 }
-// out = sum of `count` field elements (single block)
+// out[y] = sum of the `count` field elements of row y (one block per row)
 __global__ void __launch_bounds__(256) k_sum_fe(const fe* in, uint32_t count, fe* out) {
   __shared__ fe red[256];
+  in += (size_t)blockIdx.x * count;
   fe acc = fe_zero();
   for (uint32_t i = threadIdx.x; i < count; i += 256) acc = fe_add<Fr>(acc, fe_load(&in[i]));
   red[threadIdx.x] = acc;
@@ -296,7 +301,7 @@ __global__ void __launch_bounds__(256) k_sum_fe(const fe* in, uint32_t count, fe
     if (threadIdx.x < s) red[threadIdx.x] = fe_add<Fr>(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) fe_store(out, red[0]);
+  if (threadIdx.x == 0) fe_store(&out[blockIdx.x], red[0]);
 }
 
 // kate_division: q_i = sum_{j > i} a_j b^(j-i-1) = b^-(i+1) * SUFFIX(i+1), SUFFIX(j) = sum_{l >= j} a_l b^l.
@@ -618,6 +623,36 @@ __global__ void __launch_bounds__(256) k_perm_numden(PermArgs a, size_t n, uint3
   }
   fe_store(&num[i], pn);
   fe_store(&den[i], pd);
+}
+// the same for every set of a permutation argument at once: t = set * u + i over the concatenated usable rows
+// (set = chunk of `chunk` consecutive columns); the running product then chains the sets by itself
+__global__ void __launch_bounds__(256) k_perm_numden_sets(PermArgs a, uint32_t chunk, size_t total, uint32_t u, const fe* wlo, const fe* whi, uint32_t wh,
+                                                           fe* num, fe* den) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint32_t set = (uint32_t)(t / u), i = (uint32_t)(t - (size_t)set * u);
+  const f29 w = pow2tab(wlo, whi, wh, i);  // omega^i (Mont261)
+  fe pn = fe_one<Fr>(), pd = fe_one<Fr>();
+  for (uint32_t j = set * chunk; j < a.m && j < (set + 1) * chunk; j++) {
+    const fe v = fe_load(&a.value[j][i]);
+    fe idt;
+    f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_unpack(a.beta_delta[j].v), w)), idt.v);  // beta delta^j omega^i (Mont256)
+    const fe vg = fe_add<Fr>(v, a.gamma);
+    pn = fe_mul<Fr>(pn, fe_add<Fr>(vg, idt));
+    pd = fe_mul<Fr>(pd, fe_add<Fr>(vg, fe_mul<Fr>(a.beta, fe_load(&a.sigma[j][i]))));
+  }
+  fe_store(&num[t], pn);
+  fe_store(&den[t], pd);
+}
+struct ZOut {
+  fe* z[8];
+};
+// z_set[i] = product of every ratio before (set, i) in the concatenated order: R[set * u + i - 1], one at the very start
+__global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u, ZOut out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, set = blockIdx.y;
+  if (i > u) return;
+  const size_t t = (size_t)set * u + i;
+  fe_store(&out.z[set][i], t ? fe_load(&R[t - 1]) : fe_one<Fr>());
 }
 __global__ void k_fr_inv_one(const fe* in, fe* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(out, fe_inv_gcd<Fr>(fe_load(in)));  // one inversion on the critical path
@@ -1023,12 +1058,8 @@ int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_strea
 }
 
 
-int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream) {
-  H2_REQUIRE_INIT();
-  if (!d_poly || !point || !d_out || n == 0) return H2MI_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  CallScope scope_;
-  hipStream_t s = pick_stream(stream);
+// `count` polynomials of n coefficients at one point: one launch (blockIdx.y = polynomial) + one row-sum launch
+static int eval_polys(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, hipStream_t s) {
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
   if (log_n > 30) return H2MI_ERANGE;
@@ -1037,11 +1068,32 @@ int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4],
   int rc = get_powtab(point, logT, s, &pt);  // x^i, i < T
   if (rc) return rc;
   const uint32_t nblocks = (1u << logT) / 256;
-  rc = ensure_tmp(nblocks + 8, s);
+  rc = ensure_tmp((size_t)nblocks * count + 8, s);
   if (rc) return rc;
-  H2_LAUNCH("k_eval_poly", k_eval_poly, nblocks, 256, 0, s, (const fe*)d_poly, n, logT, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
-  H2_LAUNCH("k_sum_fe", k_sum_fe, 1, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
+  PolyList pl;
+  memset(&pl, 0, sizeof(pl));
+  for (size_t i = 0; i < count; i++) pl.p[i] = (const fe*)d_polys[i];
+  H2_LAUNCH("k_eval_poly", k_eval_poly, dim3(nblocks, (uint32_t)count), 256, 0, s, pl, n, logT, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
+  H2_LAUNCH("k_sum_fe", k_sum_fe, (uint32_t)count, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
   return release_tmp(s);
+}
+
+int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_poly || !point || !d_out || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  return eval_polys(&d_poly, 1, n, point, d_out, pick_stream(stream));
+}
+
+int h2mi_fr_eval_polys_dev(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_polys || !point || !d_out || n == 0 || count == 0 || count > 24) return H2MI_EINVAL;
+  for (size_t i = 0; i < count; i++)
+    if (!d_polys[i]) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  return eval_polys(d_polys, count, n, point, d_out, pick_stream(stream));
 }
 
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out, h2mi_stream_t stream) {
@@ -1177,6 +1229,60 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
   if (rc) return rc;
   H2_LAUNCH("k_perm_write", k_perm_write, ceil_div_u32((uint64_t)usable_rows + 1, 256), 256, 0, s, (const fe*)num, (const fe*)d_start_or_null, usable_rows,
             (fe*)d_z, (fe*)d_last_or_null);
+  return release_tmp(s);
+}
+
+int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
+                                        uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows,
+                                        const uint64_t omega[4], void* const* d_z, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8 || chunk_len == 0) return H2MI_EINVAL;
+  if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  const uint32_t sets = (m + chunk_len - 1) / chunk_len;
+  PermArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = m;
+  a.beta = host_fe(beta);
+  a.gamma = host_fe(gamma);
+  for (uint32_t j = 0; j < m; j++) {
+    if (!d_values[j] || !d_sigmas[j]) return H2MI_EINVAL;
+    a.value[j] = (const fe*)d_values[j];
+    a.sigma[j] = (const fe*)d_sigmas[j];
+    a.beta_delta[j] = host_fe(beta_delta_pows + 4 * j);
+  }
+  ZOut zo;
+  memset(&zo, 0, sizeof(zo));
+  for (uint32_t q = 0; q < sets; q++) {
+    if (!d_z[q]) return H2MI_EINVAL;
+    zo.z[q] = (fe*)d_z[q];
+  }
+  PowTab pw;
+  int rc = get_powtab(omega, k, s, &pw);
+  if (rc) return rc;
+  const size_t total = (size_t)sets * usable_rows;
+  const uint32_t nblocks = ceil_div_u32(total, MS_TILE);
+  rc = ensure_tmp(3 * total + 2 * (size_t)nblocks + 2, s);
+  if (rc) return rc;
+  fe* num = g_tmp;
+  fe* P = num + total;
+  fe* S = P + total;
+  fe* totals = S + total;
+  fe* offsets = totals + nblocks;
+  fe* inv_total = offsets + nblocks;
+  H2_LAUNCH("k_perm_numden_sets", k_perm_numden_sets, ceil_div_u32(total, 256), 256, 0, s, a, chunk_len, total, usable_rows, (const fe*)pw.lo, (const fe*)pw.hi,
+            pw.h, num, P);
+  H2_HIP(hipMemcpyAsync(S, P, total * 32, hipMemcpyDeviceToDevice, s));
+  rc = mulscan(P, total, 0, totals, offsets, s);
+  if (!rc) rc = mulscan(S, total, 1, totals, offsets, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_fr_inv_one", k_fr_inv_one, 1, 64, 0, s, (const fe*)(P + (total - 1)), inv_total);
+  H2_LAUNCH("k_perm_ratio", k_perm_ratio, ceil_div_u32(total, 256), 256, 0, s, (const fe*)num, (const fe*)P, (const fe*)S, (const fe*)inv_total, total, num);
+  rc = mulscan(num, total, 0, totals, offsets, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), sets), 256, 0, s, (const fe*)num, usable_rows, zo);
   return release_tmp(s);
 }
 

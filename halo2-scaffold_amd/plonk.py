@@ -70,3 +70,21 @@ def permutation_product(k: int, values, sigmas, column_indices, beta: int, gamma
     check(lib.h2mi_plonk_permutation_product_dev(vp, sp, m, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data, w.ctypes.data,
                                                  d_start.ptr if d_start is not None else None, d_z.ptr,
                                                  d_last.ptr if d_last is not None else None, None), "permutation_product")
+
+
+def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamma: int, usable_rows: int, d_zs) -> None:
+    """Every set of the permutation argument in one device pass (plonk/permutation/prover.rs `Argument::commit`):
+    `values` / `sigmas` are the equality-enabled columns in argument order, chunked by `chunk_len` = cs.degree() - 2;
+    d_zs[s] receives rows 0 .. usable_rows of set s, chained through the previous set's last value."""
+    m = len(values)
+    sets = -(-m // chunk_len)
+    assert m == len(sigmas) and 1 <= m <= 8 and len(d_zs) == sets
+    r = F.FR_MODULUS
+    vp = (C.c_void_p * m)(*[b.ptr for b in values])
+    sp = (C.c_void_p * m)(*[b.ptr for b in sigmas])
+    zp = (C.c_void_p * sets)(*[b.ptr for b in d_zs])
+    bd = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(beta * pow(FR_DELTA, j, r) % r) for j in range(m)]))
+    b_, g_ = F.fr_to_mont_limbs(beta), F.fr_to_mont_limbs(gamma)
+    w = F.fr_to_mont_limbs(F.omega_for(k))
+    check(lib.h2mi_plonk_permutation_products_dev(vp, sp, m, chunk_len, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data, w.ctypes.data,
+                                                  zp, None), "permutation_products")

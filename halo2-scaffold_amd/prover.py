@@ -50,35 +50,45 @@ class ProverWorkspace:
         self.z = [DevBuf(n * 32) for _ in range(nz)]
         self.z_polys = [DevBuf(n * 32) for _ in range(nz)]
         self.z_cosets = [DevBuf(ext * 32) for _ in range(nz)]
-        self.z_last = DevBuf(32)
         self.random_poly = DevBuf(n * 32)
         self.h = DevBuf(ext * 32)
         self.h_poly = DevBuf(n * 32)
         self.points = DevBuf(96 * 4)     # Jacobian results of the commitments of one phase
-        self.affine = DevBuf(64 * 4)
         self.evals = DevBuf(32 * 32)
         self.shplonk = ProverSHPLONK(params)
 
     def release(self):
         for b in (self.advice + self.advice_polys + self.advice_cosets + self.z + self.z_polys + self.z_cosets +
-                  [self.z_last, self.random_poly, self.h, self.h_poly, self.points, self.affine, self.evals]):
+                  [self.random_poly, self.h, self.h_poly, self.points, self.evals]):
             b.free()
         self.shplonk.release()
 
 
+_Q = F.FQ_MODULUS
+_RINV_Q = pow(1 << 256, -1, _Q)
+
+
+def _write_phase_points(ws: ProverWorkspace, transcript, k: int):
+    """fetch the k Jacobian results of a phase (the copy joins the MSM pipeline), normalise them on the host as
+    G1::batch_normalize does (one modular inversion each is microseconds here; a lone device thread takes 0.3 ms)
+    and write them to the transcript"""
+    jac = ws.points.to_numpy(shape=(4, 12), nbytes=96 * 4)[:k]
+    for row in jac:
+        X, Y, Z = (sum(int(row[4 * c + i]) << (64 * i) for i in range(4)) * _RINV_Q % _Q for c in range(3))
+        if Z == 0:
+            raise ValueError("cannot write points at infinity to the transcript")
+        zi = pow(Z, -1, _Q)
+        zi2 = zi * zi % _Q
+        transcript.write_point_xy(X * zi2 % _Q, Y * zi2 % _Q * zi % _Q)
+
+
 def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, lagrange: bool):
-    """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join), normalise on
-    the device (G1::batch_normalize), fetch the affine points and write them to the transcript"""
-    k = len(columns)
+    """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join) and write the
+    points to the transcript"""
     for i, (buf, offset_elems) in enumerate(columns):
         h = params.g_lagrange_handle if lagrange else params.g_handle
         check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + offset_elems * 32, params.n, ws.points.ptr + 96 * i, None), "commit")
-    check(lib.h2mi_join(), "join")
-    check(lib.h2mi_g1_batch_normalize_dev(ws.points.ptr, k, ws.affine.ptr, None), "normalize")
-    pts = ws.affine.to_numpy(shape=(4, 8), nbytes=64 * 4)[:k]
-    for p in pts:
-        transcript.write_point(p)
-    return pts
+    _write_phase_points(ws, transcript, len(columns))
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcript: Blake2bWrite = None, ws: ProverWorkspace = None,
@@ -94,6 +104,10 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     bf = cs.BLINDING_FACTORS
     u = n - (bf + 1)  # unusable_rows_start; also the l_last row
     sq = lambda: F.fr_from_mont_limbs(transcript.squeeze_challenge())
+    import time as _time
+
+    marks = [("start", _time.perf_counter())]
+    mark = (lambda name: marks.append((name, _time.perf_counter()))) if trace is not None else (lambda name: None)
 
     transcript.common_scalar(_m(pk.vk.transcript_repr))  # vk.hash_into
 
@@ -115,14 +129,14 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     for col, p, e in zip(ws.advice, ws.advice_polys, ws.advice_cosets):
         d.lagrange_to_coeff_oop_dev(col, p)
         d.coeff_to_extended_oop_dev(p, e)
+    mark("advice committed")
     theta = sq()  # drawn even without lookups
     beta, gamma = sq(), sq()
 
     # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1) -----------------
     zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
+    gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z)
     for m, z in enumerate(ws.z):
-        gp.permutation_product(d.k, [ws.advice[cs.PERMUTATION_COLUMNS[m]]], [pk.permutation.values[m]], [m], beta, gamma, u, z,
-                               d_start=ws.z_last if m else None, d_last=ws.z_last)
         z.upload(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
     # ---- vanishing argument: random polynomial (n coefficients from the prover's rng) ------------------------------
     check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
@@ -132,11 +146,9 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     for z, p, e in zip(ws.z, ws.z_polys, ws.z_cosets):
         d.lagrange_to_coeff_oop_dev(z, p)
         d.coeff_to_extended_oop_dev(p, e)
-    k = len(ws.z) + 1
-    check(lib.h2mi_join(), "join")
-    check(lib.h2mi_g1_batch_normalize_dev(ws.points.ptr, k, ws.affine.ptr, None), "normalize")
-    for p in ws.affine.to_numpy(shape=(4, 8), nbytes=256)[:k]:
-        transcript.write_point(p)
+    mark("queued z/random commits")
+    _write_phase_points(ws, transcript, len(ws.z) + 1)
+    mark("z, random committed")
     y = sq()
 
     # ---- quotient: evaluate_h on the extended coset, divide by X^n - 1, back to coefficients, commit the pieces ----
@@ -144,6 +156,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     d.extended_to_coeff_dev(ws.h)
     pieces = d.quotient_poly_degree
     _commit_phase(params, ws, transcript, [(ws.h, i * n) for i in range(pieces)], lagrange=False)
+    mark("h pieces committed")
     x = sq()
     xn = pow(x, n, R)
 
@@ -167,14 +180,22 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
         if i + 1 < len(ws.z_polys):
             written.append((zp, x_last))
     extra = [(ws.h_poly, x)]  # opened but not written (the verifier recomputes it)
-    for i, (poly, pt) in enumerate(written + extra):
+    # one launch per distinct point (x: 17 polynomials, omega x: 3, omega^last x: 2)
+    todo = written + extra
+    slot = {}
+    for pt in dict.fromkeys(p for _, p in todo):
+        group = [poly for poly, p in todo if p == pt]
+        ptrs = (C.c_void_p * len(group))(*[g.ptr for g in group])
         pt_l = _m(pt)  # named: the array must outlive the call that reads its memory
-        check(lib.h2mi_fr_eval_poly_dev(poly.ptr, n, pt_l.ctypes.data, ws.evals.ptr + 32 * i, None), "eval")
+        check(lib.h2mi_fr_eval_polys_dev(ptrs, len(group), n, pt_l.ctypes.data, ws.evals.ptr + 32 * len(slot), None), "eval")
+        for g in group:
+            slot[(id(g), pt)] = len(slot)
     ev = ws.evals.to_numpy(shape=(32, 4))
-    for i in range(len(written)):
-        transcript.write_scalar(ev[i])
-    value = {(id(poly), pt): F.fr_from_mont_limbs(ev[i]) for i, (poly, pt) in enumerate(written + extra)}
+    value = {key: F.fr_from_mont_limbs(ev[i]) for key, i in slot.items()}
+    for poly, pt in written:
+        transcript.write_scalar_int(value[(id(poly), pt)])
 
+    mark("evaluations written")
     # ---- queries in create_proof's order, then SHPLONK ---------------------------------------------------------------
     queries = []
     q = lambda poly, pt: queries.append((poly, pt, value[(id(poly), pt)]))
@@ -196,8 +217,10 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
         _commit_phase(params, ws, transcript, [(poly, 0)], lagrange=False)
 
     ws.shplonk.create_proof(transcript, queries, commit_and_write)
+    mark("shplonk done")
     if trace is not None:
-        trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x, ws=ws)
+        trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x, ws=ws,
+                     phase_ms=[(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(marks, marks[1:])])
     proof = transcript.finalize()
     if own_ws and trace is None:
         ws.release()

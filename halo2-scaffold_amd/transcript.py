@@ -64,9 +64,23 @@ class Blake2bWrite(_Blake2bTranscript):
         xr, yr = self.common_point(affine)
         self.writer.write(xr[:31] + bytes([xr[31] | ((yr[0] & 1) << 6)]))
 
+    def write_point_xy(self, x: int, y: int) -> None:
+        """write_point for a point the caller already holds as canonical integers (G1::batch_normalize on the host)"""
+        xr, yr = x.to_bytes(32, "little"), y.to_bytes(32, "little")
+        self.state.update(PREFIX_POINT)
+        self.state.update(xr)
+        self.state.update(yr)
+        self.writer.write(xr[:31] + bytes([xr[31] | ((yr[0] & 1) << 6)]))
+
     def write_scalar(self, limbs) -> None:
         self.common_scalar(limbs)
         self.writer.write(serde.fr_to_repr(limbs))
+
+    def write_scalar_int(self, v: int) -> None:
+        b = v.to_bytes(32, "little")
+        self.state.update(PREFIX_SCALAR)
+        self.state.update(b)
+        self.writer.write(b)
 
     def finalize(self) -> bytes:
         return self.writer.getvalue()

@@ -140,6 +140,9 @@ int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const 
 /* ---- opening-argument helpers on device-resident coefficient vectors ------------------
  * halo2_proofs::arithmetic::eval_polynomial(poly, point): out = sum_i poly[i] * point^i  (32 B at d_out) */
 int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream);
+/* the same for `count` <= 24 polynomials of n coefficients at ONE point (create_proof evaluates every queried
+ * column at x): one launch; result k at d_out + 32 k */
+int h2mi_fr_eval_polys_dev(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream);
 /* halo2_proofs::arithmetic::kate_division(a, b): quotient of a(X) by (X - b), n - 1 coefficients at d_out
  * (the remainder a(b) is dropped, as in the crate).  The caller passes b^-1 (one CPU inversion). */
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out,
@@ -192,6 +195,15 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
                                        uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4],
                                        const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4],
                                        const void* d_start_or_null, void* d_z, void* d_last_or_null, h2mi_stream_t stream);
+
+/* every set of the permutation argument in one pass: m <= 8 columns in argument order, chunked by chunk_len
+ * (= cs.degree() - 2) into ceil(m / chunk_len) sets; d_z[s] receives rows 0 .. usable_rows of set s, each set
+ * starting at the previous set's last value (plonk/permutation/prover.rs chains them through `last_z`); blinding
+ * rows untouched.  One scan over the concatenated sets instead of one call (twelve launches) per set. */
+int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
+                                        uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4],
+                                        const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4], void* const* d_z,
+                                        h2mi_stream_t stream);
 
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the

@@ -198,3 +198,68 @@ def test_create_proof_full_size_verifies_and_quotient_identity(gpu, k):
     ws.release()
     pk.release()
     params.release()
+
+
+@pytest.mark.parametrize("k,m,chunk", [(6, 3, 1), (9, 4, 2), (11, 5, 2), (12, 8, 3)])
+def test_permutation_products_all_sets_match_formula(gpu, k, m, chunk):
+    """h2mi_plonk_permutation_products_dev: every set of a permutation argument in one pass (m columns chunked by
+    cs.degree() - 2, sets chained through their last value) against the row-by-row big-integer construction of
+    plonk/permutation/prover.rs; blinding rows stay as the caller left them.  (9, 4, 2) is the range-lookup shape."""
+    from halo2_scaffold_amd import plonk as gp
+
+    n = 1 << k
+    u = n - 6
+    w = o.omega_for(k)
+    wp = [pow(w, i, o.R) for i in range(n)]
+    rng = np.random.default_rng(k)
+    vals = [o.unpack(o.random_field_limbs(n, 300 + j), o.R) for j in range(m)]
+    # a real permutation: a few transpositions between cells of the columns on top of the identity
+    ident = lambda j, i: pow(P.FR_DELTA, j, o.R) * wp[i] % o.R
+    sig = [[ident(j, i) for i in range(n)] for j in range(m)]
+    for _ in range(20):
+        (j1, i1), (j2, i2) = [(int(rng.integers(m)), int(rng.integers(u))) for _ in range(2)]
+        sig[j1][i1], sig[j2][i2] = sig[j2][i2], sig[j1][i1]
+        vals[j2][i2] = vals[j1][i1]  # equal cells, so the product still telescopes where it should
+    beta, gamma = 0xBEEF + k, 0xCAFE
+    sets = -(-m // chunk)
+    want = []
+    start = 1
+    for s in range(sets):
+        z = [0xDEAD] * n
+        z[0] = start
+        for i in range(u):
+            num = den = 1
+            for j in range(s * chunk, min(m, (s + 1) * chunk)):
+                num = num * ((vals[j][i] + beta * ident(j, i) + gamma) % o.R) % o.R
+                den = den * ((vals[j][i] + beta * sig[j][i] + gamma) % o.R) % o.R
+            z[i + 1] = z[i] * num % o.R * pow(den, -1, o.R) % o.R
+        start = z[u]
+        want.append(z)
+    dv = [gpu.DevBuf.from_numpy(o.pack(v, o.R)) for v in vals]
+    ds = [gpu.DevBuf.from_numpy(o.pack(v, o.R)) for v in sig]
+    dz = [gpu.DevBuf.from_numpy(o.pack([0xDEAD] * n, o.R)) for _ in range(sets)]
+    gp.permutation_products(k, dv, ds, chunk, beta, gamma, u, dz)
+    for s in range(sets):
+        assert _vals(dz[s], n) == want[s], s
+    for b in dv + ds + dz:
+        b.free()
+
+
+def test_eval_polys_batched_matches_oracle(gpu):
+    import ctypes as C
+
+    from halo2_scaffold_amd import field as F
+
+    for n, count in [(1, 1), (300, 5), (1 << 13, 24), (70001, 3)]:
+        polys = [o.random_field_limbs(n, 900 + i) for i in range(count)]
+        bufs = [gpu.DevBuf.from_numpy(p) for p in polys]
+        out = gpu.DevBuf(32 * count)
+        pt = 0x123456789ABCDEF0FEDCBA987654321 % o.R
+        ptl = F.fr_to_mont_limbs(pt)
+        ptrs = (C.c_void_p * count)(*[b.ptr for b in bufs])
+        assert gpu.lib.h2mi_fr_eval_polys_dev(ptrs, count, n, ptl.ctypes.data, out.ptr, None) == 0
+        got = _vals(out, count)
+        assert got == [o.eval_polynomial(o.unpack(p, o.R), pt) for p in polys]
+        for b in bufs + [out]:
+            b.free()
+    assert gpu.lib.h2mi_fr_eval_polys_dev(None, 1, 4, None, None, None) == -1

@@ -149,3 +149,49 @@ def test_caller_streams_interleaved_with_library_stream(gpu):
     for b in d_scal + d_ntt + [d_out, d_ev]:
         b.free()
     params.release()
+
+
+@pytest.mark.parametrize("k", [12, 16])
+def test_msm_dominant_value_columns(gpu, k):
+    """columns that are one value repeated (what a permutation grand product looks like in a padded circuit: constant
+    wherever a row takes part in no copy constraint): the MSM subtracts the majority value and adds value * (sum of
+    the bases) instead — same group element as the C restatement's Pippenger, for every mix; a partial-length MSM
+    (n below the registered count, where the shift must stay off) too."""
+    import ctypes as C
+
+    from oracle import cref
+
+    h2 = gpu
+    n = 1 << k
+    params = h2.ParamsKZG.setup(k, 0xD0D0 + k)
+    bases = params.get_g_lagrange()
+    rnd = o.random_field_limbs(n, 600 + k)
+    c1 = o.pack([0x123456789ABCDEF0123456789ABCDEF % o.R], o.R)[0]
+    cols = {}
+    cols["constant"] = np.tile(c1, (n, 1))
+    pc = np.tile(c1, (n, 1))
+    pc[:3] = rnd[:3]
+    pc[n - 5 :] = rnd[n - 5 :]
+    cols["grand-product-like"] = pc
+    two = np.tile(c1, (n, 1))
+    two[n // 3 :] = o.pack([o.R - 1], o.R)[0]  # two long runs: the majority (2/3) value is shifted away
+    cols["two runs"] = two
+    mix = rnd.copy()
+    mix[::3] = c1  # a third of the rows: no majority, nothing is shifted
+    cols["minority"] = mix
+    cols["ones"] = np.tile(o.pack([1], o.R)[0], (n, 1))
+    cols["minus one"] = np.tile(o.pack([o.R - 1], o.R)[0], (n, 1))
+    for name, sc in cols.items():
+        sc = np.ascontiguousarray(sc)
+        got = params.commit_lagrange(sc)
+        assert o.unpack_jacobian(got) == o.unpack_jacobian(cref.msm(sc, bases, 4)), name
+    part = np.ascontiguousarray(cols["constant"][: n - 7])
+    out = np.zeros(12, dtype=np.uint64)
+    assert h2.lib.h2mi_msm_bn254_g1(params.g_lagrange_handle, None, part.ctypes.data, n - 7, out.ctypes.data) == 0
+    assert o.unpack_jacobian(out) == o.unpack_jacobian(cref.msm(part, bases[: n - 7], 4))
+    # the shift really is in effect: a constant column costs a handful of bucket insertions, not n * windows
+    ba, ra = C.c_uint64(), C.c_uint64()
+    params.commit_lagrange(np.ascontiguousarray(cols["grand-product-like"]))
+    assert h2.lib.h2mi_msm_last_stats(params.g_lagrange_handle, C.byref(ba), C.byref(ra)) == 0
+    assert ba.value < 64 * 20, ba.value
+    params.release()
