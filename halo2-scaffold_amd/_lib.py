@@ -35,6 +35,7 @@ def _load():
         "h2mi_malloc": ([sz, C.POINTER(vp)], C.c_int),
         "h2mi_free": ([vp], C.c_int),
         "h2mi_memcpy_h2d": ([vp, vp, sz], C.c_int),
+        "h2mi_memcpy_h2d_async": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_d2h": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_d2d": ([vp, vp, sz], C.c_int),
         "h2mi_memset_zero": ([vp, sz], C.c_int),

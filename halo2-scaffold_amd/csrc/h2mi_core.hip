@@ -217,6 +217,13 @@ int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
   H2_HIP(hipStreamSynchronize(ctx().stream));
   return H2MI_OK;
 }
+int h2mi_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes) {
+  H2_REQUIRE_INIT();
+  // stream-ordered on the library's stream; for pageable `src` the runtime stages the bytes before it returns,
+  // so the caller may reuse the buffer at once (small patches: blinding rows, assigned cells)
+  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  return H2MI_OK;
+}
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
   H2_REQUIRE_INIT();
   {

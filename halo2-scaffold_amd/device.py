@@ -25,6 +25,12 @@ class DevBuf:
         assert offset + arr.nbytes <= self.nbytes
         check(lib.h2mi_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes), "h2d")
 
+    def patch(self, arr: np.ndarray, offset: int = 0):
+        """stream-ordered small upload that does not wait for the device (h2mi_memcpy_h2d_async)"""
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes and arr.nbytes <= 4096
+        check(lib.h2mi_memcpy_h2d_async(self.ptr + offset, arr.ctypes.data, arr.nbytes), "h2d_async")
+
     def to_numpy(self, dtype=np.uint64, shape=None, nbytes=None, offset=0) -> np.ndarray:
         nbytes = self.nbytes - offset if nbytes is None else nbytes
         out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)

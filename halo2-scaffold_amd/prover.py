@@ -122,29 +122,27 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
             cells = np.zeros((hi - lo, 4), dtype=np.uint64)
             for r in rows:
                 cells[r - lo] = _m(syn.advice[j][r])
-            col.upload(cells, offset=lo * 32)
-        col.upload(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
+            col.patch(cells, offset=lo * 32)
+        col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
     _commit_phase(params, ws, transcript, [(c, 0) for c in ws.advice], lagrange=True)
-    # the coefficient / extended forms depend on the columns only: queue them now, they run while the host hashes
-    for col, p, e in zip(ws.advice, ws.advice_polys, ws.advice_cosets):
-        d.lagrange_to_coeff_oop_dev(col, p)
-        d.coeff_to_extended_oop_dev(p, e)
     mark("advice committed")
     theta = sq()  # drawn even without lookups
     beta, gamma = sq(), sq()
 
-    # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1) -----------------
+    # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1), one device pass ---
     zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
     gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z)
     for m, z in enumerate(ws.z):
-        z.upload(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
+        z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
     # ---- vanishing argument: random polynomial (n coefficients from the prover's rng) ------------------------------
     check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
     for i, z in enumerate(ws.z):
         check(lib.h2mi_msm_bn254_g1_dev(params.g_lagrange_handle, z.ptr, n, ws.points.ptr + 96 * i, None), "commit z")
     check(lib.h2mi_msm_bn254_g1_dev(params.g_handle, ws.random_poly.ptr, n, ws.points.ptr + 96 * len(ws.z), None), "commit random")
-    for z, p, e in zip(ws.z, ws.z_polys, ws.z_cosets):
-        d.lagrange_to_coeff_oop_dev(z, p)
+    # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
+    # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products
+    for col, p, e in list(zip(ws.advice, ws.advice_polys, ws.advice_cosets)) + list(zip(ws.z, ws.z_polys, ws.z_cosets)):
+        d.lagrange_to_coeff_oop_dev(col, p)
         d.coeff_to_extended_oop_dev(p, e)
     mark("queued z/random commits")
     _write_phase_points(ws, transcript, len(ws.z) + 1)

@@ -54,6 +54,9 @@ const char* h2mi_version(void);
 int h2mi_malloc(size_t bytes, void** d_ptr);
 int h2mi_free(void* d_ptr);
 int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+/* queued on the library's stream without waiting for it (pageable `src` is staged by the runtime before the call
+ * returns): for the small patches a prover writes into device-resident columns (assigned cells, blinding rows) */
+int h2mi_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes);
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int h2mi_memset_zero(void* d_ptr, size_t bytes); /* asynchronous on the library's stream */
