@@ -79,17 +79,24 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nb, uint3
   return (b & 7u) * (nb >> 3) + (b >> 3);
 }
 
-// LDS image: structure-of-arrays, limb plane l of element i at lds[l * stride + i] (conflict-free
-// 4-byte accesses for consecutive lanes).
+// LDS image: structure-of-arrays, limb plane l of element i at lds[l * stride + sw(i)].  The swizzle sw XORs
+// element-index bits 6..9 into the bank bits (0..5): a wavefront's accesses in a butterfly round s vary index bits
+// {0..s-1} and {s+2..7} (rounds 0, 2, 4 would otherwise hit 16 of the 64 banks: 4-way conflicts, measured 25 M
+// conflict cycles per 2^20 pass against 4 M of LDS issue), and the bit-reversed first write varies bits 4..9 (16-way).
+// With bits (6,7) replicated into (0,1), (2,3), (4,5) and bits (8,9) added to (0,1) every one of these patterns maps its
+// 64 lanes to 64 distinct banks.
+__device__ __forceinline__ uint32_t lds_sw(uint32_t i) { return i ^ (((i >> 6) & 3u) * 21u) ^ ((i >> 8) & 3u); }
 __device__ __forceinline__ f29 lds_get(const uint32_t* lds, uint32_t stride, uint32_t i) {
   f29 r;
+  const uint32_t j = lds_sw(i);
 #pragma unroll
-  for (int l = 0; l < 9; l++) r.v[l] = lds[l * stride + i];
+  for (int l = 0; l < 9; l++) r.v[l] = lds[l * stride + j];
   return r;
 }
 __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t stride, uint32_t i, const f29& a) {
+  const uint32_t j = lds_sw(i);
 #pragma unroll
-  for (int l = 0; l < 9; l++) lds[l * stride + i] = a.v[l];
+  for (int l = 0; l < 9; l++) lds[l * stride + j] = a.v[l];
 }
 __device__ __forceinline__ f29 load_unpack(const fe* p) {
   fe x = fe_load(p);
@@ -106,12 +113,39 @@ __device__ __forceinline__ void pack_store(fe* p, const f29& a_lt2p) {
 // butterflies of stage s and the two of stage s+1 in registers, and normalises only the four results
 // (limb bounds: a = x +- t < 1.5 * 2^30 may feed the next multiplication un-normalised, y < 2.5 * 2^30).
 // Half the barriers, LDS traffic and carry normalisations of a radix-2 schedule; same multiplications.
-__device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const fe* tw, uint32_t m, uint32_t logC) {
+// local twiddles w_loc^e, e < 2^(m-1), staged at position bitrev(e, m-1): stage s then reads the CONTIGUOUS block
+// [0, 2^s) — entry bitrev(pos, s) for butterfly position pos — instead of a stride of 2^(m-1-s) packed elements
+// (32 B each: 4-way bank conflicts at the late stages, where every lane needs its own twiddle)
+// The table is kept as eight 4-byte word planes (word l of entry e at tw[l * 2^(m-1) + e]): consecutive lanes read
+// consecutive words, where 32-byte packed entries made every 16-byte read a two-way conflict.
+__device__ __forceinline__ void stage_twiddles(uint32_t* tw, const fe* loc, uint32_t m) {
+  if (m == 0) return;
+  const uint32_t cnt = 1u << (m - 1);
+  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const fe x = fe_load(&loc[i]);
+    const uint32_t j = bitrev(i, m - 1);
+#pragma unroll
+    for (int l = 0; l < 8; l++) tw[l * cnt + j] = x.v[l];
+  }
+}
+__device__ __forceinline__ f29 tw_get(const uint32_t* tw, uint32_t cnt, uint32_t j) {
+  uint32_t w[8];
+#pragma unroll
+  for (int l = 0; l < 8; l++) w[l] = tw[l * cnt + j];
+  return f29_unpack(w);
+}
+__device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const uint32_t* tw, uint32_t m, uint32_t logC) {
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   if (m == 0) return;
+  const uint32_t tcnt = 1u << (m - 1);
   uint32_t s = 0;
   if (m >= 2) {
     const uint32_t nq = 1u << (m - 2 + logC);
+    // One quad per thread and 64 quads per wavefront: a wavefront's quads of round s stay inside its own aligned block
+    // of 256 elements while 2^(s+2) <= 256, so consecutive rounds up to s = 6 exchange data only between lanes of one
+    // wavefront.  LDS instructions of a wavefront execute in order, so those rounds need no workgroup barrier: three
+    // barriers per 2^10 tile instead of six.
+    const bool wave_local = nq == T && (T & 63u) == 0;
     for (; s + 1 < m; s += 2) {
       const uint32_t h = 1u << s;
       for (uint32_t q = tid; q < nq; q += T) {
@@ -123,26 +157,28 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
         f29 x0 = lds_get(lds, dstride, i), x1 = lds_get(lds, dstride, i + h);
         f29 x2 = lds_get(lds, dstride, i + 2 * h), x3 = lds_get(lds, dstride, i + 3 * h);
         f29 t1 = x1, t3 = x3;
+        const uint32_t pb = bitrev(pos, s);  // the twiddle table is staged in bit-reversed order (see stage_twiddles)
         if (s != 0) {
-          f29 wa = f29_unpack(tw[pos << (m - 1 - s)].v);
+          f29 wa = tw_get(tw, tcnt, pb);
           t1 = f29_mul<F9>(x1, wa);
           t3 = f29_mul<F9>(x3, wa);
         }
         f29 a0 = f29_add(x0, t1), a1 = f29_sub(x0, t1, F9::K2);
         f29 a2 = f29_add(x2, t3), a3 = f29_sub(x2, t3, F9::K2);
-        f29 u3 = f29_mul<F9>(a3, f29_unpack(tw[(pos + h) << (m - 2 - s)].v));
+        f29 u3 = f29_mul<F9>(a3, tw_get(tw, tcnt, 2 * pb + 1));
         if (s == 0) {  // pos = 0: the twiddle of (a0, a2) is omega^0 — no multiplication; a2 = x2 + x3 < 4p, limbs < 2^30
           lds_put(lds, dstride, i, f29_normalize(f29_add(a0, a2)));
           lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, a2, F9::KW4)));
         } else {
-          f29 u2 = f29_mul<F9>(a2, f29_unpack(tw[pos << (m - 2 - s)].v));
+          f29 u2 = f29_mul<F9>(a2, tw_get(tw, tcnt, 2 * pb));
           lds_put(lds, dstride, i, f29_normalize(f29_add(a0, u2)));
           lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, u2, F9::K2)));
         }
         lds_put(lds, dstride, i + h, f29_normalize(f29_add(a1, u3)));
         lds_put(lds, dstride, i + 3 * h, f29_normalize(f29_sub(a1, u3, F9::K2)));
       }
-      __syncthreads();
+      if (wave_local && s + 3 < m && s + 4 <= 8) __builtin_amdgcn_wave_barrier();  // next round is a wave-local radix-4 round
+      else __syncthreads();
     }
   }
   if (s < m) {  // odd m: one closing radix-2 stage (s = m - 1; for m = 1 it is the multiplication-free stage 0)
@@ -155,7 +191,7 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
       uint32_t i = (c << m) | (grp << (s + 1)) | pos;
       f29 u = lds_get(lds, dstride, i), v = lds_get(lds, dstride, i + half);
       f29 t = v;
-      if (s != 0) t = f29_mul<F9>(v, f29_unpack(tw[pos << (m - 1 - s)].v));
+      if (s != 0) t = f29_mul<F9>(v, tw_get(tw, tcnt, bitrev(pos, s)));
       lds_put(lds, dstride, i, f29_normalize(f29_add(u, t)));
       lds_put(lds, dstride, i + half, f29_normalize(f29_sub(u, t, F9::K2)));
     }
@@ -175,9 +211,9 @@ extern __shared__ uint32_t h2_smem[];
 // non-final pass: column DFTs inside segments, in-place layout
 __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  const uint32_t dstride = C << m, tstride = 1u << (m - 1);
+  const uint32_t dstride = C << m;
   uint32_t* lds = h2_smem;
-  fe* tw = reinterpret_cast<fe*>(lds + 9 * dstride);  // packed (32 B) twiddles: keeps a 2^10 tile at 52 KiB = 3 blocks/CU
+  uint32_t* tw = lds + 9 * dstride;  // 8 word planes of packed twiddles: keeps a 2^10 tile at 52 KiB = 3 blocks/CU
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t logS = p.log_seg - m;
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
@@ -193,7 +229,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
     if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
-  for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
+  stage_twiddles(tw, p.loc, m);
   __syncthreads();
   local_ntt(lds, dstride, tw, m, logC);
   const uint32_t sh = p.log_n - p.log_seg;
@@ -209,9 +245,9 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
 // final pass: row DFTs, digit-reversed scatter
 __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  const uint32_t dstride = C << m, tstride = m ? (1u << (m - 1)) : 1u;
+  const uint32_t dstride = C << m;
   uint32_t* lds = h2_smem;
-  fe* tw = reinterpret_cast<fe*>(lds + 9 * dstride);
+  uint32_t* tw = lds + 9 * dstride;
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
   const uint32_t k2 = tile & ((1u << p.logN2) - 1);
@@ -225,7 +261,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
     if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
-  if (m) for (uint32_t i = tid; i < tstride; i += T) tw[i] = fe_load(&p.loc[i]);
+  stage_twiddles(tw, p.loc, m);
   __syncthreads();
   local_ntt(lds, dstride, tw, m, logC);
   // the caller's post-scale (Mont256 -> Mont261 first) also brings the lazily accumulated value back below 2p
@@ -783,7 +819,7 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
 }
 
 static void choose_split(uint32_t log_n, Plan* pl) {
-  const uint32_t MAXM = 10;
+  static const uint32_t MAXM = getenv("H2MI_NTT_MAXM") ? (uint32_t)atoi(getenv("H2MI_NTT_MAXM")) : 10;  // tuning knob (7 .. 10)
   if (log_n <= MAXM) {
     pl->P = 1;
     pl->m[0] = log_n;
