@@ -47,6 +47,7 @@ def _load():
         "h2mi_bases_info": ([C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p], C.c_int),
         "h2mi_msm_bn254_g1": ([C.c_uint64, vp, vp, sz, vp], C.c_int),
         "h2mi_msm_bn254_g1_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
+        "h2mi_msm_adhoc_builds": ([u64p], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),
         "h2mi_msm_set_canonical": ([C.c_int], C.c_int),
         "h2mi_fe_to_repr_dev": ([C.c_int, vp, sz, vp, vp], C.c_int),

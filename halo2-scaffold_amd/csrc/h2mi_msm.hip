@@ -21,7 +21,9 @@
 //    the bucket matrix (LDS tree reductions), bit-decomposed weights, then <= 15 doublings.
 // All arithmetic is 254-bit integer work on v_mad_u64_u32; no MFMA (not a dense contraction).
 
+#include <algorithm>
 #include <map>
+#include <vector>
 
 #include "g1.cuh"
 #include "g1_29.cuh"
@@ -99,6 +101,16 @@ struct Bases {
 };
 
 static std::map<uint64_t, Bases*> g_bases;
+// cache of ad-hoc registrations (h2mi_msm_bn254_g1 with handle = 0): see adhoc_handle
+struct AdHoc {
+  size_t n;
+  uint64_t fp[2];
+  uint64_t handle;
+  uint64_t last_use;
+};
+static std::vector<AdHoc> g_adhoc;
+static uint64_t g_adhoc_clock = 0, g_adhoc_builds = 0;
+constexpr size_t ADHOC_MAX = 4;  // g, g_lagrange and a couple of slices
 static bool g_canonical = false;
 static uint64_t g_next_handle = 1;
 
@@ -1290,6 +1302,11 @@ int h2mi_bases_release(uint64_t handle) {
   hipDeviceSynchronize();
   free_bases(it->second);
   g_bases.erase(it);
+  for (size_t i = 0; i < g_adhoc.size(); i++)
+    if (g_adhoc[i].handle == handle) {
+      g_adhoc.erase(g_adhoc.begin() + i);
+      break;
+    }
   return H2MI_OK;
 }
 
@@ -1301,6 +1318,70 @@ int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* b
   if (windows) *windows = it->second->W;
   if (buckets) *buckets = it->second->nb;
   if (n) *n = it->second->n;
+  return H2MI_OK;
+}
+
+// ---- ad-hoc bases (handle = 0): best_multiexp(coeffs, bases) called with a plain slice --------------------------
+// Registering builds the W-window table (c doublings and an inversion per point per window: ~45 ms at 2^20, 25 x
+// the MSM itself), so an unregistered call must not pay it every time: the bases are uploaded (the price of the
+// host-pointer form, 64 B x n over PCIe), fingerprinted ON THE DEVICE over every byte (two independent 64-bit
+// multiply-xor sums) and looked up in a small cache of ad-hoc registrations keyed by (n, fingerprint).  A prover that
+// keeps calling with the same SRS slice rebuilds nothing; changed bases change the fingerprint and are re-registered.
+__global__ void __launch_bounds__(256) k_bases_fingerprint(const uint64_t* words, size_t count, uint64_t* out /* [2], zeroed */) {
+  uint64_t a = 0, b = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t w = words[i];
+    uint64_t x = (w ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 29;
+    a += x * 0x94D049BB133111EBull;
+    uint64_t y = (w + (i + 1) * 0xD6E8FEB86659FD93ull) * 0xFF51AFD7ED558CCDull;
+    y ^= y >> 32;
+    b ^= y * 0xC4CEB9FE1A85EC53ull + (y >> 17);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off);
+    b ^= __shfl_down(b, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);
+    atomicXor((unsigned long long*)&out[1], (unsigned long long)b);
+  }
+}
+
+static int adhoc_handle(const uint64_t* bases, size_t n, uint64_t* handle_out) {
+  hipStream_t s = ctx().stream;
+  DevMem d, fp;
+  hipError_t e = d.alloc(n * 64);
+  if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+  H2_HIP(e);
+  H2_HIP(fp.alloc(16));
+  H2_HIP(hipMemcpyAsync(d.p, bases, n * 64, hipMemcpyHostToDevice, s));
+  H2_HIP(hipMemsetAsync(fp.p, 0, 16, s));
+  const uint32_t grid = (uint32_t)std::min<size_t>(1024, (n * 8 + 255) / 256);
+  H2_LAUNCH("k_bases_fingerprint", k_bases_fingerprint, grid, 256, 0, s, d.as<uint64_t>(), n * 8, fp.as<uint64_t>());
+  uint64_t h[2] = {0, 0};
+  H2_HIP(hipMemcpyAsync(h, fp.p, 16, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  g_adhoc_clock++;
+  for (AdHoc& a : g_adhoc)
+    if (a.n == n && a.fp[0] == h[0] && a.fp[1] == h[1] && g_bases.count(a.handle)) {
+      a.last_use = g_adhoc_clock;
+      *handle_out = a.handle;
+      return H2MI_OK;
+    }
+  if (g_adhoc.size() >= ADHOC_MAX) {  // drop the least recently used ad-hoc registration
+    size_t victim = 0;
+    for (size_t i = 1; i < g_adhoc.size(); i++)
+      if (g_adhoc[i].last_use < g_adhoc[victim].last_use) victim = i;
+    h2mi_bases_release(g_adhoc[victim].handle);
+    g_adhoc.erase(g_adhoc.begin() + victim);
+  }
+  uint64_t nh = 0;
+  int rc = register_dev(d.p, n, &nh, s);
+  if (rc) return rc;
+  g_adhoc_builds++;
+  g_adhoc.push_back({n, {h[0], h[1]}, nh, g_adhoc_clock});
+  *handle_out = nh;
   return H2MI_OK;
 }
 
@@ -1334,7 +1415,7 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   uint64_t h = handle;
   int rc = H2MI_OK;
   if (handle == 0) {
-    rc = h2mi_bases_register(bases, n, &h);
+    rc = adhoc_handle(bases, n, &h);
     if (rc) return rc;
   }
   auto it = g_bases.find(h);
@@ -1354,8 +1435,14 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   if (!rc) rc = msm_join_all(s);
   if (!rc && hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
   if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = H2MI_EHIP;
-  if (handle == 0) h2mi_bases_release(h);
-  return rc;
+  return rc;  // an ad-hoc registration (handle == 0) stays cached: see adhoc_handle
+}
+
+int h2mi_msm_adhoc_builds(uint64_t* builds_out) {
+  if (!builds_out) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  *builds_out = g_adhoc_builds;
+  return H2MI_OK;
 }
 
 int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {

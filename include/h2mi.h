@@ -95,6 +95,11 @@ int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* b
  * The reference asserts coeffs.len() == bases.len(); here n > registered n returns H2MI_ERANGE. */
 int h2mi_msm_bn254_g1(uint64_t handle_or_0, const uint64_t* bases_or_null /* used when handle==0 */,
                       const uint64_t* scalars /* n*4 limbs */, size_t n, uint64_t out_jacobian[12]);
+/* handle == 0 (best_multiexp on a plain slice of bases) does NOT rebuild the window tables on every call: the bases
+ * are uploaded, fingerprinted on the device over every byte and looked up in a cache of the four most recent ad-hoc
+ * registrations, so repeated calls with the same slice pay the 64 B x n upload only.  Register explicitly
+ * (h2mi_bases_register) to avoid that too.  h2mi_msm_adhoc_builds: how many ad-hoc registrations have been built. */
+int h2mi_msm_adhoc_builds(uint64_t* builds_out);
 /* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
                           h2mi_stream_t stream);

@@ -883,3 +883,32 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     rccl = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
     assert rccl["commitments_sha256"] == one["commitments_sha256"] and rccl["n_gpus"] == 1
     assert rccl["config"]["combines_per_step"] == 5 and "device-resident" in rccl["config"]["combine"]
+
+
+def test_eip196_vectors_hip_path(gpu):
+    """third-party anchors (tests/golden/eip196_vectors.json: EIP-196 ECADD / ECMUL vectors, not derived from the oracle)
+    through the HIP path: the XYZZ mixed / full additions and the lane-cooperative addition of the bucket reduction for
+    ECADD, the MSM pipeline (ad-hoc bases, n = 1 and n = 2) for ECMUL and ECADD."""
+    import json
+
+    v196 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eip196_vectors.json")))
+    pt = lambda xy: None if int(xy[0], 16) == 0 and int(xy[1], 16) == 0 else (int(xy[0], 16), int(xy[1], 16))
+    adds = v196["ecadd"]
+    A, B = o.pack_points([pt(v["a"]) for v in adds]), o.pack_points([pt(v["b"]) for v in adds])
+    want = [pt(v["sum"]) for v in adds]
+    out = np.zeros((len(adds), 12), dtype=np.uint64)
+    for op in (0, 2):
+        assert gpu.lib.h2mi_dbg_g1_op(op, A.ctypes.data, B.ctypes.data, out.ctypes.data, len(adds)) == 0
+        assert [o.unpack_jacobian(r) for r in out] == want, op
+    assert gpu.lib.h2mi_dbg_g1_quad_op(0, A.ctypes.data, B.ctypes.data, out.ctypes.data, len(adds)) == 0
+    assert [o.unpack_jacobian(r) for r in out] == want
+    ones = o.pack([1, 1], o.R)
+    for i, v in enumerate(adds):
+        if pt(v["a"]) is None:
+            continue
+        got = gpu.best_multiexp(ones, np.ascontiguousarray(np.stack([A[i], B[i]])))
+        assert o.unpack_jacobian(got) == want[i], v["name"]
+    for v in v196["ecmul"]:
+        k = int(v["k"], 16) % o.R
+        got = gpu.best_multiexp(o.pack([k], o.R), o.pack_points([pt(v["p"])]))
+        assert o.unpack_jacobian(got) == pt(v["product"]), v["name"]

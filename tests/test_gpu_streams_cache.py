@@ -195,3 +195,39 @@ def test_msm_dominant_value_columns(gpu, k):
     assert h2.lib.h2mi_msm_last_stats(params.g_lagrange_handle, C.byref(ba), C.byref(ra)) == 0
     assert ba.value < 64 * 20, ba.value
     params.release()
+
+
+def test_adhoc_bases_are_cached_not_rebuilt(gpu):
+    """best_multiexp(coeffs, bases) with a plain slice of bases (handle = 0): the first call registers them, the
+    following calls with the same bytes find the registration by its device-side fingerprint and build nothing;
+    changing one limb of one point is a different set (re-registered, right result); results against the C oracle."""
+    import ctypes as C
+
+    from oracle import cref
+
+    h2 = gpu
+    n = 5000
+    bases = cref.g1_mul_gen(o.random_field_limbs(n, 71), 2)
+    sc = [o.random_field_limbs(n, 72 + i) for i in range(3)]
+    builds = C.c_uint64()
+
+    def nbuilds():
+        assert h2.lib.h2mi_msm_adhoc_builds(C.byref(builds)) == 0
+        return builds.value
+
+    b0 = nbuilds()
+    for s in sc:
+        assert o.unpack_jacobian(h2.best_multiexp(s, bases)) == o.unpack_jacobian(cref.msm(s, bases, 2))
+    assert nbuilds() == b0 + 1  # three commits against the same slice: one registration
+    other = bases.copy()
+    other[n // 2] = bases[0]  # still valid curve points, different bytes
+    assert o.unpack_jacobian(h2.best_multiexp(sc[0], other)) == o.unpack_jacobian(cref.msm(sc[0], other, 2))
+    assert nbuilds() == b0 + 2
+    assert o.unpack_jacobian(h2.best_multiexp(sc[1], bases)) == o.unpack_jacobian(cref.msm(sc[1], bases, 2))
+    assert nbuilds() == b0 + 2  # the first set is still cached
+    # more distinct sets than the cache holds: the least recently used registration is dropped, nothing leaks or breaks
+    for j in range(5):
+        bj = np.ascontiguousarray(bases[j + 1 : j + 1 + 1000])
+        sj = np.ascontiguousarray(sc[0][:1000])
+        assert o.unpack_jacobian(h2.best_multiexp(sj, bj)) == o.unpack_jacobian(cref.msm(sj, bj, 1))
+    assert nbuilds() == b0 + 7

@@ -206,3 +206,42 @@ def test_plonk_quotient_oracle_identity():
     zb = bad.permutation_products(beta, gamma)
     hb = bad.dom.extended_to_coeff(bad.divide_by_vanishing(bad.evaluate_h(zb, beta, gamma, y)))
     assert not P.check_quotient_identity(bad, zb, hb, beta, gamma, y, 5)
+
+
+# ---- third-party anchors (not derived from the oracle): EIP-196 ECADD / ECMUL vectors ---------------------------------
+EIP196 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eip196_vectors.json")))
+
+
+def _eip_pt(xy):
+    x, y = int(xy[0], 16), int(xy[1], 16)
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def test_eip196_vectors_python_oracle():
+    """the alt_bn128 precompile vectors (independent of this repository) against oracle/bn254.py: affine
+    chord-and-tangent addition, Jacobian addition, double-and-add multiplication"""
+    for v in EIP196["ecadd"]:
+        a, b, want = _eip_pt(v["a"]), _eip_pt(v["b"]), _eip_pt(v["sum"])
+        assert o.is_on_curve(a) and o.is_on_curve(b) and o.is_on_curve(want), v["name"]
+        assert o.g1_add(a, b) == want, v["name"]
+        assert o.jac_to_affine(o.jac_add(o.jac_from_affine(a), o.jac_from_affine(b))) == want, v["name"]
+    for v in EIP196["ecmul"]:
+        p, k, want = _eip_pt(v["p"]), int(v["k"], 16), _eip_pt(v["product"])
+        assert o.g1_mul(k % o.R, p) == want, v["name"]
+        assert o.jac_to_affine(o.jac_mul(k % o.R, o.jac_from_affine(p))) == want, v["name"]
+    assert o.FR_ROOT_OF_UNITY == int(EIP196["fr_root_of_unity"], 16) and o.FR_S == EIP196["fr_two_adicity"]
+    assert pow(o.FR_ROOT_OF_UNITY, 1 << 28, o.R) == 1 and pow(o.FR_ROOT_OF_UNITY, 1 << 27, o.R) == o.R - 1
+
+
+def test_eip196_vectors_c_restatement():
+    """the same vectors through oracle/h2ref.c: the serial Pippenger (n = 2 with scalars 1, 1 is an addition; n = 1 a
+    scalar multiplication) and its 64-bit-limb Montgomery arithmetic"""
+    from oracle import cref
+
+    for v in EIP196["ecadd"]:
+        a, b, want = _eip_pt(v["a"]), _eip_pt(v["b"]), _eip_pt(v["sum"])
+        got = cref.msm(o.pack([1, 1], o.R), o.pack_points([a, b]), 1)
+        assert o.unpack_jacobian(got) == want, v["name"]
+    for v in EIP196["ecmul"]:
+        p, k, want = _eip_pt(v["p"]), int(v["k"], 16), _eip_pt(v["product"])
+        assert o.unpack_jacobian(cref.msm(o.pack([k % o.R], o.R), o.pack_points([p]), 1)) == want, v["name"]
