@@ -29,6 +29,8 @@ def _load():
     sz = C.c_size_t
     sig = {
         "h2mi_init": ([C.c_int], C.c_int),
+        "h2mi_init_devices": ([C.c_int], C.c_int),
+        "h2mi_device_count": ([], C.c_int),
         "h2mi_shutdown": ([], None),
         "h2mi_strerror": ([C.c_int], C.c_char_p),
         "h2mi_version": ([], C.c_char_p),

@@ -9,6 +9,20 @@ Ctx& ctx() {
   return c;
 }
 
+int use_device(int idx) {
+  Ctx& c = ctx();
+  if (idx < 0 || idx >= (int)c.devs.size()) return H2MI_EINVAL;
+  const DevCtx& d = c.devs[idx];
+  if (c.cur != idx || c.device != d.device) H2_HIP(hipSetDevice(d.device));
+  c.cur = idx;
+  c.device = d.device;
+  c.stream = d.stream;
+  c.head_stream = d.head_stream;
+  c.accum_stream = d.accum_stream;
+  c.tail_stream = d.tail_stream;
+  return H2MI_OK;
+}
+
 void note_hip_error(hipError_t e, const char* file, int line) {
   snprintf(ctx().last_err, sizeof(ctx().last_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
   if (getenv("H2MI_VERBOSE")) fprintf(stderr, "[h2mi] %s\n", ctx().last_err);
@@ -141,6 +155,11 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const fe* scalars, size_
   affine_store(out + i * 64, xyzz_to_affine(acc));
 }
 
+int launch_fold_groups(const uint8_t* pts, size_t world, size_t k, uint8_t* out, hipStream_t s) {
+  H2_LAUNCH("k_g1_fold_groups", k_g1_fold_groups, ceil_div_u32(k, 64), 64, 0, s, pts, world, k, out);
+  return H2MI_OK;
+}
+
 static uint8_t* g_fixed_table = nullptr;
 static Built g_fixed_built;
 
@@ -150,36 +169,85 @@ using namespace h2;
 
 extern "C" {
 
+static int create_dev(int device, DevCtx* d) {
+  H2_HIP(hipSetDevice(device));
+  d->device = device;
+  H2_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&d->tail_stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&d->head_stream, hipStreamNonBlocking));
+  H2_HIP(hipStreamCreateWithFlags(&d->accum_stream, hipStreamNonBlocking));
+  return H2MI_OK;
+}
+
 int h2mi_init(int device) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  if (ctx().inited) return ctx().device == device ? H2MI_OK : H2MI_EINVAL;
+  if (ctx().inited) return (ctx().devs.size() == 1 && ctx().devs[0].device == device) ? H2MI_OK : H2MI_EINVAL;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return H2MI_ENODEV;
   if (device < 0 || device >= count) return H2MI_EINVAL;
-  H2_HIP(hipSetDevice(device));
-  H2_HIP(hipStreamCreateWithFlags(&ctx().stream, hipStreamNonBlocking));
-  H2_HIP(hipStreamCreateWithFlags(&ctx().tail_stream, hipStreamNonBlocking));
-  H2_HIP(hipStreamCreateWithFlags(&ctx().head_stream, hipStreamNonBlocking));
-  H2_HIP(hipStreamCreateWithFlags(&ctx().accum_stream, hipStreamNonBlocking));
-  ctx().device = device;
+  DevCtx d;
+  int rc = create_dev(device, &d);
+  if (rc) return rc;
+  ctx().devs.assign(1, d);
+  ctx().cur = -1;
   ctx().inited = true;
-  return H2MI_OK;
+  return use_device(0);
+}
+
+int h2mi_init_devices(int n_devices) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (n_devices < 1 || n_devices > 16) return H2MI_EINVAL;
+  if (ctx().inited) return (int)ctx().devs.size() == n_devices ? H2MI_OK : H2MI_EINVAL;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return H2MI_ENODEV;
+  const bool virt = getenv("H2MI_VIRTUAL_DEVICES") != nullptr;  // rehearsal: entry i runs on GPU i % count
+  if (n_devices > count && !virt) return H2MI_ENODEV;
+  std::vector<DevCtx> devs((size_t)n_devices);
+  for (int i = 0; i < n_devices; i++) {
+    int rc = create_dev(i % count, &devs[(size_t)i]);
+    if (rc) return rc;
+  }
+  // peer access between the primary device and the others (slices of device-resident scalars and the 96-byte
+  // partial results travel over xGMI); ignore "already enabled"
+  for (int i = 1; i < n_devices; i++) {
+    if (devs[(size_t)i].device == devs[0].device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devs[0].device, devs[(size_t)i].device) == hipSuccess && can) {
+      hipSetDevice(devs[0].device);
+      hipDeviceEnablePeerAccess(devs[(size_t)i].device, 0);
+      hipSetDevice(devs[(size_t)i].device);
+      hipDeviceEnablePeerAccess(devs[0].device, 0);
+    }
+  }
+  (void)hipGetLastError();
+  ctx().devs = devs;
+  ctx().cur = -1;
+  ctx().inited = true;
+  return use_device(0);
+}
+
+int h2mi_device_count(void) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return ctx().inited ? (int)ctx().devs.size() : 0;
 }
 
 void h2mi_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   if (!ctx().inited) return;
+  use_device(0);
   msm_join_all(ctx().stream);
   hipStreamSynchronize(ctx().stream);
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; g_fixed_built.destroy(); }
-  hipDeviceSynchronize();
-  hipStreamDestroy(ctx().head_stream);
-  hipStreamDestroy(ctx().accum_stream);
-  hipStreamDestroy(ctx().tail_stream);
-  ctx().head_stream = ctx().accum_stream = nullptr;
-  hipStreamDestroy(ctx().stream);
-  ctx().stream = nullptr;
-  ctx().tail_stream = nullptr;
+  for (DevCtx& d : ctx().devs) {
+    hipSetDevice(d.device);
+    hipDeviceSynchronize();
+    hipStreamDestroy(d.head_stream);
+    hipStreamDestroy(d.accum_stream);
+    hipStreamDestroy(d.tail_stream);
+    hipStreamDestroy(d.stream);
+  }
+  ctx().devs.clear();
+  ctx().head_stream = ctx().accum_stream = ctx().tail_stream = ctx().stream = nullptr;
   ctx().inited = false;
 }
 

@@ -18,9 +18,19 @@ struct ProfRec {
   hipEvent_t a, b;
 };
 
+// One entry per device the process drives (h2mi_init: one; h2mi_init_devices(n): n).  Entry 0 is the primary
+// device: transforms, polynomial helpers and the final fold of a sharded MSM run there.  With fewer physical GPUs
+// than requested (H2MI_VIRTUAL_DEVICES=1) several entries share one GPU — a rehearsal mode for one-GPU boxes.
+struct DevCtx {
+  int device = -1;
+  hipStream_t stream = nullptr, head_stream = nullptr, accum_stream = nullptr, tail_stream = nullptr;
+};
+
 struct Ctx {
   bool inited = false;
   int device = -1;
+  std::vector<DevCtx> devs;
+  int cur = 0;  // index into devs of the entry whose streams are mirrored in the members below
   hipStream_t stream = nullptr;
   // MSM pipeline on the library's own stream: sort (memory-bound) | accumulation (VALU-bound) | bucket
   // reduction (latency-bound) of consecutive MSMs run on three internal streams and overlap.
@@ -33,6 +43,8 @@ struct Ctx {
 };
 
 Ctx& ctx();
+// make entry `idx` current: hipSetDevice + the stream members of Ctx mirror its streams (callers hold the mutex)
+int use_device(int idx);
 
 inline hipStream_t pick_stream(h2mi_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
 
@@ -97,6 +109,9 @@ struct Built {
     ev = nullptr;
   }
 };
+
+// h2mi_core.hip: out[j] = sum over r < world of pts[r*k + j] (Jacobian, Montgomery-2^256), one launch on `s`
+int launch_fold_groups(const uint8_t* pts, size_t world, size_t k, uint8_t* out, hipStream_t s);
 
 // h2mi_msm.hip: make `s` wait for all outstanding MSM tails
 int msm_join_all(hipStream_t s);

@@ -88,6 +88,7 @@ struct Slot {
 constexpr int NSLOT = 4;
 
 struct Bases {
+  int dev = 0;                  // index into ctx().devs of the device that owns every allocation below
   size_t n = 0;
   size_t stride = 0;            // table row length: n + 1 (slot n = the sum of all n bases, see k_msm_pick_shift)
   bool has_sum = false;
@@ -934,6 +935,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
   Bases* B = new Bases();
   B->n = n;
+  B->dev = ctx().cur;
   B->stride = n + 1;
   B->c = pick_window(n);
   B->W = (255 + B->c - 1) / B->c;
@@ -1034,6 +1036,33 @@ struct Deferred {
   Bases* B;
   Slot* S;
 };
+// ---- one prover process, several devices (h2mi_init_devices) ---------------------------------------------------
+// A sharded handle owns one ordinary registration per device, each over a contiguous slice of the bases — the
+// partition best_multiexp applies per CPU thread and the torchrun path applies per rank.  An MSM
+// on it launches every slice from the calling thread (scalars: host -> each device, or peer copies from the primary
+// device), and the 96-byte partial results are gathered to the primary device and folded there at the next join.
+struct Shard {
+  uint64_t handle = 0;       // ordinary handle in g_bases
+  size_t lo = 0, hi = 0;     // slice [lo, hi) of the registered bases
+  uint8_t* stage = nullptr;  // on the shard's device: scalars of its slice (lazy)
+  uint8_t* part = nullptr;   // on the shard's device: ring of Jacobian partial results, 96 B each
+  hipEvent_t ready = nullptr;
+};
+constexpr uint32_t SHARD_RING = 16;  // sharded MSMs that may be queued between two joins
+struct Sharded {
+  size_t n = 0;
+  std::vector<Shard> shard;
+  uint8_t* gather = nullptr;  // on the primary device: [ring][shard] partial results
+  uint32_t next = 0;
+};
+struct PendingFold {
+  Sharded* sh;
+  uint32_t ring;
+  void* d_out;  // on the primary device
+};
+static std::map<uint64_t, Sharded*> g_sharded;
+static std::vector<PendingFold> g_pending_folds;
+static int fold_sharded(hipStream_t s0);
 static std::vector<Deferred> g_deferred;
 static int flush_tails();
 static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
@@ -1220,34 +1249,194 @@ static TailDesc tail_desc(const Bases* B, const Slot& S) {
 
 // launch the deferred bucket reductions (all handles) as batches on the tail stream
 static int flush_tails() {
-  hipStream_t t = ctx().tail_stream;
-  size_t i = 0;
-  while (i < g_deferred.size()) {
-    TailBatch tb;
-    uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0;
-    const size_t first = i;
-    for (; i < g_deferred.size() && count < TAIL_BATCH; i++, count++) {
-      Bases* B = g_deferred[i].B;
-      Slot& S = *g_deferred[i].S;
-      H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
-      tb.d[count] = tail_desc(B, S);
-      max_tasks1 = std::max(max_tasks1, S.tasks1);
-      max_nb = std::max(max_nb, B->nb);
-      max_logNh = std::max(max_logNh, B->logNh);
-      max_logNl = std::max(max_logNl, B->logNl);
-    }
-    for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
-    int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, t);
-    if (rc) return rc;
-    for (size_t j = first; j < i; j++) {
-      Slot& S = *g_deferred[j].S;
-      H2_HIP(hipEventRecord(S.tail_done, t));
-      S.tail_pending = true;
-      S.tail_ever = true;
-      S.tail_deferred = false;
+  if (g_deferred.empty()) return H2MI_OK;
+  const int prev = ctx().cur;
+  // the reductions of a device run on that device's tail stream, batched per device
+  for (int dev = 0; dev < (int)ctx().devs.size(); dev++) {
+    std::vector<Deferred> mine;
+    for (const Deferred& d : g_deferred)
+      if (d.B->dev == dev) mine.push_back(d);
+    if (mine.empty()) continue;
+    int rc0 = use_device(dev);
+    if (rc0) return rc0;
+    hipStream_t t = ctx().tail_stream;
+    size_t i = 0;
+    while (i < mine.size()) {
+      TailBatch tb;
+      uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0;
+      const size_t first = i;
+      for (; i < mine.size() && count < TAIL_BATCH; i++, count++) {
+        Bases* B = mine[i].B;
+        Slot& S = *mine[i].S;
+        H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
+        tb.d[count] = tail_desc(B, S);
+        max_tasks1 = std::max(max_tasks1, S.tasks1);
+        max_nb = std::max(max_nb, B->nb);
+        max_logNh = std::max(max_logNh, B->logNh);
+        max_logNl = std::max(max_logNl, B->logNl);
+      }
+      for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
+      int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, t);
+      if (rc) return rc;
+      for (size_t j = first; j < i; j++) {
+        Slot& S = *mine[j].S;
+        H2_HIP(hipEventRecord(S.tail_done, t));
+        S.tail_pending = true;
+        S.tail_ever = true;
+        S.tail_deferred = false;
+      }
     }
   }
   g_deferred.clear();
+  return use_device(prev);
+}
+
+static const uint64_t G1_IDENTITY_J[12] = {0, 0, 0, 0, 0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL, 0, 0, 0, 0};
+
+static hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
+  const int pd = ctx().devs[(size_t)dst_dev].device, ps = ctx().devs[(size_t)src_dev].device;
+  if (pd == ps) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  return hipMemcpyPeerAsync(dst, pd, src, ps, bytes, s);
+}
+
+// gather the partial results of every sharded MSM queued since the last join to the primary device and fold them;
+// the primary stream s0 has already been made to wait for every reduction (msm_join_all)
+static int fold_sharded(hipStream_t s0) {
+  if (g_pending_folds.empty()) return H2MI_OK;
+  for (const PendingFold& pf : g_pending_folds) {
+    Sharded* sh = pf.sh;
+    const size_t W = sh->shard.size();
+    uint8_t* g = sh->gather + (size_t)pf.ring * W * 96;
+    for (size_t i = 0; i < W; i++) {
+      const Shard& sd = sh->shard[i];
+      const int dev = g_bases[sd.handle]->dev;
+      H2_HIP(copy_between(g + 96 * i, 0, sd.part + (size_t)pf.ring * 96, dev, 96, s0));
+    }
+    int rc = launch_fold_groups(g, W, 1, (uint8_t*)pf.d_out, s0);
+    if (rc) return rc;
+  }
+  g_pending_folds.clear();
+  return H2MI_OK;
+}
+
+static void free_sharded(Sharded* sh) {
+  for (Shard& sd : sh->shard) {
+    hipFree(sd.stage);
+    hipFree(sd.part);
+    if (sd.ready) hipEventDestroy(sd.ready);
+  }
+  hipFree(sh->gather);
+  delete sh;
+}
+
+// register bases (host pointer, or device pointer on the primary device) as one slice per device
+static int register_sharded(const void* bases, bool on_host, size_t n, uint64_t* handle_out) {
+  const size_t D = ctx().devs.size();
+  Sharded* sh = new Sharded();
+  sh->n = n;
+  int rc = H2MI_OK;
+  for (size_t i = 0; i < D && !rc; i++) {
+    const size_t base = n / D, rem = n % D;
+    const size_t lo = i * base + std::min(i, rem), hi = lo + base + (i < rem ? 1 : 0);
+    if (hi == lo) continue;  // fewer bases than devices
+    rc = use_device((int)i);
+    if (rc) break;
+    hipStream_t s = ctx().stream;
+    Shard sd;
+    sd.lo = lo;
+    sd.hi = hi;
+    void* tmp = nullptr;
+    if (hipMalloc(&tmp, (hi - lo) * 64) != hipSuccess || hipMalloc((void**)&sd.part, (size_t)SHARD_RING * 96) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ready, hipEventDisableTiming) != hipSuccess) {
+      hipFree(tmp);
+      hipFree(sd.part);
+      rc = H2MI_ENOMEM;
+      break;
+    }
+    hipError_t e = on_host ? hipMemcpyAsync(tmp, (const uint8_t*)bases + lo * 64, (hi - lo) * 64, hipMemcpyHostToDevice, s)
+                           : copy_between(tmp, (int)i, (const uint8_t*)bases + lo * 64, 0, (hi - lo) * 64, s);
+    if (e != hipSuccess) rc = H2MI_EHIP;
+    if (!rc) rc = register_dev(tmp, hi - lo, &sd.handle, s);  // synchronises s
+    hipFree(tmp);
+    if (rc) {
+      hipFree(sd.part);
+      hipEventDestroy(sd.ready);
+      break;
+    }
+    sh->shard.push_back(sd);
+  }
+  if (!rc) rc = use_device(0);
+  if (!rc && hipMalloc((void**)&sh->gather, (size_t)SHARD_RING * sh->shard.size() * 96) != hipSuccess) rc = H2MI_ENOMEM;
+  if (rc) {
+    for (Shard& sd : sh->shard) h2mi_bases_release(sd.handle);
+    use_device(0);
+    free_sharded(sh);
+    return rc;
+  }
+  const uint64_t h = g_next_handle++;
+  g_sharded[h] = sh;
+  *handle_out = h;
+  return H2MI_OK;
+}
+
+// queue one MSM over the first n registered bases of a sharded handle; the folded result reaches d_out (primary
+// device) at the next join.  scalars: host pointer, or device pointer on the primary device.
+static int msm_sharded(Sharded* sh, const void* scalars, bool on_host, size_t n, void* d_out) {
+  if (n > sh->n) return H2MI_ERANGE;
+  size_t queued = 0;
+  for (const PendingFold& pf : g_pending_folds) queued += pf.sh == sh ? 1 : 0;
+  int rc = use_device(0);
+  if (rc) return rc;
+  hipStream_t s0 = ctx().stream;
+  if (queued >= SHARD_RING) {  // the ring of partial results is full: fold what is queued
+    rc = msm_join_all(s0);
+    if (rc) return rc;
+  }
+  const uint32_t ring = sh->next++ % SHARD_RING;
+  hipEvent_t src_ready = nullptr;
+  if (!on_host) {  // the other devices' copies must follow whatever produced the scalars on the primary stream
+    src_ready = sh->shard[0].ready;
+    H2_HIP(hipEventRecord(src_ready, s0));
+  }
+  for (size_t i = 0; i < sh->shard.size() && !rc; i++) {
+    Shard& sd = sh->shard[i];
+    Bases* B = g_bases[sd.handle];
+    rc = use_device(B->dev);
+    if (rc) break;
+    hipStream_t si = ctx().stream;
+    const size_t cnt = n > sd.lo ? std::min(n, sd.hi) - sd.lo : 0;
+    uint8_t* out = sd.part + (size_t)ring * 96;
+    if (cnt == 0) {
+      H2_HIP(hipMemcpyAsync(out, G1_IDENTITY_J, 96, hipMemcpyHostToDevice, si));
+      continue;
+    }
+    const uint8_t* src = (const uint8_t*)scalars + sd.lo * 32;
+    const void* d_sc = src;
+    if (on_host || B->dev != 0) {
+      if (!sd.stage && hipMalloc((void**)&sd.stage, (sd.hi - sd.lo) * 32) != hipSuccess) {
+        sd.stage = nullptr;
+        rc = H2MI_ENOMEM;
+        break;
+      }
+      if (on_host) {
+        H2_HIP(hipMemcpyAsync(sd.stage, src, cnt * 32, hipMemcpyHostToDevice, si));
+      } else {
+        H2_HIP(hipStreamWaitEvent(si, src_ready, 0));
+        H2_HIP(copy_between(sd.stage, B->dev, src, 0, cnt * 32, si));
+        // the caller may overwrite its scalars in primary-stream order once this call returns
+        if (i != 0) {
+          H2_HIP(hipEventRecord(sd.ready, si));
+          H2_HIP(hipStreamWaitEvent(s0, sd.ready, 0));
+        }
+      }
+      d_sc = sd.stage;
+    }
+    rc = msm_dev(B, d_sc, cnt, out, si);
+  }
+  int rc2 = use_device(0);
+  if (rc) return rc;
+  if (rc2) return rc2;
+  g_pending_folds.push_back({sh, ring, d_out});
   return H2MI_OK;
 }
 
@@ -1259,8 +1448,10 @@ int msm_join_all(hipStream_t s) {
     for (Slot& S : kv.second->slot)
       if (S.tail_pending) {
         H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
-        if (s == ctx().stream) S.tail_pending = false;  // only the library stream's later work is now ordered behind it
+        // only the owning device's library stream is thereby ordered behind this slot's previous use
+        if (s == ctx().devs[(size_t)kv.second->dev].stream) S.tail_pending = false;
       }
+  if (s == ctx().devs[0].stream) return fold_sharded(s);  // partial results of sharded MSMs: gather + fold on the primary device
   return H2MI_OK;
 }
 
@@ -1274,6 +1465,7 @@ int h2mi_bases_register_dev(const void* d_bases, size_t n, uint64_t* handle_out)
   H2_REQUIRE_INIT();
   if (!d_bases || !handle_out) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (ctx().devs.size() > 1) return register_sharded(d_bases, /*on_host=*/false, n, handle_out);
   return register_dev(d_bases, n, handle_out, ctx().stream);
 }
 
@@ -1281,6 +1473,7 @@ int h2mi_bases_register(const uint64_t* bases, size_t n, uint64_t* handle_out) {
   H2_REQUIRE_INIT();
   if (!bases || !handle_out || n == 0) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (ctx().devs.size() > 1) return register_sharded(bases, /*on_host=*/true, n, handle_out);
   void* d = nullptr;
   hipError_t e = hipMalloc(&d, n * 64);
   if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
@@ -1296,6 +1489,21 @@ int h2mi_bases_register(const uint64_t* bases, size_t n, uint64_t* handle_out) {
 int h2mi_bases_release(uint64_t handle) {
   H2_REQUIRE_INIT();
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto sh = g_sharded.find(handle);
+  if (sh != g_sharded.end()) {
+    int rc = msm_join_all(ctx().devs[0].stream);  // folds still queued on it
+    if (rc) return rc;
+    for (DevCtx& d : ctx().devs) {
+      hipSetDevice(d.device);
+      hipDeviceSynchronize();
+    }
+    ctx().cur = -1;
+    use_device(0);
+    for (Shard& sd : sh->second->shard) h2mi_bases_release(sd.handle);
+    free_sharded(sh->second);
+    g_sharded.erase(sh);
+    return H2MI_OK;
+  }
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   flush_tails();
@@ -1312,6 +1520,12 @@ int h2mi_bases_release(uint64_t handle) {
 
 int h2mi_bases_info(uint64_t handle, uint32_t* c, uint32_t* windows, uint32_t* buckets, uint64_t* n) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto sh = g_sharded.find(handle);
+  if (sh != g_sharded.end()) {  // window geometry of the first slice, base count of the whole set
+    int rc = h2mi_bases_info(sh->second->shard[0].handle, c, windows, buckets, nullptr);
+    if (n) *n = sh->second->n;
+    return rc;
+  }
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (c) *c = it->second->c;
@@ -1396,6 +1610,11 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
     H2_HIP(hipMemcpyAsync(d_out_jacobian, G1_IDENTITY, 96, hipMemcpyHostToDevice, pick_stream(stream)));
     return H2MI_OK;
   }
+  auto sh = g_sharded.find(handle);
+  if (sh != g_sharded.end()) {  // every slice from this thread; folded into d_out_jacobian at the next join
+    if (stream) return H2MI_EINVAL;  // sharded MSMs run on the library's streams only
+    return msm_sharded(sh->second, d_scalars, /*on_host=*/false, n, d_out_jacobian);
+  }
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (n > it->second->n) return H2MI_ERANGE;
@@ -1414,6 +1633,17 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   uint64_t h = handle;
   int rc = H2MI_OK;
+  auto shd = g_sharded.find(handle);
+  if (shd != g_sharded.end()) {
+    static uint8_t* d_res = nullptr;  // 96 B on the primary device
+    if (!d_res) H2_HIP(hipMalloc((void**)&d_res, 96));
+    hipStream_t s0 = ctx().devs[0].stream;
+    rc = msm_sharded(shd->second, scalars, /*on_host=*/true, n, d_res);
+    if (!rc) rc = msm_join_all(s0);
+    if (!rc && hipMemcpyAsync(out, d_res, 96, hipMemcpyDeviceToHost, s0) != hipSuccess) rc = H2MI_EHIP;
+    if (hipStreamSynchronize(s0) != hipSuccess && !rc) rc = H2MI_EHIP;
+    return rc;
+  }
   if (handle == 0) {
     rc = adhoc_handle(bases, n, &h);
     if (rc) return rc;
@@ -1474,6 +1704,20 @@ int h2mi_msm_set_canonical(int on) {
 int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds) {
   H2_REQUIRE_INIT();
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto sh = g_sharded.find(handle);
+  if (sh != g_sharded.end()) {  // sums over the slices
+    uint64_t ba = 0, ra = 0;
+    for (Shard& sd : sh->second->shard) {
+      uint64_t a = 0, r = 0;
+      int rc = h2mi_msm_last_stats(sd.handle, &a, &r);
+      if (rc) return rc;
+      ba += a;
+      ra += r;
+    }
+    if (bucket_adds) *bucket_adds = ba;
+    if (reduce_adds) *reduce_adds = ra;
+    return H2MI_OK;
+  }
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   Bases* B = it->second;

@@ -14,8 +14,9 @@
  * Conventions: every function returns H2MI_OK (0) or a negative H2MI_E* code; h2mi_strerror() names
  * it.  No C++ exception crosses this boundary.  Pointers named d_* are DEVICE pointers (HBM of the
  * process's GPU); all others are host pointers owned by the caller for the duration of the call.
- * One process drives one GPU (h2mi_init picks it); multi-GPU jobs run one process per GPU and combine
- * the 96-byte partial MSM results themselves (all-gather + h2mi_g1_sum_jacobian).
+ * Multi-GPU, two ways: one process per GPU (h2mi_init picks the GPU; the job combines the 96-byte partial MSM
+ * results itself: RCCL all-gather + h2mi_g1_fold_groups_dev), or ONE process driving n GPUs
+ * (h2mi_init_devices: the bases are sharded at registration and every MSM folds its partial results internally).
  * Calls are serialised by an internal mutex, so any thread may call.
  * There is NO CPU fallback: without a usable GPU every compute entry point returns H2MI_ENODEV.
  */
@@ -46,6 +47,17 @@ typedef void* h2mi_stream_t; /* a hipStream_t, or NULL for the library's own str
  * for the same device.  Replaces nothing in the reference (which has no device); the Rust shim calls
  * it once from a `std::sync::Once`. */
 int h2mi_init(int device);
+/* One prover process, n devices (SURVEY.md 8b `h2mi_init(n_devices)`; the reference is one process calling
+ * create_proof once, src/scaffold.rs:246-366): devices 0 .. n-1, device 0 the primary.  Afterwards
+ *   h2mi_bases_register{,_dev}   shard the base set: one contiguous slice (and its window tables) per device;
+ *   h2mi_msm_bn254_g1{,_dev}     launch every slice from the calling thread and fold the 96-byte partial results on
+ *                                the primary device (host form: at once; _dev form, stream = NULL only: at the next
+ *                                h2mi_join / h2mi_sync / h2mi_memcpy_d2h, like every queued MSM);
+ * transforms, polynomial helpers and every d_* pointer stay on the primary device (NTT is single-GPU by design).
+ * H2MI_VIRTUAL_DEVICES=1 lets n exceed the number of GPUs (entry i runs on GPU i mod count): a one-GPU rehearsal of
+ * the sharding, scalar distribution and fold.  Mutually exclusive with h2mi_init. */
+int h2mi_init_devices(int n_devices);
+int h2mi_device_count(void); /* devices this process drives (0 before init) */
 void h2mi_shutdown(void);
 const char* h2mi_strerror(int code);
 const char* h2mi_version(void);

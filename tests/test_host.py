@@ -42,6 +42,17 @@ def test_no_cpu_fallback_without_gpu(h2):
     assert b"no CPU fallback" in h2.lib.h2mi_strerror(-2)
 
 
+def test_multi_device_mode_needs_devices(h2):
+    """h2mi_init_devices (one process, n GPUs) fails like h2mi_init without a GPU and leaves the library uninitialised;
+    the slice partition it applies is the one dist.slice_bounds states (contiguous, sizes differing by at most one)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_multidevice.py")
+    assert h2.lib.h2mi_init_devices(4) == -2 and h2.lib.h2mi_device_count() == 0
+    assert h2.lib.h2mi_init_devices(0) == -1 and h2.lib.h2mi_init_devices(17) == -1
+
+
 def test_argument_checks_mirror_reference_asserts(h2):
     with pytest.raises(AssertionError):  # assert_eq!(coeffs.len(), bases.len())
         h2.best_multiexp(np.zeros((3, 4), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64))
