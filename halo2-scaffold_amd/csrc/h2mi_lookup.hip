@@ -1,0 +1,178 @@
+// libh2mi.so — the lookup argument's permuted columns on the device (BASELINE config 3).
+//
+// halo2_proofs plonk/lookup/prover.rs `permute_expression_pair` (reached from create_proof's `lookups.commit_permuted`;
+// the reference selects a lookup table with LOOKUP_BITS, src/scaffold.rs:44-48,462): A' = the usable input rows sorted,
+// S' = the table rearranged so that S'[j] = A'[j] wherever A' starts a new run and the table values not consumed that
+// way fill the repeated rows.  The crate sorts 2^k field elements and walks a BTreeMap on one thread.
+//
+// Here (single-expression lookups: one input column against one fixed column, the range-check case): every valid input
+// value IS a table value, and the table is fixed, so its distinct values are sorted once at keygen (host) and a proof
+// needs no sort at all — a counting sort against that table:
+//   k_lk_rank         rank of every input in the sorted table (binary search on canonical 256-bit values), histogram
+//   scan              run starts of A'
+//   k_lk_leftover     table multiplicity minus one for every value that occurs among the inputs; scan -> positions
+//   k_lk_fill_input   A'[j] = value of the run containing j; marks repeated rows; scan -> repeated rows before j
+//   k_lk_fill_table   S'[j] = A'[j] on a run start, else the (number of repeated rows after j)-th leftover value
+//                     (the crate pops repeated rows from the END while walking the leftovers in ascending order)
+// Integer / byte work over HBM-resident vectors: no field multiplication except the Montgomery -> canonical conversion
+// of the inputs.
+#include <algorithm>
+
+#include "fp.cuh"
+#include "h2mi_internal.h"
+#include "scan.cuh"
+
+namespace h2 {
+
+using Fr = FrP;
+
+__device__ __forceinline__ int cmp256(const fe& a, const fe& b) {  // canonical little-endian words
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    if (a.v[i] != b.v[i]) return a.v[i] < b.v[i] ? -1 : 1;
+  }
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_lk_rank(const fe* input, uint32_t u, const fe* sorted, uint32_t n_unique, uint32_t* rank, uint32_t* cnt,
+                                                 uint32_t* missing) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= u) return;
+  const fe v = fe_from_mont<Fr>(fe_load(&input[i]));
+  uint32_t lo = 0, hi = n_unique;  // first index with sorted[idx] >= v
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cmp256(fe_load(&sorted[mid]), v) < 0) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo < n_unique && cmp256(fe_load(&sorted[lo]), v) == 0) {
+    rank[i] = lo;
+    atomicAdd(&cnt[lo], 1u);
+  } else {
+    rank[i] = 0xFFFFFFFFu;
+    atomicAdd(missing, 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lk_leftover(const uint32_t* cnt, const uint32_t* mult, uint32_t n_unique, uint32_t* left, uint32_t* missing) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_unique) return;
+  const uint32_t used = cnt[r] ? 1u : 0u;
+  if (used > mult[r]) {  // cannot happen for values found in the table; keeps the arithmetic unsigned-safe
+    atomicAdd(missing, 1u);
+    left[r] = 0;
+  } else {
+    left[r] = mult[r] - used;
+  }
+}
+
+// largest r < m with start[r] <= x, where start is an exclusive scan (non-decreasing) and start[m] = total > x
+__device__ __forceinline__ uint32_t run_of(const uint32_t* start, uint32_t m, uint32_t x) {
+  uint32_t lo = 0, hi = m;  // first index in [0, m] with start[idx] > x
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (start[mid] <= x) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo - 1;
+}
+
+__global__ void __launch_bounds__(256) k_lk_fill_input(const uint32_t* start, uint32_t n_unique, const fe* sorted_mont, uint32_t u, fe* a_perm,
+                                                       uint32_t* repeated) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= u) return;
+  const uint32_t r = run_of(start, n_unique, j);
+  fe_store(&a_perm[j], fe_load(&sorted_mont[r]));
+  repeated[j] = j != start[r] ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_lk_fill_table(const uint32_t* repeated, const uint32_t* rep_before, const uint32_t* lstart, uint32_t n_unique,
+                                                       const fe* sorted_mont, const fe* a_perm, uint32_t u, fe* s_perm) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= u) return;
+  if (!repeated[j]) {
+    fe_store(&s_perm[j], fe_load(&a_perm[j]));
+    return;
+  }
+  const uint32_t after = rep_before[u] - rep_before[j] - 1;  // repeated rows with a larger index
+  fe_store(&s_perm[j], fe_load(&sorted_mont[run_of(lstart, n_unique, after)]));
+}
+
+static uint32_t* g_lk_scratch = nullptr;
+static size_t g_lk_words = 0;
+
+static int scan_u32(const uint32_t* in, uint32_t* out, uint32_t m /* multiple of 4 */, uint32_t* segsum, hipStream_t s) {
+  const uint32_t nseg = ceil_div_u32(m, SCAN_SEG_BINS);
+  if (nseg > 1) H2_LAUNCH("k_scan_segsum", k_scan_segsum<SCAN_SEG_BINS>, nseg, 1024, 0, s, in, m, segsum);
+  H2_LAUNCH("k_scan_seg_lookup", k_scan_seg<SCAN_SEG_BINS>, dim3(nseg, 1), 1024, 0, s, in, out, (const uint32_t*)nullptr, (uint32_t*)nullptr, m, (const uint32_t*)segsum);
+  return H2MI_OK;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorted, const void* d_table_sorted_mont, const void* d_table_mult,
+                                  uint32_t n_unique, uint32_t k, uint32_t usable_rows, void* d_permuted_input, void* d_permuted_table,
+                                  uint64_t* not_in_table_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_input || !d_table_sorted || !d_table_sorted_mont || !d_table_mult || !d_permuted_input || !d_permuted_table || n_unique == 0)
+    return H2MI_EINVAL;
+  if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k) || n_unique > usable_rows) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  const uint32_t u = usable_rows;
+  const uint32_t mu = (n_unique + 3u) & ~3u, uu = (u + 3u) & ~3u;  // scan lengths (multiples of 4; the pads are zero)
+  const uint32_t nseg = ceil_div_u32(std::max(mu, uu), SCAN_SEG_BINS) + 1;
+  // scratch (words): cnt[mu+4] start[mu+4] left[mu+4] lstart[mu+4] rank[uu] rep[uu+4] rep_before[uu+4] segsum[nseg] missing[4]
+  const size_t words = 4 * ((size_t)mu + 4) + (size_t)uu + 2 * ((size_t)uu + 4) + nseg + 4;
+  if (g_lk_words < words) {
+    if (g_lk_scratch) {
+      H2_HIP(hipDeviceSynchronize());
+      H2_HIP(hipFree(g_lk_scratch));
+      g_lk_scratch = nullptr;
+      g_lk_words = 0;
+    }
+    hipError_t e = hipMalloc((void**)&g_lk_scratch, words * 4);
+    if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
+    H2_HIP(e);
+    g_lk_words = words;
+  }
+  uint32_t* cnt = g_lk_scratch;
+  uint32_t* start = cnt + mu + 4;
+  uint32_t* left = start + mu + 4;
+  uint32_t* lstart = left + mu + 4;
+  uint32_t* rank = lstart + mu + 4;
+  uint32_t* rep = rank + uu;
+  uint32_t* rep_before = rep + uu + 4;
+  uint32_t* segsum = rep_before + uu + 4;
+  uint32_t* missing = segsum + nseg;
+  H2_HIP(hipMemsetAsync(g_lk_scratch, 0, words * 4, s));
+  const fe* in = (const fe*)d_input;
+  const fe* sorted = (const fe*)d_table_sorted;
+  const fe* sorted_mont = (const fe*)d_table_sorted_mont;
+  H2_LAUNCH("k_lk_rank", k_lk_rank, ceil_div_u32(u, 256), 256, 0, s, in, u, sorted, n_unique, rank, cnt, missing);
+  int rc = scan_u32(cnt, start, mu, segsum, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_lk_leftover", k_lk_leftover, ceil_div_u32(n_unique, 256), 256, 0, s, (const uint32_t*)cnt, (const uint32_t*)d_table_mult, n_unique, left, missing);
+  rc = scan_u32(left, lstart, mu, segsum, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_lk_fill_input", k_lk_fill_input, ceil_div_u32(u, 256), 256, 0, s, (const uint32_t*)start, n_unique, sorted_mont, u, (fe*)d_permuted_input, rep);
+  rc = scan_u32(rep, rep_before, uu, segsum, s);
+  if (rc) return rc;
+  // rep_before[uu] holds the total; the fill kernel reads it at index u: identical when u is a multiple of 4, else the
+  // zero pads make rep_before[u] == rep_before[uu]
+  H2_LAUNCH("k_lk_fill_table", k_lk_fill_table, ceil_div_u32(u, 256), 256, 0, s, (const uint32_t*)rep, (const uint32_t*)rep_before, (const uint32_t*)lstart,
+            n_unique, sorted_mont, (const fe*)d_permuted_input, u, (fe*)d_permuted_table);
+  if (not_in_table_out) {  // the crate fails the proof (ConstraintSystemFailure) when an input is not in the table
+    uint32_t m = 0;
+    H2_HIP(hipMemcpyAsync(&m, missing, 4, hipMemcpyDeviceToHost, s));
+    H2_HIP(hipStreamSynchronize(s));
+    *not_in_table_out = m;
+  }
+  return H2MI_OK;
+}
+
+}  // extern "C"

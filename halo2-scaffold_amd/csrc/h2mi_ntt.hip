@@ -690,6 +690,86 @@ __global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u
   const size_t t = (size_t)set * u + i;
   fe_store(&out.z[set][i], t ? fe_load(&R[t - 1]) : fe_one<Fr>());
 }
+// lookup argument's grand product (plonk/lookup/prover.rs commit_product), single-expression lookups:
+// num_i = (a_i + beta)(t_i + gamma), den_i = (a'_i + beta)(s'_i + gamma), i < u
+__global__ void __launch_bounds__(256) k_lookup_numden(const fe* input, const fe* table, const fe* pin, const fe* ptab, fe beta, fe gamma, uint32_t u,
+                                                        fe* num, fe* den) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= u) return;
+  fe_store(&num[i], fe_mul<Fr>(fe_add<Fr>(fe_load(&input[i]), beta), fe_add<Fr>(fe_load(&table[i]), gamma)));
+  fe_store(&den[i], fe_mul<Fr>(fe_add<Fr>(fe_load(&pin[i]), beta), fe_add<Fr>(fe_load(&ptab[i]), gamma)));
+}
+
+// ---- quotient numerator of the range-check constraint system (BASELINE config 3) -------------------
+// What the reference's RangeWithInstanceCircuitBuilder produces (src/scaffold.rs:434-485) [halo2-base shape restated
+// from memory]: one vertical gate q (a + a(wX) a(w^2 X) - a(w^3 X)) on the advice column, a permutation argument over
+// n_perm <= 4 equality-enabled columns in chunks of two (constraint-system degree 4), one single-expression lookup of
+// the lookup-advice column in the fixed table.  Terms in evaluate_h's order (gates, permutation, lookups), Horner in y,
+// divided by X^n - 1; extended domain 4n.
+struct RangeCosets {
+  const fe* a;
+  const fe* la;
+  const fe* q;
+  const fe* table;
+  const fe* perm_value[4];
+  const fe* perm_sigma[4];
+  const fe* perm_z[2];
+  const fe* lk_input;
+  const fe* lk_table;
+  const fe* lk_z;
+  const fe* l0;
+  const fe* l_last;
+  const fe* l_active;
+  uint32_t n_perm;
+};
+__global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma, fe y, fe delta,
+                                                           fe zeta, const fe* xlo, const fe* xhi, uint32_t xh, TInv t_inv, fe* out) {
+  const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= size) return;
+  auto at = [&](int r) { return (idx + size + (uint32_t)(r * (int)rot)) & (size - 1); };
+  const uint32_t r_next = at(1), r_prev = at(-1), r_last = at(-(int)last_rot);
+  const fe one = fe_one<Fr>();
+  const fe l0 = fe_load(&c.l0[idx]), ll = fe_load(&c.l_last[idx]), la_ = fe_load(&c.l_active[idx]);
+  // gate
+  fe v = fe_mul<Fr>(fe_load(&c.q[idx]), fe_sub<Fr>(fe_add<Fr>(fe_load(&c.a[idx]), fe_mul<Fr>(fe_load(&c.a[at(1)]), fe_load(&c.a[at(2)]))),
+                                                   fe_load(&c.a[at(3)])));
+  // permutation argument: sets of two columns
+  const uint32_t sets = (c.n_perm + 1) >> 1;
+  const fe z_first = fe_load(&c.perm_z[0][idx]);
+  const fe z_lastset = fe_load(&c.perm_z[sets - 1][idx]);
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, z_first), l0));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z_lastset), z_lastset), ll));
+  if (sets == 2) v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z_lastset, fe_load(&c.perm_z[0][r_last])), l0));
+  fe X;
+  f29_to_mont256<F9>(pow2tab(xlo, xhi, xh, idx), X.v);
+  fe cur = fe_mul<Fr>(beta, fe_mul<Fr>(zeta, X));
+  for (uint32_t s = 0; s < sets; s++) {
+    fe left = fe_load(&c.perm_z[s][r_next]), right = s == 0 ? z_first : z_lastset;
+    for (uint32_t j = 2 * s; j < c.n_perm && j < 2 * s + 2; j++) {
+      const fe val = fe_load(&c.perm_value[j][idx]);
+      left = fe_mul<Fr>(left, fe_add<Fr>(fe_add<Fr>(val, fe_mul<Fr>(beta, fe_load(&c.perm_sigma[j][idx]))), gamma));
+      right = fe_mul<Fr>(right, fe_add<Fr>(fe_add<Fr>(val, cur), gamma));
+      cur = fe_mul<Fr>(cur, delta);
+    }
+    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la_));
+  }
+  // lookup argument: five terms
+  const fe ap = fe_load(&c.lk_input[idx]), sp = fe_load(&c.lk_table[idx]), zl = fe_load(&c.lk_z[idx]);
+  const fe table_value = fe_mul<Fr>(fe_add<Fr>(fe_load(&c.la[idx]), beta), fe_add<Fr>(fe_load(&c.table[idx]), gamma));
+  const fe a_minus_s = fe_sub<Fr>(ap, sp);
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, zl), l0));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(zl), zl), ll));
+  {
+    const fe lhs = fe_mul<Fr>(fe_mul<Fr>(fe_load(&c.lk_z[r_next]), fe_add<Fr>(ap, beta)), fe_add<Fr>(sp, gamma));
+    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(lhs, fe_mul<Fr>(zl, table_value)), la_));
+  }
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(a_minus_s, l0));
+  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_mul<Fr>(a_minus_s, fe_sub<Fr>(ap, fe_load(&c.lk_input[r_prev]))), la_));
+  v = fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]);
+  fe_store(&out[idx], v);
+}
+
 __global__ void k_fr_inv_one(const fe* in, fe* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(out, fe_inv_gcd<Fr>(fe_load(in)));  // one inversion on the critical path
 }
@@ -1320,6 +1400,80 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
   if (rc) return rc;
   H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), sets), 256, 0, s, (const fe*)num, usable_rows, zo);
   return release_tmp(s);
+}
+
+int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,
+                                  uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], void* d_z, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_input || !d_table || !d_permuted_input || !d_permuted_table || !beta || !gamma || !d_z) return H2MI_EINVAL;
+  if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  const size_t total = usable_rows;
+  const uint32_t nblocks = ceil_div_u32(total, MS_TILE);
+  int rc = ensure_tmp(3 * total + 2 * (size_t)nblocks + 2, s);
+  if (rc) return rc;
+  fe* num = g_tmp;
+  fe* P = num + total;
+  fe* S = P + total;
+  fe* totals = S + total;
+  fe* offsets = totals + nblocks;
+  fe* inv_total = offsets + nblocks;
+  H2_LAUNCH("k_lookup_numden", k_lookup_numden, ceil_div_u32(total, 256), 256, 0, s, (const fe*)d_input, (const fe*)d_table, (const fe*)d_permuted_input,
+            (const fe*)d_permuted_table, host_fe(beta), host_fe(gamma), usable_rows, num, P);
+  H2_HIP(hipMemcpyAsync(S, P, total * 32, hipMemcpyDeviceToDevice, s));
+  rc = mulscan(P, total, 0, totals, offsets, s);
+  if (!rc) rc = mulscan(S, total, 1, totals, offsets, s);
+  if (rc) return rc;
+  H2_LAUNCH("k_fr_inv_one", k_fr_inv_one, 1, 64, 0, s, (const fe*)(P + (total - 1)), inv_total);
+  H2_LAUNCH("k_perm_ratio", k_perm_ratio, ceil_div_u32(total, 256), 256, 0, s, (const fe*)num, (const fe*)P, (const fe*)S, (const fe*)inv_total, total, num);
+  rc = mulscan(num, total, 0, totals, offsets, s);
+  if (rc) return rc;
+  ZOut zo;
+  memset(&zo, 0, sizeof(zo));
+  zo.z[0] = (fe*)d_z;
+  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), 1), 256, 0, s, (const fe*)num, usable_rows, zo);
+  return release_tmp(s);
+}
+
+int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint32_t extended_k, uint32_t blinding_factors, const uint64_t beta[4],
+                                    const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4], const uint64_t zeta[4],
+                                    const uint64_t extended_omega[4], const uint64_t* t_inv, void* d_h_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
+  if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  if (c->n_perm == 0 || c->n_perm > 4) return H2MI_EINVAL;
+  RangeCosets rc_;
+  memset(&rc_, 0, sizeof(rc_));
+  rc_.a = (const fe*)c->a; rc_.la = (const fe*)c->lookup_advice; rc_.q = (const fe*)c->q; rc_.table = (const fe*)c->table;
+  rc_.lk_input = (const fe*)c->lookup_permuted_input; rc_.lk_table = (const fe*)c->lookup_permuted_table; rc_.lk_z = (const fe*)c->lookup_z;
+  rc_.l0 = (const fe*)c->l0; rc_.l_last = (const fe*)c->l_last; rc_.l_active = (const fe*)c->l_active;
+  rc_.n_perm = c->n_perm;
+  if (!rc_.a || !rc_.la || !rc_.q || !rc_.table || !rc_.lk_input || !rc_.lk_table || !rc_.lk_z || !rc_.l0 || !rc_.l_last || !rc_.l_active) return H2MI_EINVAL;
+  for (uint32_t j = 0; j < c->n_perm; j++) {
+    rc_.perm_value[j] = (const fe*)c->perm_value[j];
+    rc_.perm_sigma[j] = (const fe*)c->perm_sigma[j];
+    if (!rc_.perm_value[j] || !rc_.perm_sigma[j]) return H2MI_EINVAL;
+  }
+  for (uint32_t q = 0; q < (c->n_perm + 1) / 2; q++) {
+    rc_.perm_z[q] = (const fe*)c->perm_z[q];
+    if (!rc_.perm_z[q]) return H2MI_EINVAL;
+  }
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  PowTab px;
+  int rc = get_powtab(extended_omega, extended_k, s, &px);
+  if (rc) return rc;
+  const uint32_t rot = 1u << (extended_k - k);
+  TInv tinv;
+  memset(&tinv, 0, sizeof(tinv));
+  for (uint32_t i = 0; i < rot; i++) tinv.v[i] = host_fe(t_inv + 4 * i);
+  const uint32_t size = 1u << extended_k;
+  H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, host_fe(beta),
+            host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, tinv, (fe*)d_h_out);
+  return H2MI_OK;
 }
 
 int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,

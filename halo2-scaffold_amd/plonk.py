@@ -12,6 +12,7 @@ import numpy as np
 
 from . import field as F
 from ._lib import check, lib
+from ._lib import check as _check
 from .device import DevBuf
 from .domain import EvaluationDomain
 
@@ -88,3 +89,77 @@ def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamm
     w = F.fr_to_mont_limbs(F.omega_for(k))
     check(lib.h2mi_plonk_permutation_products_dev(vp, sp, m, chunk_len, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data, w.ctypes.data,
                                                   zp, None), "permutation_products")
+
+
+# ---- lookup argument, single-expression lookups (the range check of the reference's RangeWithInstanceCircuitBuilder,
+# src/scaffold.rs:434-485 with LOOKUP_BITS, :44-48) -----------------------------------------------------------------------
+class LookupTable:
+    """keygen-time description of a fixed lookup table column for the device's counting sort: the distinct values of
+    its usable rows in ascending (canonical integer) order, their multiplicities, uploaded once."""
+
+    def __init__(self, table_values, usable_rows: int):
+        """table_values: the fixed column as integers (as the circuit assigns them), at least usable_rows of them"""
+        counts = {}
+        for v in table_values[:usable_rows]:
+            v %= F.FR_MODULUS
+            counts[v] = counts.get(v, 0) + 1
+        vals = sorted(counts)
+        self.n_unique = len(vals)
+        self.usable_rows = usable_rows
+        can = np.zeros((self.n_unique, 4), dtype=np.uint64)
+        mont = np.zeros((self.n_unique, 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            can[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+            mont[i] = F.fr_to_mont_limbs(v)
+        self.sorted_canonical = DevBuf.from_numpy(can)
+        self.sorted_mont = DevBuf.from_numpy(mont)
+        self.mult = DevBuf.from_numpy(np.array([counts[v] for v in vals], dtype=np.uint32))
+
+    def free(self):
+        for b in (self.sorted_canonical, self.sorted_mont, self.mult):
+            b.free()
+
+
+def lookup_permute(k: int, d_input: DevBuf, table: LookupTable, d_permuted_input: DevBuf, d_permuted_table: DevBuf, check: bool = True) -> int:
+    """lookup/prover.rs permute_expression_pair on the device; rows beyond usable_rows are left to the caller (blinding).
+    Returns the number of inputs that are not table values (the crate raises ConstraintSystemFailure when non-zero)."""
+    missing = C.c_uint64()
+    _check(lib.h2mi_plonk_lookup_permute_dev(d_input.ptr, table.sorted_canonical.ptr, table.sorted_mont.ptr, table.mult.ptr, table.n_unique, k,
+                                             table.usable_rows, d_permuted_input.ptr, d_permuted_table.ptr, C.byref(missing) if check else None, None),
+           "lookup_permute")
+    return missing.value
+
+
+def lookup_product(k: int, d_input: DevBuf, d_table: DevBuf, d_permuted_input: DevBuf, d_permuted_table: DevBuf, beta: int, gamma: int,
+                   usable_rows: int, d_z: DevBuf) -> None:
+    b_, g_ = F.fr_to_mont_limbs(beta), F.fr_to_mont_limbs(gamma)
+    _check(lib.h2mi_plonk_lookup_product_dev(d_input.ptr, d_table.ptr, d_permuted_input.ptr, d_permuted_table.ptr, k, usable_rows, b_.ctypes.data,
+                                             g_.ctypes.data, d_z.ptr, None), "lookup_product")
+
+
+class _RangeCosets(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lookup_advice", C.c_void_p), ("q", C.c_void_p), ("table", C.c_void_p), ("perm_value", C.c_void_p * 4),
+                ("perm_sigma", C.c_void_p * 4), ("perm_z", C.c_void_p * 2), ("lookup_permuted_input", C.c_void_p), ("lookup_permuted_table", C.c_void_p),
+                ("lookup_z", C.c_void_p), ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p), ("n_perm", C.c_uint32)]
+
+
+def evaluate_h_range(domain: EvaluationDomain, a: DevBuf, lookup_advice: DevBuf, q: DevBuf, table: DevBuf, perm_values, perm_sigmas, perm_zs,
+                     lk_input: DevBuf, lk_table: DevBuf, lk_z: DevBuf, l0: DevBuf, l_last: DevBuf, l_active: DevBuf, beta: int, gamma: int, y: int,
+                     out: DevBuf) -> None:
+    """h(X) on the extended coset (already divided by X^n - 1) for the range-check constraint system (degree 4)"""
+    m = len(perm_values)
+    assert 1 <= m <= 4 and len(perm_sigmas) == m and len(perm_zs) == (m + 1) // 2
+    cs = _RangeCosets()
+    cs.a, cs.lookup_advice, cs.q, cs.table = a.ptr, lookup_advice.ptr, q.ptr, table.ptr
+    for j in range(m):
+        cs.perm_value[j], cs.perm_sigma[j] = perm_values[j].ptr, perm_sigmas[j].ptr
+    for s in range(len(perm_zs)):
+        cs.perm_z[s] = perm_zs[s].ptr
+    cs.lookup_permuted_input, cs.lookup_permuted_table, cs.lookup_z = lk_input.ptr, lk_table.ptr, lk_z.ptr
+    cs.l0, cs.l_last, cs.l_active = l0.ptr, l_last.ptr, l_active.ptr
+    cs.n_perm = m
+    mm = F.fr_to_mont_limbs
+    t_inv = np.ascontiguousarray(vanishing_inverses(domain))
+    args = [mm(beta), mm(gamma), mm(y), mm(FR_DELTA), mm(domain.g_coset), mm(domain.extended_omega)]
+    _check(lib.h2mi_plonk_evaluate_h_range_dev(C.byref(cs), domain.k, domain.extended_k, BLINDING_FACTORS, *[x.ctypes.data for x in args],
+                                               t_inv.ctypes.data, out.ptr, None), "evaluate_h_range")

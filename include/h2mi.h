@@ -225,6 +225,46 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
                                         const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4], void* const* d_z,
                                         h2mi_stream_t stream);
 
+/* ---- lookup argument (plonk/lookup/prover.rs), single-expression lookups: the range check the reference's
+ * RangeWithInstanceCircuitBuilder configures with LOOKUP_BITS (src/scaffold.rs:44-48,434-485; examples/range.rs:10-34).
+ * commit_permuted's permute_expression_pair on the device: d_permuted_input[0 .. usable_rows) = the usable input rows
+ * sorted (Fr's Ord: canonical integer order), d_permuted_table = the table rearranged against it (the input value where
+ * a run starts, the unconsumed table values — ascending — on the repeated rows, last repeated row first); rows beyond
+ * usable_rows (the blinding rows) are left untouched.  The fixed table is described by its distinct usable values in
+ * ascending order (canonical little-endian integers AND the same values in Montgomery form) and their multiplicities,
+ * prepared once at keygen: a proof needs no sort, only a counting sort against them.  not_in_table_out (may be NULL;
+ * non-NULL synchronises) receives the number of inputs that are not table values — the crate fails the proof then. */
+int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorted_canonical, const void* d_table_sorted_mont,
+                                  const void* d_table_mult /* u32 x n_unique */, uint32_t n_unique, uint32_t k, uint32_t usable_rows,
+                                  void* d_permuted_input, void* d_permuted_table, uint64_t* not_in_table_out, h2mi_stream_t stream);
+/* commit_product: z[0] = 1, z[i+1] = z[i] (a_i + beta)(t_i + gamma) / ((a'_i + beta)(s'_i + gamma)), i < usable_rows;
+ * blinding rows untouched; one field inversion per call */
+int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,
+                                  uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], void* d_z, h2mi_stream_t stream);
+/* evaluate_h + vanishing division for the range-check constraint system [halo2-base shape restated from memory]: gate
+ * q (a + a(wX) a(w^2 X) - a(w^3 X)), permutation argument over n_perm <= 4 columns in chunks of two (degree 4: the
+ * extended domain is 4n), one lookup of `lookup_advice` in `table`.  All vectors are extended-coset evaluations. */
+typedef struct {
+  const void* a;               /* the gate's advice column */
+  const void* lookup_advice;   /* the lookup input column */
+  const void* q;               /* gate selector */
+  const void* table;           /* fixed lookup table */
+  const void* perm_value[4];   /* equality-enabled columns in argument order */
+  const void* perm_sigma[4];
+  const void* perm_z[2];       /* ceil(n_perm / 2) grand products */
+  const void* lookup_permuted_input;
+  const void* lookup_permuted_table;
+  const void* lookup_z;
+  const void* l0;
+  const void* l_last;
+  const void* l_active;
+  uint32_t n_perm;
+} h2mi_range_cosets;
+int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* cosets, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,
+                                    const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4],
+                                    const uint64_t zeta[4], const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
+                                    void* d_h_out, h2mi_stream_t stream);
+
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
  * generator (1, 2) with on-device normalisation. */

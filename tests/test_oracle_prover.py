@@ -82,3 +82,40 @@ def test_permutation_assembly_matches_hand_derivation():
         pa.copy(left, right)
     assert {c: t for c, t in pa.mapping.items() if c != t} == cyc
     assert syn.advice[2] == {1: 49, 2: 49 + 72} and syn.fixed[2] == {1: o.R - 1, 2: o.R - 1} and syn.fixed[4] == {2: 72}
+
+
+def test_lookup_oracle_quotient_identity_and_rejection():
+    """oracle/lookup.py (the range-check constraint system: vertical gate, permutation in chunks of two, one lookup):
+    permuted columns are a permutation pair with the crate's structure, both grand products close, the numerator is
+    divisible by X^n - 1 (degree bound) and the verifier's identity holds at random points; a value outside the table is
+    rejected; a tampered copy constraint breaks the identity."""
+    from oracle import lookup as L
+
+    k, bits = 6, 4
+    inst = L.RangeInstance(k, bits, seed=3, extra_cols=2)
+    u, n = inst.u, inst.n
+    beta, gamma, y = 0xB0B, 0xCAFE, 0xD00D
+    ap, sp = inst.permuted()
+    assert ap[:u] == sorted(inst.la[:u]) and sorted(sp[:u]) == sorted(inst.table[:u])
+    assert ap[0] == sp[0] and all(ap[j] == sp[j] or ap[j] == ap[j - 1] for j in range(1, u))
+    zl = L.lookup_product(inst.la, inst.table, ap, sp, beta, gamma, u, inst.blind(5))
+    zs = inst.permutation_products(beta, gamma)
+    assert zl[u] == 1 and zs[-1][u] == 1 and len(zs) == 2
+    h = inst.divide_by_vanishing(inst.evaluate_h(zs, ap, sp, zl, beta, gamma, y))
+    full = [c * inst.dom.extended_ifft_divisor % o.R for c in o.ntt(h, inst.dom.extended_omega_inv)]
+    assert not any(full[3 * n:])
+    hc = inst.dom.extended_to_coeff(h)
+    assert all(L.check_quotient_identity(inst, zs, ap, sp, zl, hc, beta, gamma, y, x) for x in (7, 0xABCDEF123))
+    bad = L.RangeInstance(k, bits, seed=3, extra_cols=2)
+    bad.la[9] = (1 << bits) + 3
+    with pytest.raises(ValueError):
+        bad.permuted()
+    t = L.RangeInstance(k, bits, seed=3, extra_cols=2)
+    t.la[2] = (t.la[2] + 1) % (1 << bits)  # copy-constrained to a[8]: still in the table, no longer equal
+    ap2, sp2 = t.permuted()
+    zl2 = L.lookup_product(t.la, t.table, ap2, sp2, beta, gamma, u, t.blind(5))
+    zs2 = t.permutation_products(beta, gamma)
+    assert zl2[u] == 1 and zs2[-1][u] != 1
+    h2 = t.divide_by_vanishing(t.evaluate_h(zs2, ap2, sp2, zl2, beta, gamma, y))
+    hc2 = t.dom.extended_to_coeff(h2)
+    assert not L.check_quotient_identity(t, zs2, ap2, sp2, zl2, hc2, beta, gamma, y, 7)
