@@ -87,6 +87,7 @@ def _load():
         "h2mi_profile_enable": ([C.c_int], C.c_int),
         "h2mi_profile_filter": ([C.c_char_p], C.c_int),
         "h2mi_profile_reset": ([], C.c_int),
+        "h2mi_profile_dump": ([C.c_char_p, sz, C.POINTER(sz)], C.c_int),
         "h2mi_profile_query": ([C.c_char_p, C.POINTER(C.c_double), u64p], C.c_int),
         "h2mi_dbg_field_op": ([C.c_int, C.c_int, vp, vp, vp, sz], C.c_int),
         "h2mi_dbg_g1_op": ([C.c_int, vp, vp, vp, sz], C.c_int),

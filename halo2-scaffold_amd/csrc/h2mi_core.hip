@@ -1,4 +1,6 @@
 // libh2mi.so — lifecycle, device memory, profiling, elementwise test hooks and the small G1 helpers.
+#include <algorithm>
+
 #include "g1.cuh"
 #include "h2mi_internal.h"
 
@@ -366,6 +368,29 @@ int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches)
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = cnt;
+  return H2MI_OK;
+}
+
+int h2mi_profile_dump(char* buf, size_t cap, size_t* needed_out) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  H2_HIP(hipDeviceSynchronize());
+  std::string out;
+  hipEvent_t first = ctx().prof.empty() ? nullptr : ctx().prof.front().a;
+  for (auto& r : ctx().prof) {
+    float ms = 0, t0 = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    if (hipEventElapsedTime(&t0, first, r.a) != hipSuccess) t0 = -1;  // events of another device
+    char line[160];
+    snprintf(line, sizeof(line), "%s %.4f %.4f\n", r.name.c_str(), t0, ms);
+    out += line;
+  }
+  if (needed_out) *needed_out = out.size() + 1;
+  if (buf && cap) {
+    const size_t nn = std::min(cap - 1, out.size());
+    memcpy(buf, out.data(), nn);
+    buf[nn] = 0;
+  }
   return H2MI_OK;
 }
 

@@ -296,6 +296,9 @@ int h2mi_profile_filter(const char* prefix);
 int h2mi_profile_reset(void);
 /* total milliseconds and launch count for kernels whose name starts with `prefix`; synchronises */
 int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches);
+/* every recorded launch in order, one text line each: "<kernel> <start ms after the first recorded launch> <duration ms>";
+ * needed_out (may be NULL) receives the buffer size the full text needs; synchronises */
+int h2mi_profile_dump(char* buf, size_t cap, size_t* needed_out);
 
 /* ---- test hooks (elementwise device arithmetic, used by the parity tests only) ------------------- */
 int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,4=inv,5=from_mont,6=to_mont,7=neg,8=dbl*/,
