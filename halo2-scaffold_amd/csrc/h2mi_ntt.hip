@@ -34,20 +34,41 @@ using F9 = Fr29;
 // by at most 2p per stage (< 25p after 10 stages, capacity 2^261 = 169p), so stages need no modular
 // correction at all — one carry normalisation per output.
 
-// out[i] = (base^(2^log_stride))^i, written as canonical Montgomery-2^261 words
-__global__ void __launch_bounds__(256) k_pow_table(fe* out, uint32_t count, fe base, uint32_t log_stride) {
+// out[i] = (base^(2^log_stride))^i for i < count = 2^bits, written as canonical Montgomery-2^261 words.  Per-challenge
+// tables (evaluation points, their inverses) are built on a prover's critical path, so the chain is kept short: the
+// lazy 29-bit-limb layer, log_stride squarings, then square-and-multiply over the `bits` exponent bits that can be set
+// (the 32-bit-limb version walked all 32 bits: 36 us per launch, 28 launches per proof).
+__global__ void __launch_bounds__(256) k_pow_table(fe* out, uint32_t count, fe base, uint32_t log_stride, uint32_t bits) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  fe b = base;
-  for (uint32_t s = 0; s < log_stride; s++) b = fe_sqr<Fr>(b);
-  fe r = fe_one<Fr>();
-  for (int bit = 31; bit >= 0; bit--) {
-    r = fe_sqr<Fr>(r);
-    if ((i >> bit) & 1u) r = fe_mul<Fr>(r, b);
+  f29 b = f29_from_mont256<F9>(base.v);  // Mont261; products of Mont261 values stay Mont261
+  for (uint32_t s = 0; s < log_stride; s++) b = f29_sqr<F9>(b);
+  f29 r = f29_const<F9>(F9::ONE);
+  for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    r = f29_sqr<F9>(r);
+    if ((i >> bit) & 1u) r = f29_mul<F9>(r, b);
   }
   fe o;
-  f29_pack(f29_reduce_canonical<F9>(f29_from_mont256<F9>(r.v)), o.v);
+  f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(r, f29_const<F9>(F9::ONE))), o.v);  // below 2p, then canonical
   fe_store(&out[i], o);
+}
+// lo (i < 2^h) and hi ((base^(2^h))^i, i < 2^(log_n - h)) halves of a two-level table in one launch
+__global__ void __launch_bounds__(256) k_pow_table2(fe* lo, fe* hi, uint32_t h, uint32_t hi_bits, fe base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool is_hi = blockIdx.y != 0;
+  const uint32_t count = 1u << (is_hi ? hi_bits : h);
+  if (i >= count) return;
+  f29 b = f29_from_mont256<F9>(base.v);
+  if (is_hi)
+    for (uint32_t s = 0; s < h; s++) b = f29_sqr<F9>(b);
+  f29 r = f29_const<F9>(F9::ONE);
+  for (int bit = (int)(is_hi ? hi_bits : h) - 1; bit >= 0; bit--) {
+    r = f29_sqr<F9>(r);
+    if ((i >> bit) & 1u) r = f29_mul<F9>(r, b);
+  }
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(r, f29_const<F9>(F9::ONE))), o.v);
+  fe_store(&(is_hi ? hi : lo)[i], o);
 }
 
 struct PassParams {
@@ -888,8 +909,7 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
     return H2MI_ENOMEM;
   }
   fe b = host_fe(base);
-  H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nlo, 256), 256, 0, s, t.lo, nlo, b, 0u);
-  H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(nhi, 256), 256, 0, s, t.hi, nhi, b, t.h);
+  H2_LAUNCH("k_pow_table", k_pow_table2, dim3(ceil_div_u32(std::max(nlo, nhi), 256), 2), 256, 0, s, t.lo, t.hi, t.h, log_n - t.h, b);
   H2_HIP(t.built.mark(s));
   t.last_use = g_epoch;
   g_powtab_bytes += t.bytes;
@@ -949,7 +969,7 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
       return H2MI_ENOMEM;
     }
     // w_loc = omega^(n / 2^m): order 2^m
-    H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m);
+    H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m, m - 1);
   }
   H2_HIP(pl.built.mark(s));
   pl.last_use = g_epoch;
