@@ -591,7 +591,22 @@ static bool g_tmp_used = false;
 // [RECALL], restated in oracle/plonk.py).  On the device: numerators / denominators per row, ONE field inversion
 // for the whole column (prefix and suffix products of the denominators), then a prefix product of the ratios.
 // Multiplicative scans over Fr in tiles of 1024 (local scan, scan of the tile totals, apply), forward or reverse.
+// Everything between the numerator / denominator kernels and the final write lives in the lazy 29-bit-limb layer:
+// the intermediate vectors hold canonical Montgomery-2^261 words, whose products stay in that domain
+// (f29_mul(a 2^261, b 2^261) = a b 2^261); the columns themselves are Montgomery-2^256 and are converted once on the
+// way in (one multiplication) and once on the way out (the mixed-domain product start * R, or a multiplication by 2^-5).
 constexpr uint32_t MS_TILE = 1024;
+__device__ __forceinline__ f29 ld261(const fe* p) { return f29_unpack(fe_load(p).v); }
+__device__ __forceinline__ fe pack261(const f29& a_lt2p) {
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(a_lt2p), o.v);
+  return o;
+}
+__device__ __forceinline__ fe one261() {
+  fe o;
+  f29_pack(f29_const<F9>(F9::ONE), o.v);
+  return o;
+}
 __global__ void __launch_bounds__(256) k_mulscan_local(const fe* in, size_t n, int reverse, fe* local, fe* totals) {
   __shared__ fe tile[MS_TILE];
   __shared__ fe tprod[256];
@@ -599,25 +614,27 @@ __global__ void __launch_bounds__(256) k_mulscan_local(const fe* in, size_t n, i
   const size_t base = (size_t)blockIdx.x * MS_TILE;
   for (uint32_t r = 0; r < 4; r++) {  // logical position j; physical index n-1-j for a suffix scan
     size_t j = base + tid + 256 * r;
-    tile[tid + 256 * r] = j < n ? fe_load(&in[reverse ? n - 1 - j : j]) : fe_one<Fr>();
+    tile[tid + 256 * r] = j < n ? fe_load(&in[reverse ? n - 1 - j : j]) : one261();
   }
   __syncthreads();
-  fe p0 = tile[4 * tid], p1 = fe_mul<Fr>(p0, tile[4 * tid + 1]), p2 = fe_mul<Fr>(p1, tile[4 * tid + 2]), p3 = fe_mul<Fr>(p2, tile[4 * tid + 3]);
-  tprod[tid] = p3;
+  const f29 p0 = f29_unpack(tile[4 * tid].v), p1 = f29_mul<F9>(p0, f29_unpack(tile[4 * tid + 1].v)), p2 = f29_mul<F9>(p1, f29_unpack(tile[4 * tid + 2].v)),
+            p3 = f29_mul<F9>(p2, f29_unpack(tile[4 * tid + 3].v));
+  tprod[tid] = pack261(p3);
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan of the 256 thread products (Hillis-Steele)
-    fe v = fe_one<Fr>();
+    fe v = one261();
     if (tid >= d) v = tprod[tid - d];
     __syncthreads();
-    tprod[tid] = fe_mul<Fr>(tprod[tid], v);
+    if (tid >= d) tprod[tid] = pack261(f29_mul<F9>(f29_unpack(tprod[tid].v), f29_unpack(v.v)));
     __syncthreads();
   }
-  const fe left = tid ? tprod[tid - 1] : fe_one<Fr>();
+  f29 left = f29_const<F9>(F9::ONE);
+  if (tid) left = f29_unpack(tprod[tid - 1].v);
   __syncthreads();
-  tile[4 * tid] = fe_mul<Fr>(left, p0);
-  tile[4 * tid + 1] = fe_mul<Fr>(left, p1);
-  tile[4 * tid + 2] = fe_mul<Fr>(left, p2);
-  tile[4 * tid + 3] = fe_mul<Fr>(left, p3);
+  tile[4 * tid] = pack261(f29_mul<F9>(left, p0));
+  tile[4 * tid + 1] = pack261(f29_mul<F9>(left, p1));
+  tile[4 * tid + 2] = pack261(f29_mul<F9>(left, p2));
+  tile[4 * tid + 3] = pack261(f29_mul<F9>(left, p3));
   __syncthreads();
   for (uint32_t r = 0; r < 4; r++) {
     size_t j = base + tid + 256 * r;
@@ -625,34 +642,37 @@ __global__ void __launch_bounds__(256) k_mulscan_local(const fe* in, size_t n, i
   }
   if (tid == 255) fe_store(&totals[blockIdx.x], tile[MS_TILE - 1]);
 }
-// exclusive scan of the tile totals (single workgroup, chunks of 256 with a running carry)
-__global__ void __launch_bounds__(256) k_mulscan_offsets(const fe* totals, uint32_t nblocks, fe* offsets) {
-  __shared__ fe tprod[256];
+// exclusive scan of the tile totals: ONE workgroup of 1024 threads, each owning a run of consecutive totals (serial
+// product), one Hillis-Steele scan over the 1024 run products, then the runs are walked again.  (Chunks of 256 with a
+// running carry took 110 us for the 3072 totals of a three-column product: twelve dependent rounds of eight steps.)
+__global__ void __launch_bounds__(1024) k_mulscan_offsets(const fe* totals, uint32_t nblocks, fe* offsets) {
+  __shared__ fe tprod[1024];
   const uint32_t tid = threadIdx.x;
-  fe carry = fe_one<Fr>();
-  for (uint32_t c0 = 0; c0 < nblocks; c0 += 256) {
-    const uint32_t b = c0 + tid;
-    const fe mine = b < nblocks ? fe_load(&totals[b]) : fe_one<Fr>();
-    tprod[tid] = mine;
+  const uint32_t per = (nblocks + 1023) / 1024;
+  const uint32_t lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+  f29 run = f29_const<F9>(F9::ONE);
+  for (uint32_t b = lo; b < hi; b++) run = f29_mul<F9>(run, ld261(&totals[b]));
+  tprod[tid] = pack261(run);
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    fe v = one261();
+    if (tid >= d) v = tprod[tid - d];
     __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-      fe v = fe_one<Fr>();
-      if (tid >= d) v = tprod[tid - d];
-      __syncthreads();
-      tprod[tid] = fe_mul<Fr>(tprod[tid], v);
-      __syncthreads();
-    }
-    const fe excl = fe_mul<Fr>(carry, tid ? tprod[tid - 1] : fe_one<Fr>());
-    if (b < nblocks) fe_store(&offsets[b], excl);
-    carry = fe_mul<Fr>(carry, tprod[255]);
+    if (tid >= d) tprod[tid] = pack261(f29_mul<F9>(f29_unpack(tprod[tid].v), f29_unpack(v.v)));
     __syncthreads();
+  }
+  f29 acc = f29_const<F9>(F9::ONE);
+  if (tid) acc = f29_unpack(tprod[tid - 1].v);
+  for (uint32_t b = lo; b < hi; b++) {
+    fe_store(&offsets[b], pack261(f29_mul<F9>(acc, f29_const<F9>(F9::ONE))));
+    acc = f29_mul<F9>(acc, ld261(&totals[b]));
   }
 }
 __global__ void __launch_bounds__(256) k_mulscan_apply(fe* local, const fe* offsets, size_t n, int reverse) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n || j < MS_TILE) return;  // the first tile has offset one
   fe* p = &local[reverse ? n - 1 - j : j];
-  fe_store(p, fe_mul<Fr>(fe_load(p), fe_load(&offsets[j / MS_TILE])));
+  fe_store(p, pack261(f29_mul<F9>(ld261(p), ld261(&offsets[j / MS_TILE]))));
 }
 
 struct PermArgs {
@@ -662,24 +682,30 @@ struct PermArgs {
   fe beta, gamma;
   uint32_t m;
 };
+// factors of one column at one row (Mont261, lazy sums below 6p): v + beta delta^j omega^i + gamma, v + beta sigma + gamma
+__device__ __forceinline__ void perm_factors(const PermArgs& a, uint32_t j, size_t i, const f29& w, f29& numf, f29& denf) {
+  const f29 v = f29_from_mont256<F9>(fe_load(&a.value[j][i]).v);
+  const f29 g = f29_from_mont256<F9>(a.gamma.v);
+  const f29 vg = f29_add(v, g);
+  numf = f29_add(vg, f29_mul<F9>(f29_from_mont256<F9>(a.beta_delta[j].v), w));
+  denf = f29_add(vg, f29_mul<F9>(f29_from_mont256<F9>(a.beta.v), f29_from_mont256<F9>(fe_load(&a.sigma[j][i]).v)));
+}
 // rows i < u: num = prod_j (v_j + beta delta^j omega^i + gamma), den = prod_j (v_j + beta sigma_j + gamma); one beyond
 __global__ void __launch_bounds__(256) k_perm_numden(PermArgs a, size_t n, uint32_t u, const fe* wlo, const fe* whi, uint32_t wh, fe* num, fe* den) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe pn = fe_one<Fr>(), pd = fe_one<Fr>();
+  f29 pn = f29_const<F9>(F9::ONE), pd = pn;
   if (i < u) {
     const f29 w = pow2tab(wlo, whi, wh, (uint32_t)i);  // omega^i (Mont261)
     for (uint32_t j = 0; j < a.m; j++) {
-      const fe v = fe_load(&a.value[j][i]);
-      fe idt;
-      f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_unpack(a.beta_delta[j].v), w)), idt.v);  // beta delta^j omega^i (Mont256)
-      const fe vg = fe_add<Fr>(v, a.gamma);
-      pn = fe_mul<Fr>(pn, fe_add<Fr>(vg, idt));
-      pd = fe_mul<Fr>(pd, fe_add<Fr>(vg, fe_mul<Fr>(a.beta, fe_load(&a.sigma[j][i]))));
+      f29 nf, df;
+      perm_factors(a, j, i, w, nf, df);
+      pn = f29_mul<F9>(nf, pn);
+      pd = f29_mul<F9>(df, pd);
     }
   }
-  fe_store(&num[i], pn);
-  fe_store(&den[i], pd);
+  fe_store(&num[i], pack261(pn));
+  fe_store(&den[i], pack261(pd));
 }
 // the same for every set of a permutation argument at once: t = set * u + i over the concatenated usable rows
 // (set = chunk of `chunk` consecutive columns); the running product then chains the sets by itself
@@ -689,17 +715,15 @@ __global__ void __launch_bounds__(256) k_perm_numden_sets(PermArgs a, uint32_t c
   if (t >= total) return;
   const uint32_t set = (uint32_t)(t / u), i = (uint32_t)(t - (size_t)set * u);
   const f29 w = pow2tab(wlo, whi, wh, i);  // omega^i (Mont261)
-  fe pn = fe_one<Fr>(), pd = fe_one<Fr>();
+  f29 pn = f29_const<F9>(F9::ONE), pd = pn;
   for (uint32_t j = set * chunk; j < a.m && j < (set + 1) * chunk; j++) {
-    const fe v = fe_load(&a.value[j][i]);
-    fe idt;
-    f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_unpack(a.beta_delta[j].v), w)), idt.v);  // beta delta^j omega^i (Mont256)
-    const fe vg = fe_add<Fr>(v, a.gamma);
-    pn = fe_mul<Fr>(pn, fe_add<Fr>(vg, idt));
-    pd = fe_mul<Fr>(pd, fe_add<Fr>(vg, fe_mul<Fr>(a.beta, fe_load(&a.sigma[j][i]))));
+    f29 nf, df;
+    perm_factors(a, j, i, w, nf, df);
+    pn = f29_mul<F9>(nf, pn);
+    pd = f29_mul<F9>(df, pd);
   }
-  fe_store(&num[t], pn);
-  fe_store(&den[t], pd);
+  fe_store(&num[t], pack261(pn));
+  fe_store(&den[t], pack261(pd));
 }
 struct ZOut {
   fe* z[8];
@@ -709,7 +733,9 @@ __global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, set = blockIdx.y;
   if (i > u) return;
   const size_t t = (size_t)set * u + i;
-  fe_store(&out.z[set][i], t ? fe_load(&R[t - 1]) : fe_one<Fr>());
+  fe o = fe_one<Fr>();
+  if (t) f29_to_mont256<F9>(ld261(&R[t - 1]), o.v);
+  fe_store(&out.z[set][i], o);
 }
 // lookup argument's grand product (plonk/lookup/prover.rs commit_product), single-expression lookups:
 // num_i = (a_i + beta)(t_i + gamma), den_i = (a'_i + beta)(s'_i + gamma), i < u
@@ -717,8 +743,11 @@ __global__ void __launch_bounds__(256) k_lookup_numden(const fe* input, const fe
                                                         fe* num, fe* den) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= u) return;
-  fe_store(&num[i], fe_mul<Fr>(fe_add<Fr>(fe_load(&input[i]), beta), fe_add<Fr>(fe_load(&table[i]), gamma)));
-  fe_store(&den[i], fe_mul<Fr>(fe_add<Fr>(fe_load(&pin[i]), beta), fe_add<Fr>(fe_load(&ptab[i]), gamma)));
+  const f29 b = f29_from_mont256<F9>(beta.v), g = f29_from_mont256<F9>(gamma.v);
+  auto lift = [](const fe* p) { return f29_from_mont256<F9>(fe_load(p).v); };
+  // the second operand of a product must be normalized: sums of two values below 2p are carried first
+  fe_store(&num[i], pack261(f29_mul<F9>(f29_add(lift(&input[i]), b), f29_normalize(f29_add(lift(&table[i]), g)))));
+  fe_store(&den[i], pack261(f29_mul<F9>(f29_add(lift(&pin[i]), b), f29_normalize(f29_add(lift(&ptab[i]), g)))));
 }
 
 // ---- quotient numerator of the range-check constraint system (BASELINE config 3) -------------------
@@ -791,24 +820,32 @@ __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_
   fe_store(&out[idx], v);
 }
 
+// the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
+// as a Montgomery-2^256 value is (32 x) 2^256; its inverse (x^-1 / 32) 2^256 times 2^10 is x^-1 2^261.
 __global__ void k_fr_inv_one(const fe* in, fe* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(out, fe_inv_gcd<Fr>(fe_load(in)));  // one inversion on the critical path
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  fe r = fe_inv_gcd<Fr>(fe_load(in));
+  for (int i = 0; i < 10; i++) r = fe_dbl<Fr>(r);
+  fe_store(out, r);
 }
 // ratio_i = num_i / den_i = num_i * P_(i-1) * S_(i+1) / P_(n-1)   (P, S: prefix / suffix products of den)
 __global__ void __launch_bounds__(256) k_perm_ratio(const fe* num, const fe* P, const fe* S, const fe* inv_total, size_t n, fe* ratio) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe r = fe_mul<Fr>(fe_load(&num[i]), fe_load(inv_total));
-  if (i) r = fe_mul<Fr>(r, fe_load(&P[i - 1]));
-  if (i + 1 < n) r = fe_mul<Fr>(r, fe_load(&S[i + 1]));
-  fe_store(&ratio[i], r);
+  f29 r = f29_mul<F9>(ld261(&num[i]), ld261(inv_total));
+  if (i) r = f29_mul<F9>(r, ld261(&P[i - 1]));
+  if (i + 1 < n) r = f29_mul<F9>(r, ld261(&S[i + 1]));
+  fe_store(&ratio[i], pack261(r));
 }
 // z[0] = start, z[i+1] = start * R_i for i < u (R: inclusive prefix products of the ratios); rows beyond u untouched
 __global__ void __launch_bounds__(256) k_perm_write(const fe* R, const fe* start_or_null, uint32_t u, fe* z, fe* last_or_null) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > u) return;
   const fe st = start_or_null ? fe_load(start_or_null) : fe_one<Fr>();
-  const fe v = i ? fe_mul<Fr>(st, fe_load(&R[i - 1])) : st;
+  fe v = st;
+  if (i) {  // mixed-domain product: (start 2^256) (R 2^261) / 2^261 = start R 2^256
+    f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_unpack(st.v), ld261(&R[i - 1]))), v.v);
+  }
   fe_store(&z[i], v);
   if (i == u && last_or_null) fe_store(last_or_null, v);
 }
@@ -1312,7 +1349,7 @@ static int mulscan(fe* data, size_t n, int reverse, fe* totals, fe* offsets, hip
   const uint32_t nblocks = ceil_div_u32(n, MS_TILE);
   H2_LAUNCH("k_mulscan_local", k_mulscan_local, nblocks, 256, 0, s, (const fe*)data, n, reverse, data, totals);
   if (nblocks > 1) {
-    H2_LAUNCH("k_mulscan_offsets", k_mulscan_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
+    H2_LAUNCH("k_mulscan_offsets", k_mulscan_offsets, 1, 1024, 0, s, (const fe*)totals, nblocks, offsets);
     H2_LAUNCH("k_mulscan_apply", k_mulscan_apply, ceil_div_u32(n, 256), 256, 0, s, data, (const fe*)offsets, n, reverse);
   }
   return H2MI_OK;
