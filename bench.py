@@ -165,8 +165,8 @@ def main():
     # Blake2b-derived challenges, device permutation products / evaluate_h / openings / SHPLONK).  Host-inclusive:
     # the transcript and the control flow run on the host between device phases, as they do in the reference.
     create_proof_stats = None
-    if world == 1 and dist is None and shape.name == "standard_plonk" and not args.no_create_proof:
-        create_proof_stats = time_create_proof(h2, R, args)
+    if shape.name == "standard_plonk" and not args.no_create_proof:
+        create_proof_stats = time_create_proof(h2, R, args, dist, backend, torch.device("cuda", local_rank), coll_dev)
 
     if rank != 0:
         if dist is not None:
@@ -280,37 +280,67 @@ def main():
         dist.destroy_process_group()
 
 
-def time_create_proof(h2, R, args):
+def time_create_proof(h2, R, args, dist, backend, torch_device, coll_dev):
     """keygen once, then `steps` proofs of the reference's circuit (examples/standard_plonk.rs:33-50) through one
-    workspace; every proof uses a fresh witness and rng seed.  Wall-clock around create_proof(), proof bytes out."""
+    workspace; every proof uses a fresh witness and rng seed.  Wall-clock around create_proof(), proof bytes out.
+    N > 1 (one process per GPU): every rank runs the prover; each commitment is the rank's slice MSM and the partial
+    points are combined at every transcript join (RCCL all-gather + device fold), so all ranks draw the same challenges
+    and hold the same proof; transforms, quotient and openings are replicated (NTT is single-GPU by design)."""
     import hashlib
 
+    import torch
+
     from halo2_scaffold_amd import circuits, keygen, prover
+    from halo2_scaffold_amd.params import ParamsKZG
 
     lib = h2.lib
     circuit = circuits.StandardPlonk(None)
+    combiner = None
+    params = R.params
     t0 = time.perf_counter()
-    vk = keygen.keygen_vk(R.params, circuit)
-    pk = keygen.keygen_pk(R.params, vk, circuit)
+    if dist is not None:  # keygen against the whole SRS (the vk must be the full commitments), then commit by slice
+        from halo2_scaffold_amd.dist import PhaseCombiner
+
+        full = ParamsKZG.setup(args.k, 0x5EC2E7 + 0x48324D49)
+        vk = keygen.keygen_vk(full, circuit)
+        pk = keygen.keygen_pk(full, vk, circuit)
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        full.release()
+        combiner = PhaseCombiner(4, backend, torch_device)
+    else:
+        vk = keygen.keygen_vk(params, circuit)
+        pk = keygen.keygen_pk(params, vk, circuit)
     h2._lib.check(lib.h2mi_sync(), "sync")
     keygen_s = time.perf_counter() - t0
-    ws = prover.ProverWorkspace(R.params, pk)
+    ws = prover.ProverWorkspace(params, pk, combiner=combiner)
+
+    def barrier():
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
     proof = b""
     for i in range(max(args.warmup, 1)):
-        proof = prover.create_proof(R.params, pk, circuits.StandardPlonk(0x1234 + i), 1000 + i, ws=ws)
-    h2._lib.check(lib.h2mi_sync(), "sync")
+        proof = prover.create_proof(params, pk, circuits.StandardPlonk(0x1234 + i), 1000 + i, ws=ws)
+    barrier()
     times = []
     for i in range(args.steps):
         t0 = time.perf_counter()
-        proof = prover.create_proof(R.params, pk, circuits.StandardPlonk(0xABCDEF + i), 2000 + i, ws=ws)
+        proof = prover.create_proof(params, pk, circuits.StandardPlonk(0xABCDEF + i), 2000 + i, ws=ws)
         times.append(time.perf_counter() - t0)
+    barrier()
+    if dist is not None:  # the slowest rank's mean
+        t = torch.tensor([sum(times) / len(times)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = [float(t.item())] * len(times)
     # device-only share of one proof (all kernels bracketed by events; untimed extra pass)
     import ctypes as C
 
     lib.h2mi_profile_reset()
     lib.h2mi_profile_filter(b"")
     lib.h2mi_profile_enable(1)
-    prover.create_proof(R.params, pk, circuits.StandardPlonk(7), 7, ws=ws)
+    prover.create_proof(params, pk, circuits.StandardPlonk(7), 7, ws=ws)
     lib.h2mi_profile_enable(0)
     tot, cnt = C.c_double(), C.c_uint64()
     lib.h2mi_profile_query(b"", C.byref(tot), C.byref(cnt))
@@ -322,15 +352,18 @@ def time_create_proof(h2, R, args):
         kernels[name] = {"ms": round(t_.value, 4), "launches": c_.value}
     lib.h2mi_profile_reset()
     tr = {}
-    prover.create_proof(R.params, pk, circuits.StandardPlonk(8), 8, ws=ws, trace=tr)  # host-side phase boundaries (each ends in a device sync)
+    prover.create_proof(params, pk, circuits.StandardPlonk(8), 8, ws=ws, trace=tr)  # host-side phase boundaries (each ends in a device sync)
     phase_ms = tr.get("phase_ms")
     ws.release()
     pk.release()
+    if combiner is not None:
+        combiner.release()
     times.sort()
     return {
         "ms_per_proof": round(sum(times) / len(times) * 1e3, 3),
         "min_ms": round(times[0] * 1e3, 3),
         "proofs": len(times),
+        "combines_per_proof": 6 if combiner is not None else 0,
         "proof_bytes": len(proof),
         "last_proof_sha256": hashlib.sha256(proof).hexdigest(),
         "keygen_vk_pk_seconds": round(keygen_s, 3),

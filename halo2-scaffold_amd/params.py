@@ -26,6 +26,7 @@ class ParamsKZG:
         self.g_lagrange_handle = None
         self._g_dev = None
         self._gl_dev = None
+        self.lo = 0             # first base of the slice this object commits against (multi-GPU: register_slice)
         self.g2_bytes = None    # the verifier's two G2 elements, carried as their 64-byte encodings
         self.s_g2_bytes = None
 
@@ -60,6 +61,7 @@ class ParamsKZG:
         assert 0 <= lo < hi <= self.n and self._gl_dev is not None
         p = ParamsKZG(self.k)
         p.n = hi - lo
+        p.lo = lo
         p.g2_bytes, p.s_g2_bytes = self.g2_bytes, self.s_g2_bytes
         h = C.c_uint64()
         check(lib.h2mi_bases_register_dev(self._g_dev.ptr + lo * 64, p.n, C.byref(h)), "register g slice")

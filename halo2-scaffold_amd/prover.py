@@ -39,7 +39,10 @@ class ProverWorkspace:
     """device buffers of one prover, reused from proof to proof (the reference's examples prove repeatedly against
     one pk: examples/linear_regression.rs:178-185)"""
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey):
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, combiner=None):
+        """combiner: a dist.PhaseCombiner with >= 4 slots when `params` is one rank's slice of the SRS (one process per
+        GPU): every commitment is then this rank's partial point, combined across ranks at the phase's join"""
+        self.combiner = combiner
         d = pk.vk.domain
         n, ext = d.n, d.extended_len()
         na = pk.circuit.N_ADVICE
@@ -55,7 +58,7 @@ class ProverWorkspace:
         self.h_poly = DevBuf(n * 32)
         self.points = DevBuf(96 * 4)     # Jacobian results of the commitments of one phase
         self.evals = DevBuf(32 * 32)
-        self.shplonk = ProverSHPLONK(params)
+        self.shplonk = ProverSHPLONK(n)
 
     def release(self):
         for b in (self.advice + self.advice_polys + self.advice_cosets + self.z + self.z_polys + self.z_cosets +
@@ -72,7 +75,12 @@ def _write_phase_points(ws: ProverWorkspace, transcript, k: int):
     """fetch the k Jacobian results of a phase (the copy joins the MSM pipeline), normalise them on the host as
     G1::batch_normalize does (one modular inversion each is microseconds here; a lone device thread takes 0.3 ms)
     and write them to the transcript"""
-    jac = ws.points.to_numpy(shape=(4, 12), nbytes=96 * 4)[:k]
+    if ws.combiner is not None:  # sliced SRS: all-gather + fold of the phase's partial points, then the same on every rank
+        check(lib.h2mi_join(), "join")
+        ws.combiner.combine(0, k)
+        jac = ws.combiner.combined.to_numpy(shape=(ws.combiner.slots, 12))[:k]
+    else:
+        jac = ws.points.to_numpy(shape=(4, 12), nbytes=96 * 4)[:k]
     for row in jac:
         X, Y, Z = (sum(int(row[4 * c + i]) << (64 * i) for i in range(4)) * _RINV_Q % _Q for c in range(3))
         if Z == 0:
@@ -86,9 +94,15 @@ def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, l
     """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join) and write the
     points to the transcript"""
     for i, (buf, offset_elems) in enumerate(columns):
-        h = params.g_lagrange_handle if lagrange else params.g_handle
-        check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + offset_elems * 32, params.n, ws.points.ptr + 96 * i, None), "commit")
+        _commit(params, ws, buf, offset_elems, lagrange, i)
     _write_phase_points(ws, transcript, len(columns))
+
+
+def _commit(params: ParamsKZG, ws: ProverWorkspace, buf: DevBuf, offset_elems: int, lagrange: bool, slot: int):
+    """queue one commitment into result slot `slot` of the phase: the whole column, or this rank's slice of it"""
+    h = params.g_lagrange_handle if lagrange else params.g_handle
+    out = (ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr) + 96 * slot
+    check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + (offset_elems + params.lo) * 32, params.n, out, None), "commit")
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcript: Blake2bWrite = None, ws: ProverWorkspace = None,
@@ -137,8 +151,8 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     # ---- vanishing argument: random polynomial (n coefficients from the prover's rng) ------------------------------
     check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
     for i, z in enumerate(ws.z):
-        check(lib.h2mi_msm_bn254_g1_dev(params.g_lagrange_handle, z.ptr, n, ws.points.ptr + 96 * i, None), "commit z")
-    check(lib.h2mi_msm_bn254_g1_dev(params.g_handle, ws.random_poly.ptr, n, ws.points.ptr + 96 * len(ws.z), None), "commit random")
+        _commit(params, ws, z, 0, True, i)
+    _commit(params, ws, ws.random_poly, 0, False, len(ws.z))
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
     # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products
     for col, p, e in list(zip(ws.advice, ws.advice_polys, ws.advice_cosets)) + list(zip(ws.z, ws.z_polys, ws.z_cosets)):

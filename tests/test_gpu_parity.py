@@ -859,6 +859,9 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     assert two["commitments_sha256"] == one["commitments_sha256"]
     # the partial points are combined at every transcript join (five per StandardPlonk proof), not once per proof
     assert two["config"]["combines_per_step"] == 5 and one["config"]["combines_per_step"] == 0
+    # the data-true prover over the sliced SRS: every rank holds the same 992-byte proof as the single-GPU prover
+    assert two["create_proof"]["last_proof_sha256"] == one["create_proof"]["last_proof_sha256"]
+    assert two["create_proof"]["combines_per_proof"] == 6 and two["create_proof"]["proof_bytes"] == 992
     # four ranks (slices of a quarter, leaf transforms spread over four owners): 4 + this process stay below the
     # box's limit of 6 GPU processes
     with socket.socket() as s:
@@ -870,6 +873,7 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     assert r4.returncode == 0, r4.stdout[-1000:] + r4.stderr[-2000:]
     four = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
     assert four["n_gpus"] == 4 and four["commitments_sha256"] == one["commitments_sha256"] and four["config"]["combines_per_step"] == 5
+    assert four["create_proof"]["last_proof_sha256"] == one["create_proof"]["last_proof_sha256"]
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert key in two and key in one
     # the same code path over RCCL ("nccl" backend) with a single rank: process group on the GPU, device
@@ -883,6 +887,7 @@ def test_bench_world2_rehearsal_matches_single_gpu(gpu):
     rccl = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
     assert rccl["commitments_sha256"] == one["commitments_sha256"] and rccl["n_gpus"] == 1
     assert rccl["config"]["combines_per_step"] == 5 and "device-resident" in rccl["config"]["combine"]
+    assert rccl["create_proof"]["last_proof_sha256"] == one["create_proof"]["last_proof_sha256"]
 
 
 def test_eip196_vectors_hip_path(gpu):
