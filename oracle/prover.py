@@ -8,9 +8,10 @@ verifier}.rs, plonk/permutation/*, plonk/vanishing/*, poly/kzg/multiopen/shplonk
 poly/kzg/multiopen/shplonk.rs `construct_intermediate_sets`); the crate is not available here and the reference
 holds no proof bytes.  What pins it instead: `verify_proof` below accepts exactly the proofs whose openings are
 consistent — it re-derives every challenge from the proof bytes, recomputes the gate / permutation expressions
-from the claimed evaluations, and checks the final KZG equation.  The pairing check e(L, [s]G2) = e(Rt, G2) is
-replaced by its G1 form s * L == Rt, which the oracle can evaluate because it knows the toxic-waste scalar s of
-the synthetic SRS (bench and tests generate the SRS from a seed; the reference uses `ParamsKZG::setup(k, OsRng)`).
+from the claimed evaluations, and checks the final KZG equation either as the reference's verifier does, with the
+pairing e(L, [s]G2) = e(Rt, G2) over the SRS's two G2 elements (oracle/pairing.py; no secret involved), or in its G1
+form s * L == Rt with the toxic-waste scalar of the synthetic SRS (cheap; bench and tests generate the SRS from a
+seed; the reference uses `ParamsKZG::setup(k, OsRng)`).
 
 Two deliberate stand-ins, both documented where they are used:
   * rng: the reference passes OsRng (examples/standard_plonk.rs:48), so its bytes are not reproducible; here every
@@ -126,7 +127,8 @@ class VerifierKey:
     commitment is sum_cells v L_row(s) G; sigma_j is the identity image DELTA^j omega^i — the evaluations of the
     polynomial DELTA^j X, whose commitment is DELTA^j s G — patched at the cells of the copy cycle."""
 
-    def __init__(self, k: int, s: int, fixed_commitments, permutation_commitments):
+    def __init__(self, k: int, s, fixed_commitments, permutation_commitments):
+        """s may be None when verify_proof is given the SRS's G2 elements (pairing check)"""
         self.k, self.n, self.s = k, 1 << k, s
         self.dom = o.Domain(k, P.CS_DEGREE)
         self.fixed_commitments = list(fixed_commitments)
@@ -378,9 +380,11 @@ class ProofReader:
         return self.tr.squeeze_challenge()
 
 
-def verify_proof(pk, proof: bytes) -> bool:
-    """plonk/verifier.rs verify_proof + VerifierSHPLONK, with the final pairing check done in G1 through the known s.
-    `pk`: a ProvingKey or a VerifierKey — only k, the domain, the commitments, transcript_repr and s are used."""
+def verify_proof(pk, proof: bytes, g2=None, s_g2=None) -> bool:
+    """plonk/verifier.rs verify_proof + VerifierSHPLONK.  `pk`: a ProvingKey or a VerifierKey — only k, the domain, the
+    commitments and transcript_repr are used, plus ONE of: the SRS's two G2 elements (g2, s_g2: affine points over Fq2)
+    for the real final check e(h2, [s]G2) = e(outer, G2) (oracle/pairing.py; what the reference's verifier does with
+    `params.verifier_params()`), or, when they are not given, pk.s for the same equation in G1 (s * h2 == outer)."""
     dom, n = pk.dom, pk.n
     try:
         rd = ProofReader(proof)
@@ -489,4 +493,10 @@ def verify_proof(pk, proof: bytes) -> bool:
     outer = o.g1_add(outer, o.g1_mul((-z_0) % R, h1))
     outer = o.g1_add(outer, o.g1_mul(u, h2))
     # e(h2, [s]G2) == e(outer, G2)  <=>  s * h2 == outer
+    if g2 is not None and s_g2 is not None:
+        from . import pairing
+
+        if outer is None:
+            return h2 is None
+        return pairing.pairing_product_is_one([(h2, s_g2), (o.g1_neg(outer), g2)])
     return o.g1_mul(pk.s, h2) == outer

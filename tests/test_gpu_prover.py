@@ -149,6 +149,14 @@ def test_create_proof_full_size_verifies_and_quotient_identity(gpu, k):
     trace = {}
     proof = prover.create_proof(params, pk, circuits.StandardPlonk(xw), seed, trace=trace)
     assert OP.verify_proof(cf, proof)
+    # ... and as the reference's verifier finishes: the pairing check over the SRS's two G2 elements, no secret involved
+    # (the product's ParamsKZG carries exactly these two elements in its SRS file form)
+    from oracle import formats as fm
+
+    g2, s_g2 = fm.G2_GEN, fm.g2_mul(SRS_SECRET)
+    assert params.g2_bytes == fm.g2_to_bytes(g2) and params.s_g2_bytes == fm.g2_to_bytes(s_g2)
+    no_secret = OP.VerifierKey(k, None, o.unpack_points(vk.fixed_commitments), o.unpack_points(vk.permutation_commitments))
+    assert OP.verify_proof(no_secret, proof, g2=g2, s_g2=s_g2)
     bad = bytearray(proof)
     bad[32 * 10 + 3] ^= 1  # an opened evaluation
     assert not OP.verify_proof(cf, bytes(bad))

@@ -119,3 +119,30 @@ def test_lookup_oracle_quotient_identity_and_rejection():
     h2 = t.divide_by_vanishing(t.evaluate_h(zs2, ap2, sp2, zl2, beta, gamma, y))
     hc2 = t.dom.extended_to_coeff(h2)
     assert not L.check_quotient_identity(t, zs2, ap2, sp2, zl2, hc2, beta, gamma, y, 7)
+
+
+def test_pairing_oracle_is_bilinear_and_verifier_needs_no_secret():
+    """oracle/pairing.py: non-degenerate, of order r, bilinear in both arguments (no wrong twist, line function or final
+    exponent survives that); then verify_proof with the SRS's two G2 elements — the reference's actual check,
+    e(h2, [s]G2) = e(outer, G2) — agrees with the known-s form on a good proof and on tampered ones."""
+    from oracle import formats as fm
+    from oracle import pairing as PA
+
+    G = o.G1_GEN
+    e1 = PA.pairing(fm.G2_GEN, G)
+    assert not (e1 == PA.F12.one()) and e1 ** o.R == PA.F12.one()
+    assert PA.pairing(fm.G2_GEN, o.g1_mul(5, G)) == e1 ** 5
+    assert PA.pairing(fm.g2_mul(7), G) == e1 ** 7
+    assert PA.pairing(fm.g2_mul(3), o.g1_mul(11, G)) == e1 ** 33
+    assert PA.pairing(fm.G2_GEN, None) == PA.F12.one()
+    k = 4
+    pk = OP.ProvingKey(k, SRS_SECRET)
+    proof = OP.create_proof(pk, 424242, 5)["proof"]
+    g2, s_g2 = fm.G2_GEN, fm.g2_mul(SRS_SECRET)
+    vk = OP.VerifierKey(k, None, pk.fixed_commitments, pk.permutation_commitments)  # no secret
+    assert OP.verify_proof(vk, proof, g2=g2, s_g2=s_g2)
+    for pos in (5, 32 * 9 + 2, len(proof) - 3):
+        bad = bytearray(proof)
+        bad[pos] ^= 0x10
+        assert not OP.verify_proof(vk, bytes(bad), g2=g2, s_g2=s_g2), pos
+    assert not OP.verify_proof(vk, proof, g2=g2, s_g2=fm.g2_mul(SRS_SECRET + 1))  # another SRS
