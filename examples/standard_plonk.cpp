@@ -1,19 +1,18 @@
-// C++ counterpart of the reference's examples/standard_plonk.rs (lines 25-65) over include/h2mi.hpp:
-// same flow — setup the SRS for 2^k rows, "keygen" (commit the fixed / permutation columns and bring them
-// to coefficient and extended form), then "Creating proof": the commitments and transforms create_proof
-// issues for the StandardPlonk circuit (reference src/circuits/standard_plonk.rs:29-112), timed like the
-// reference's ark-std spans.  The advice columns are the circuit's real witness (x, x, x^2 / x, x, x^2+72 in
-// rows 1-2, zeros elsewhere, random blinding rows at the end); permutation products, the random polynomial
-// and h(X) are synthetic dense vectors, because gate evaluation and the transcript are out of scope
-// (DESIGN.md).  It is NOT a prover: instead of verify_proof it self-checks the KZG identity
-// commit(f; g) == commit_lagrange(NTT f; g_lagrange) and f(s)*G on every run.
+// C++ counterpart of the reference's examples/standard_plonk.rs (lines 25-65) over include/h2mi.hpp + h2mi_plonk.hpp:
+// the same flow with the same names —
+//     ParamsKZG::setup(k, ..); keygen_vk; keygen_pk; "Creating proof": Blake2bWrite::init, create_proof, finalize
+// — on the reference's StandardPlonk circuit (src/circuits/standard_plonk.rs), data-true: real witness and copy
+// constraints, challenges from the Blake2b transcript, 992 proof bytes.  Spans are timed like the reference's ark-std
+// timers.  The reference then calls verify_proof; no verifier is part of the product (it is not on the hot path): the
+// proof bytes printed here are checked by the test-suite against the oracle prover / verifier and the golden proofs.
 //
-// Usage: standard_plonk [k]      (the reference hard-codes k = 5)
+// Usage: standard_plonk [k [srs_secret_hex [witness_hex [seed]]]]     (the reference hard-codes k = 5 and draws the rest
+//        from OsRng; here they are arguments so that runs are comparable)
 #include <chrono>
 #include <cstdio>
-#include <random>
+#include <string>
 
-#include "../include/h2mi.hpp"
+#include "../include/h2mi_plonk.hpp"
 
 using namespace h2mi;
 using Clock = std::chrono::steady_clock;
@@ -28,131 +27,55 @@ struct Timer {
   }
 };
 
-static Fr random_fr(std::mt19937_64& rng) {  // uniform Montgomery representative = uniform field element
-  for (;;) {
-    Fr a = {{rng(), rng(), rng(), rng() & 0x3fffffffffffffffULL}};
-    for (int i = 3; i >= 0; i--) {
-      if (a.l[i] < fr::MODULUS[i]) return a;
-      if (a.l[i] > fr::MODULUS[i]) break;
-    }
-  }
+static Fr fr_from_hex(std::string h) {  // canonical integer (< 2^256, reduced mod r by the Montgomery conversions) -> Fr
+  if (h.rfind("0x", 0) == 0) h = h.substr(2);
+  while (h.size() < 64) h = "0" + h;
+  if (h.size() > 64) h = h.substr(h.size() - 64);
+  Fr raw;
+  for (int i = 0; i < 4; i++) raw.l[i] = std::stoull(h.substr(64 - 16 * (i + 1), 16), nullptr, 16);
+  // raw may exceed r: (raw R^-1) * R^2 * ... two Montgomery products bring it to raw * R mod r
+  return fr::mul(raw, fr::R2);
 }
-static std::vector<Fr> random_vec(size_t n, std::mt19937_64& rng) {
-  std::vector<Fr> v(n);
-  for (auto& x : v) x = random_fr(rng);
-  return v;
+static std::string hex(const std::vector<uint8_t>& b) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t c : b) {
+    s.push_back(d[c >> 4]);
+    s.push_back(d[c & 15]);
+  }
+  return s;
 }
 
 int main(int argc, char** argv) {
   const uint32_t k = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 5;  // `let k = 5;`
-  const size_t n = (size_t)1 << k;
-  const uint32_t cs_degree = 3, blinding_rows = 5;
+  const Fr s = fr_from_hex(argc > 2 ? argv[2] : "5ec2e7");
+  const Fr x = fr_from_hex(argc > 3 ? argv[3] : "c0ffee");
+  const uint64_t seed = argc > 4 ? std::stoull(argv[4]) : 11;
   try {
     init();
-    std::mt19937_64 rng(0x48324D49);  // the reference uses OsRng everywhere; a seed makes runs comparable
-    const Fr zero = {{0, 0, 0, 0}};
-
     // let params = ParamsKZG::<Bn256>::setup(k, OsRng);
-    const Fr s = random_fr(rng);
     auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
-    poly::EvaluationDomain domain(cs_degree, k);
-
-    // keygen_vk / keygen_pk: 5 fixed columns (q_a, q_b, q_c, q_ab, constant) + 3 permutation sigmas
-    std::vector<std::vector<Fr>> fixed(5, std::vector<Fr>(n, zero));
-    const Fr one = fr::ONE, minus_one = fr::neg(fr::ONE);
-    if (n > 2) {
-      fixed[2][1] = minus_one; fixed[3][1] = one;                                   // row 1: q_c = -1, q_ab = 1
-      fixed[2][2] = minus_one; fixed[3][2] = one; fixed[4][2] = fr::from_u64(72);  // row 2: + constant 72
+    // let circuit = StandardPlonk { x: Value::unknown() }; keygen_vk; keygen_pk
+    plonk::StandardPlonk keygen_circuit;
+    plonk::VerifyingKey vk = [&] { Timer t("Generating verifying key"); return plonk::keygen_vk(params, keygen_circuit); }();
+    auto pk = [&] { Timer t("Generating proving key"); return plonk::keygen_pk(params, vk, keygen_circuit); }();
+    // let circuit = StandardPlonk { x: Value::known(..) };
+    plonk::StandardPlonk circuit(x);
+    std::vector<uint8_t> proof;
+    plonk::ProverWorkspace ws(params, *pk);  // the prover's device buffers, kept across proofs
+    for (int run = 0; run < 3; run++) {  // later runs show the steady state (tables and plans are cached)
+      Timer t(run ? "Creating proof" : "Creating proof (first call: builds the domain's tables)");
+      auto transcript = transcript::Blake2bWrite::init();
+      plonk::create_proof(params, *pk, circuit, seed, transcript, &ws);
+      proof = transcript.finalize();
     }
-    std::vector<std::vector<Fr>> sigma(3);
-    for (auto& sg : sigma) sg = random_vec(n, rng);
-    std::vector<G1> vk_commitments;
-    {
-      Timer t("Generating verifying key");
-      for (auto& c : fixed) vk_commitments.push_back(params.commit_lagrange(c));
-      for (auto& c : sigma) vk_commitments.push_back(params.commit_lagrange(c));
-    }
-    {
-      Timer t("Generating proving key");
-      for (auto& c : fixed) (void)domain.coeff_to_extended(domain.lagrange_to_coeff(c));
-      for (auto& c : sigma) (void)domain.coeff_to_extended(domain.lagrange_to_coeff(c));
-    }
-
-    // the witness of StandardPlonk { x }: a, b, c columns
-    const Fr x = random_fr(rng);
-    std::vector<std::vector<Fr>> advice(3, std::vector<Fr>(n, zero));
-    if (n > 2) {
-      const Fr xx = fr::mul(x, x);
-      const Fr xx72 = fr::add(xx, fr::from_u64(72));
-      advice[0][0] = x;
-      advice[0][1] = x; advice[1][1] = x; advice[2][1] = xx;
-      advice[0][2] = x; advice[1][2] = x; advice[2][2] = xx72;
-    }
-    for (auto& col : advice)  // blinding factors in the last rows (create_proof step 2)
-      for (size_t r = n > blinding_rows ? n - blinding_rows : 0; r < n; r++) col[r] = random_fr(rng);
-
-    std::vector<G1> proof_points;
-    {
-      Timer t("Creating proof");
-      // advice commitments
-      for (auto& col : advice) proof_points.push_back(params.commit_lagrange(col));
-      // permutation products: commit, to coefficients, to the extended domain
-      std::vector<std::vector<Fr>> zs(3);
-      for (auto& z : zs) {
-        z = random_vec(n, rng);
-        proof_points.push_back(params.commit_lagrange(z));
-        (void)domain.coeff_to_extended(domain.lagrange_to_coeff(z));
-      }
-      // vanishing argument: random polynomial
-      proof_points.push_back(params.commit(random_vec(n, rng)));
-      // advice to coefficient / extended form
-      std::vector<std::vector<Fr>> advice_coeff;
-      for (auto& col : advice) {
-        advice_coeff.push_back(domain.lagrange_to_coeff(col));
-        (void)domain.coeff_to_extended(advice_coeff.back());
-      }
-      // h(X): extended -> coefficients, (degree - 1) pieces
-      std::vector<Fr> h = domain.extended_to_coeff(random_vec(domain.extended_len(), rng));
-      for (uint32_t piece = 0; piece < cs_degree - 1; piece++)
-        proof_points.push_back(params.commit(std::vector<Fr>(h.begin() + piece * n, h.begin() + (piece + 1) * n)));
-      // evaluations at the challenge x and the two SHPLONK commitments
-      const Fr xc = random_fr(rng);
-      std::vector<Fr> evals;
-      for (auto& c : advice_coeff) evals.push_back(arithmetic::eval_polynomial(c, xc));
-      proof_points.push_back(params.commit(advice_coeff[0]));
-      std::vector<Fr> q = arithmetic::kate_division(advice_coeff[0], xc);
-      proof_points.push_back(params.commit(q));
-      // (X - xc) q(X) + f(xc) == f(X): spot-check at a second point
-      const Fr zc = random_fr(rng);
-      Fr lhs = fr::add(fr::mul(fr::sub(zc, xc), arithmetic::eval_polynomial(q, zc)), evals[0]);
-      if (!(lhs == arithmetic::eval_polynomial(advice_coeff[0], zc))) {
-        std::printf("kate_division self-check FAILED\n");
-        return 1;
-      }
-    }
-    std::printf("proof replay: %zu commitments\n", proof_points.size());
-
-    // self-check instead of verify_proof: commit(f; g) == commit_lagrange(NTT f; g_lagrange) == f(s) G
-    {
-      Timer t("verify");
-      std::vector<Fr> f = random_vec(n, rng);
-      G1 c1 = params.commit(f), c2 = params.commit_lagrange(domain.coeff_to_lagrange(f));
-      Fr fs = arithmetic::eval_polynomial(f, s);
-      std::vector<Fr> one_scalar = {fs};
-      std::vector<G1Affine> g0 = {params.get_g()[0]};
-      G1 c3 = arithmetic::best_multiexp(one_scalar, g0);
-      std::vector<G1Affine> a = batch_normalize({c1, c2, c3});
-      bool ok = std::memcmp(&a[0], &a[1], 64) == 0 && std::memcmp(&a[0], &a[2], 64) == 0 && !c1.is_identity();
-      if (!ok) {
-        std::printf("self-check FAILED\n");
-        return 1;
-      }
-    }
-    std::printf("MSM / NTT self-check passed (commit == commit_lagrange == f(s)*G) at k = %u\n", k);
+    std::printf("vk %s\n", hex(vk.to_bytes()).c_str());
+    std::printf("proof %s\n", hex(proof).c_str());
+    std::printf("proof_bytes %zu\n", proof.size());
     h2mi_shutdown();
     return 0;
   } catch (const Error& e) {
-    std::fprintf(stderr, "h2mi error %d: %s\n", e.code, e.what());
+    std::fprintf(stderr, "standard_plonk: %s\n", e.what());
     return 2;
   }
 }

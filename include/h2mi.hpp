@@ -333,6 +333,9 @@ class ParamsKZG {
   }
   uint32_t k() const { return k_; }
   uint64_t n() const { return n_; }
+  // registered-bases handles for callers that keep their polynomials on the device (h2mi_msm_bn254_g1_dev)
+  uint64_t g_handle() const { return h_g_; }
+  uint64_t g_lagrange_handle() const { return h_gl_; }
   std::vector<G1Affine> get_g() const { return download(d_g_); }
   std::vector<G1Affine> get_g_lagrange() const { return download(d_gl_); }
   // commit / commit_lagrange: best_multiexp against the matching base set (KZG ignores the blind)
