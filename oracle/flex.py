@@ -1,0 +1,616 @@
+"""CPU oracle: keygen / create_proof / verify_proof for a small family of PLONKish constraint systems, data-driven — the
+generic engine behind the halo2-lib shapes the reference proves through `scaffold::prove`
+(src/scaffold.rs:246-366: GateWithInstanceCircuitBuilder / RangeWithInstanceCircuitBuilder, :379-485; closures
+examples/halo2_lib.rs:14-60 and examples/range.rs:10-34), and — as a cross-check of the engine itself — the StandardPlonk
+circuit, whose proofs must come out byte-identical to oracle/prover.py's.
+
+TEST INFRASTRUCTURE ONLY (see oracle/bn254.py).  PARITY UNPINNED: halo2_proofs (plonk/{keygen,prover,verifier}.rs,
+plonk/lookup/*, plonk/permutation/*) and halo2-base (FlexGateConfig's vertical gate q (a + a(wX) a(w^2 X) - a(w^3 X)),
+RangeConfig's lookup-advice column, the constants column, the cell layout of load_witness / mul / add / mul_add /
+range_check) are restated from memory; neither crate is available here.  Pinned by `verify` accepting exactly the
+consistent proofs (every challenge re-derived, gate / permutation / lookup expressions recomputed from the opened
+evaluations, SHPLONK's final equation by pairing or by the known SRS secret).
+
+A constraint system here = columns (advice / fixed / instance), gates (Python callables over a query function), the
+equality-enabled columns in argument order, single-expression lookups (input column in table column), the explicit
+query lists (their order is the order create_proof writes evaluations in), degree and blinding_factors.
+rng stand-in (the reference passes OsRng): SplitMix64 streams seed+1 advice blinding (column-major, bf + 1 rows),
+seed+2 permutation-product blinding (set-major, bf rows), seed+3 random polynomial, seed+4 permuted lookup columns
+(A' then S', bf + 1 rows each, lookup-major), seed+5 lookup-product blinding (bf rows per lookup).
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+
+from . import bn254 as o
+from . import formats as fmt
+from . import lookup as L
+from . import plonk as P
+from .prover import (ProofReader, construct_intermediate_sets, div_by_vanishing, evaluate_vanishing_polynomial, lagrange_interpolate,
+                     rotate_omega)
+
+R = o.R
+ADVICE, FIXED, INSTANCE = "advice", "fixed", "instance"
+
+
+class ConstraintSystem:
+    def __init__(self, name, n_advice, n_fixed, n_instance, gates, perm_columns, lookups, advice_queries, fixed_queries, instance_queries, degree,
+                 blinding_factors):
+        self.name = name
+        self.n_advice, self.n_fixed, self.n_instance = n_advice, n_fixed, n_instance
+        self.gates = gates                    # callables g(q) -> value, q(kind, column, rotation)
+        self.perm_columns = perm_columns      # [(kind, column)] in the order enable_equality was called
+        self.lookups = lookups                # [((kind, column) input, (kind, column) table)]
+        self.advice_queries, self.fixed_queries, self.instance_queries = advice_queries, fixed_queries, instance_queries
+        self.degree, self.blinding_factors = degree, blinding_factors
+
+    @property
+    def chunk(self):
+        return self.degree - 2
+
+
+def standard_plonk_cs():
+    gate = lambda q: (q(FIXED, 0, 0) * q(ADVICE, 0, 0) + q(FIXED, 1, 0) * q(ADVICE, 1, 0) + q(FIXED, 2, 0) * q(ADVICE, 2, 0)
+                      + q(FIXED, 3, 0) * q(ADVICE, 0, 0) * q(ADVICE, 1, 0) + q(FIXED, 4, 0)) % R
+    return ConstraintSystem("standard_plonk", 3, 5, 0, [gate], [(ADVICE, 0), (ADVICE, 1), (ADVICE, 2)], [], [(0, 0), (1, 0), (2, 0)],
+                            [(c, 0) for c in range(5)], [], 3, 5)
+
+
+def flex_gate_cs(lookup: bool):
+    """halo2-base at these sizes: advice 0 = the gate column (vertical gate, selector = fixed 0), fixed 1 = constants,
+    instance 0; with `lookup`: advice 1 = lookup advice, fixed 2 = the table.  enable_equality order: gate advice,
+    (lookup advice,) constants, instance (the scaffold adds it last: src/scaffold.rs:394-395, 449-450)."""
+    gate = lambda q: q(FIXED, 0, 0) * (q(ADVICE, 0, 0) + q(ADVICE, 0, 1) * q(ADVICE, 0, 2) - q(ADVICE, 0, 3)) % R
+    perm = [(ADVICE, 0)] + ([(ADVICE, 1)] if lookup else []) + [(FIXED, 1), (INSTANCE, 0)]
+    adv_q = [(0, 0), (0, 1), (0, 2), (0, 3)] + ([(1, 0)] if lookup else [])
+    fix_q = [(0, 0), (1, 0)] + ([(2, 0)] if lookup else [])
+    # blinding_factors = max(3, most queries on one advice column = 4) + 2
+    return ConstraintSystem("range" if lookup else "flex_gate", 2 if lookup else 1, 3 if lookup else 2, 1, [gate], perm,
+                            [((ADVICE, 1), (FIXED, 2))] if lookup else [], adv_q, fix_q, [(0, 0)], 4 if lookup else 3, 6)
+
+
+class Assignment:
+    """what synthesize leaves: sparse cells per column, copy constraints in call order, the public inputs"""
+
+    def __init__(self, cs):
+        self.advice = [dict() for _ in range(cs.n_advice)]
+        self.fixed = [dict() for _ in range(cs.n_fixed)]
+        self.instance = [[] for _ in range(cs.n_instance)]
+        self.copies = []  # ((kind, column, row), (kind, column, row)): constrain_equal(left, right)
+
+
+# ---- the two halo2-lib closures of the reference, laid out as halo2-base lays them out [RECALL] ------------------------
+class _Ctx:
+    """halo2-base Context on one advice column: cells appended in order; Existing(cell) copies; Constant(v) cells are tied
+    to the constants column afterwards (one fixed cell per distinct value, in order of first appearance)."""
+
+    def __init__(self, asg):
+        self.asg = asg
+        self.cells = []           # values of advice column 0
+        self.const_cells = []     # (row, value)
+        self.lookup_cells = []    # rows whose value must be looked up
+
+    def load_witness(self, v):
+        self.cells.append(v % R)
+        return len(self.cells) - 1
+
+    def assign_region_last(self, items, gate_offsets):
+        base = len(self.cells)
+        for kind, v in items:
+            row = len(self.cells)
+            if kind == "existing":
+                self.cells.append(self.cells[v])
+                self.asg.copies.append(((ADVICE, 0, row), (ADVICE, 0, v)))
+            elif kind == "constant":
+                self.cells.append(v % R)
+                self.const_cells.append((row, v % R))
+            else:
+                self.cells.append(v % R)
+        for off in gate_offsets:
+            self.asg.fixed[0][base + off] = 1
+        return len(self.cells) - 1
+
+    def mul(self, a, b):
+        return self.assign_region_last([("constant", 0), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b])], [0])
+
+    def add_const(self, a, c):
+        return self.assign_region_last([("existing", a), ("constant", c), ("constant", 1), ("witness", self.cells[a] + c)], [0])
+
+    def add(self, a, b):
+        return self.assign_region_last([("existing", a), ("existing", b), ("constant", 1), ("witness", self.cells[a] + self.cells[b])], [0])
+
+    def mul_add_const(self, a, b, c):
+        return self.assign_region_last([("constant", c), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b] + c)], [0])
+
+    def finish(self, public_rows, lookup_column=None):
+        asg = self.asg
+        for row, v in enumerate(self.cells):
+            asg.advice[0][row] = v
+        consts = {}
+        for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, then constrain_equal
+            if v not in consts:
+                consts[v] = len(consts)
+                asg.fixed[1][consts[v]] = v
+            asg.copies.append(((ADVICE, 0, row), (FIXED, 1, consts[v])))
+        if lookup_column is not None:  # cells_to_lookup: copied into the lookup-advice column, top down
+            for i, row in enumerate(self.lookup_cells):
+                asg.advice[lookup_column][i] = self.cells[row]
+                asg.copies.append(((ADVICE, lookup_column, i), (ADVICE, 0, row)))
+        for i, row in enumerate(public_rows):  # constrain_instance(cell, instance, i)
+            asg.instance[0].append(self.cells[row])
+            asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
+
+
+def halo2_lib_assignment(cs, x):
+    """examples/halo2_lib.rs:14-60: x^2 + 72 three ways; public: x and out"""
+    asg = Assignment(cs)
+    ctx = _Ctx(asg)
+    xc = ctx.load_witness(x)
+    x_sq = ctx.mul(xc, xc)
+    out = ctx.add_const(x_sq, 72)
+    val = (x * x + 72) % R
+    ctx.assign_region_last([("constant", 72), ("existing", xc), ("existing", xc), ("witness", val)], [0])
+    ctx.mul_add_const(xc, xc, 72)
+    ctx.finish([xc, out])
+    return asg
+
+
+def range_assignment(cs, x, lookup_bits, n):
+    """examples/range.rs:10-34: x public, range_check(x, 64) with LOOKUP_BITS limbs, then x + x.  The table column holds
+    0 .. 2^LOOKUP_BITS - 1 (RangeConfig::load_lookup_table), zero elsewhere."""
+    assert 0 <= x < 1 << 64
+    asg = Assignment(cs)
+    ctx = _Ctx(asg)
+    xc = ctx.load_witness(x)
+    num_limbs = -(-64 // lookup_bits)
+    limbs = [(x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1) for i in range(num_limbs)]
+    # inner_product_left_last(limbs, bases) with bases[0] = 1: [l0, l1, 2^b, acc1, l2, 2^2b, acc2, ...], gate on every third row
+    rows = [ctx.load_witness(limbs[0])]
+    acc_row, acc = rows[0], limbs[0]
+    for i in range(1, num_limbs):
+        base = len(ctx.cells) - 1  # the accumulator cell doubles as the gate's first cell
+        acc = acc + limbs[i] * (1 << (lookup_bits * i))
+        ctx.cells.append(limbs[i])
+        rows.append(len(ctx.cells) - 1)
+        ctx.cells.append((1 << (lookup_bits * i)) % R)
+        ctx.const_cells.append((len(ctx.cells) - 1, (1 << (lookup_bits * i)) % R))
+        ctx.cells.append(acc % R)
+        asg.fixed[0][base] = 1
+        acc_row = len(ctx.cells) - 1
+    asg.copies.append(((ADVICE, 0, xc), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
+    ctx.lookup_cells += rows
+    rem = 64 % lookup_bits
+    if rem:  # the top limb must fit the remaining bits: limb * 2^(lookup_bits - rem) is looked up too
+        top = ctx.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
+                                      ("witness", limbs[-1] << (lookup_bits - rem))], [0])
+        ctx.lookup_cells.append(top)
+    ctx.add(xc, xc)
+    ctx.finish([xc], lookup_column=1)
+    for i in range(1 << lookup_bits):
+        asg.fixed[2][i] = i
+    return asg
+
+
+# ---- keygen ----------------------------------------------------------------------------------------------------------
+class Keys:
+    def __init__(self, cs, k, s, asg_fixed, copies):
+        self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
+        n = self.n
+        self.dom = o.Domain(k, cs.degree)
+        self.u = n - (cs.blinding_factors + 1)
+        self.pw, self.lag = o.srs_scalars(k, s)
+        self.fixed = [[cells.get(r, 0) for r in range(n)] for cells in asg_fixed]
+        w = self.dom.omega
+        self.omega_pows = [1] * n
+        for i in range(1, n):
+            self.omega_pows[i] = self.omega_pows[i - 1] * w % R
+        m = len(cs.perm_columns)
+        self.dpow = [pow(P.FR_DELTA, j, R) for j in range(m)]
+        index = {col: j for j, col in enumerate(cs.perm_columns)}
+        asm = {}
+        aux, sizes = {}, {}
+        g = lambda d, c: d.get(c, c)
+        for left, right in copies:  # permutation/keygen.rs Assembly::copy on (argument column index, row)
+            lc_, rc_ = (index[(left[0], left[1])], left[2]), (index[(right[0], right[1])], right[2])
+            lcy, rcy = g(aux, lc_), g(aux, rc_)
+            if lcy == rcy:
+                continue
+            if sizes.get(lcy, 1) < sizes.get(rcy, 1):
+                lcy, rcy = rcy, lcy
+            sizes[lcy] = sizes.get(lcy, 1) + sizes.get(rcy, 1)
+            i = rcy
+            while True:
+                aux[i] = lcy
+                i = g(asm, i)
+                if i == rcy:
+                    break
+            asm[lc_], asm[rc_] = g(asm, rc_), g(asm, lc_)
+        ident = lambda j, i: self.dpow[j] * self.omega_pows[i] % R
+        self.sigma = [[ident(j, i) for i in range(n)] for j in range(m)]
+        for (j, i), (tj, ti) in asm.items():
+            self.sigma[j][i] = ident(tj, ti)
+        self.l0 = [1] + [0] * (n - 1)
+        self.l_last = [0] * n
+        self.l_last[self.u] = 1
+        self.l_active = [1 if i < self.u else 0 for i in range(n)]
+        d = self.dom
+        self.fixed_polys = [d.lagrange_to_coeff(c) for c in self.fixed]
+        self.sigma_polys = [d.lagrange_to_coeff(c) for c in self.sigma]
+        self.fixed_commitments = [self.commit_lagrange(c) for c in self.fixed]
+        self.permutation_commitments = [self.commit_lagrange(c) for c in self.sigma]
+        self.transcript_repr = self._transcript_repr()
+
+    def commit_lagrange(self, evals):
+        return o.g1_mul(sum(e * l for e, l in zip(evals, self.lag)) % R, o.G1_GEN)
+
+    def commit(self, coeffs):
+        return o.g1_mul(sum(c * p for c, p in zip(coeffs, self.pw)) % R, o.G1_GEN)
+
+    def vk_bytes(self):
+        out = bytearray(struct.pack("<II", self.k, self.cs.degree))
+        for c in self.fixed_commitments + self.permutation_commitments:
+            out += fmt.g1_to_bytes(c)
+        return bytes(out)
+
+    def _transcript_repr(self):
+        h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+        s = self.vk_bytes()
+        h.update(struct.pack("<Q", len(s)))
+        h.update(s)
+        return int.from_bytes(h.digest(), "little") % R
+
+
+def _rand(count, seed):
+    return o.unpack(o.random_field_limbs(count, seed), R)
+
+
+def _column(keys, kind, col, advice, instance_cols):
+    return {ADVICE: advice, FIXED: keys.fixed, INSTANCE: instance_cols}[kind][col]
+
+
+def prove(keys: Keys, asg: Assignment, seed: int) -> dict:
+    cs, n, u, dom = keys.cs, keys.n, keys.u, keys.dom
+    bf = cs.blinding_factors
+    ev = o.eval_polynomial
+    tr = fmt.Blake2bTranscript()
+    tr.common_scalar(keys.transcript_repr)
+    instance_cols = []
+    for vals in asg.instance:  # KZG: instance values are hashed, not committed
+        for v in vals:
+            tr.common_scalar(v)
+        instance_cols.append(list(vals) + [0] * (n - len(vals)))
+    blind = iter(_rand(cs.n_advice * (bf + 1), seed + 1))
+    advice = []
+    for cells in asg.advice:
+        col = [cells.get(r, 0) for r in range(n)]
+        assert all(r < u for r in cells), "assignment reaches into the blinding rows"
+        for r in range(u, n):
+            col[r] = next(blind)
+        advice.append(col)
+    for c in advice:
+        tr.write_point(keys.commit_lagrange(c))
+    theta = tr.squeeze_challenge()
+    col_of = lambda kc: _column(keys, kc[0], kc[1], advice, instance_cols)
+    lk_blind = iter(_rand(2 * (bf + 1) * max(len(cs.lookups), 1), seed + 4))
+    permuted = []
+    for inp, tab in cs.lookups:
+        a_in, t_in = col_of(inp), col_of(tab)
+        ap, sp = L.permute_expression_pair(a_in, t_in, u, [next(lk_blind) for _ in range(bf + 1)], [next(lk_blind) for _ in range(bf + 1)])
+        permuted.append((ap, sp))
+        tr.write_point(keys.commit_lagrange(ap))
+        tr.write_point(keys.commit_lagrange(sp))
+    beta, gamma = tr.squeeze_challenge(), tr.squeeze_challenge()
+    # permutation products
+    m = len(cs.perm_columns)
+    zblind = iter(_rand(-(-m // cs.chunk) * bf, seed + 2))
+    zs, start = [], 1
+    for s0 in range(0, m, cs.chunk):
+        z = [0] * n
+        z[0] = start
+        for i in range(u):
+            num = den = 1
+            for j in range(s0, min(m, s0 + cs.chunk)):
+                v = col_of(cs.perm_columns[j])[i]
+                num = num * ((v + beta * keys.dpow[j] * keys.omega_pows[i] + gamma) % R) % R
+                den = den * ((v + beta * keys.sigma[j][i] + gamma) % R) % R
+            z[i + 1] = z[i] * num % R * pow(den, -1, R) % R
+        for r in range(u + 1, n):
+            z[r] = next(zblind)
+        start = z[u]
+        zs.append(z)
+    for z in zs:
+        tr.write_point(keys.commit_lagrange(z))
+    lz_blind = iter(_rand(bf * max(len(cs.lookups), 1), seed + 5))
+    lzs = []
+    for (inp, tab), (ap, sp) in zip(cs.lookups, permuted):
+        lz = L.lookup_product(col_of(inp), col_of(tab), ap, sp, beta, gamma, u, [next(lz_blind) for _ in range(bf)])
+        lzs.append(lz)
+        tr.write_point(keys.commit_lagrange(lz))
+    random_poly = _rand(n, seed + 3)
+    tr.write_point(keys.commit(random_poly))
+    y = tr.squeeze_challenge()
+    # ---- quotient ------------------------------------------------------------------------------------------------
+    size = 1 << dom.extended_k
+    rot = size // n
+    E = lambda lagr: dom.coeff_to_extended(dom.lagrange_to_coeff(lagr))
+    adv_c, fix_c, ins_c = [E(c) for c in advice], [E(c) for c in keys.fixed], [E(c) for c in instance_cols]
+    sig_c, z_c = [E(c) for c in keys.sigma], [E(z) for z in zs]
+    lk_c = [(E(ap), E(sp), E(lz)) for (ap, sp), lz in zip(permuted, lzs)]
+    l0, ll, lact = E(keys.l0), E(keys.l_last), E(keys.l_active)
+    cosets = {ADVICE: adv_c, FIXED: fix_c, INSTANCE: ins_c}
+    h_ext = [0] * size
+    tinv = [pow((pow(dom.g_coset * pow(dom.extended_omega, i, R) % R, n, R) - 1) % R, -1, R) for i in range(rot)]
+    for idx in range(size):
+        rn = lambda r: (idx + r * rot) % size
+        q = lambda kind, col, r: cosets[kind][col][rn(r)]
+        v = 0
+        for gate in cs.gates:
+            v = (v * y + gate(q)) % R
+        v = _permutation_terms(cs, v, y, beta, gamma, lambda kc: cosets[kc[0]][kc[1]][idx], [s[idx] for s in sig_c], [z[idx] for z in z_c],
+                               [z[rn(1)] for z in z_c], [z[rn(-(bf + 1))] for z in z_c], l0[idx], ll[idx], lact[idx],
+                               dom.g_coset * pow(dom.extended_omega, idx, R) % R)
+        for (inp, tab), (ap, sp, lz) in zip(cs.lookups, lk_c):
+            v = _lookup_terms(v, y, beta, gamma, cosets[inp[0]][inp[1]][idx], cosets[tab[0]][tab[1]][idx], ap[idx], ap[rn(-1)], sp[idx], lz[idx],
+                              lz[rn(1)], l0[idx], ll[idx], lact[idx])
+        h_ext[idx] = v * tinv[idx % rot] % R
+    h_coeffs = dom.extended_to_coeff(h_ext)
+    pieces = [h_coeffs[i * n : (i + 1) * n] for i in range(dom.quotient_poly_degree)]
+    for p in pieces:
+        tr.write_point(keys.commit(p))
+    x = tr.squeeze_challenge()
+    xn = pow(x, n, R)
+    # ---- evaluations -----------------------------------------------------------------------------------------------
+    advice_polys = [dom.lagrange_to_coeff(c) for c in advice]
+    z_polys = [dom.lagrange_to_coeff(z) for z in zs]
+    lk_polys = [(dom.lagrange_to_coeff(ap), dom.lagrange_to_coeff(sp), dom.lagrange_to_coeff(lz)) for (ap, sp), lz in zip(permuted, lzs)]
+    rx = lambda r: rotate_omega(dom, x, r)
+    for c, r in cs.advice_queries:
+        tr.write_scalar(ev(advice_polys[c], rx(r)))
+    for c, r in cs.fixed_queries:
+        tr.write_scalar(ev(keys.fixed_polys[c], rx(r)))
+    h_poly = [0] * n
+    for piece in reversed(pieces):
+        h_poly = [(a * xn + b) % R for a, b in zip(h_poly, piece)]
+    tr.write_scalar(ev(random_poly, x))
+    for sp_ in keys.sigma_polys:
+        tr.write_scalar(ev(sp_, x))
+    x_next, x_last, x_inv = rx(1), rx(-(bf + 1)), rx(-1)
+    for i, zp in enumerate(z_polys):
+        tr.write_scalar(ev(zp, x))
+        tr.write_scalar(ev(zp, x_next))
+        if i + 1 < len(z_polys):
+            tr.write_scalar(ev(zp, x_last))
+    for app, spp, lzp in lk_polys:  # lookup Evaluated: product, product_next, permuted_input, permuted_input_inv, permuted_table
+        for poly, pt in ((lzp, x), (lzp, x_next), (app, x), (app, x_inv), (spp, x)):
+            tr.write_scalar(ev(poly, pt))
+    # ---- queries, SHPLONK --------------------------------------------------------------------------------------------
+    polys, queries = {}, []
+
+    def qq(key, poly, pt):
+        polys[key] = poly
+        queries.append((key, pt, ev(poly, pt)))
+
+    for c, r in cs.advice_queries:
+        qq(("advice", c), advice_polys[c], rx(r))
+    for i, zp in enumerate(z_polys):
+        qq(("z", i), zp, x)
+        qq(("z", i), zp, x_next)
+    for i in reversed(range(len(z_polys) - 1)):
+        qq(("z", i), z_polys[i], x_last)
+    for li, (app, spp, lzp) in enumerate(lk_polys):  # lookup open: product@x, input@x, table@x, input@x_inv, product@x_next
+        qq(("lz", li), lzp, x)
+        qq(("la", li), app, x)
+        qq(("ls", li), spp, x)
+        qq(("la", li), app, x_inv)
+        qq(("lz", li), lzp, x_next)
+    for c, r in cs.fixed_queries:
+        qq(("fixed", c), keys.fixed_polys[c], rx(r))
+    for i, sp_ in enumerate(keys.sigma_polys):
+        qq(("sigma", i), sp_, x)
+    qq(("h",), h_poly, x)
+    qq(("random",), random_poly, x)
+    _shplonk_prove(keys, tr, polys, queries, n)
+    return {"proof": bytes(tr.proof), "theta": theta, "beta": beta, "gamma": gamma, "y": y, "x": x, "zs": zs, "permuted": permuted, "lzs": lzs,
+            "h_coeffs": h_coeffs, "advice": advice}
+
+
+def _permutation_terms(cs, v, y, beta, gamma, value_of, sig, z, z_next, z_last, l0, ll, lact, X):
+    if not cs.perm_columns:
+        return v
+    v = (v * y + (1 - z[0]) * l0) % R
+    v = (v * y + (z[-1] * z[-1] - z[-1]) * ll) % R
+    for s in range(1, len(z)):
+        v = (v * y + (z[s] - z_last[s - 1]) * l0) % R
+    cur = beta * X % R
+    m = len(cs.perm_columns)
+    for s, s0 in enumerate(range(0, m, cs.chunk)):
+        left, right = z_next[s], z[s]
+        for j in range(s0, min(m, s0 + cs.chunk)):
+            val = value_of(cs.perm_columns[j])
+            left = left * (val + beta * sig[j] + gamma) % R
+            right = right * (val + cur + gamma) % R
+            cur = cur * P.FR_DELTA % R
+        v = (v * y + (left - right) * lact) % R
+    return v
+
+
+def _lookup_terms(v, y, beta, gamma, a_in, t_in, ap, ap_prev, sp, lz, lz_next, l0, ll, lact):
+    v = (v * y + (1 - lz) * l0) % R
+    v = (v * y + (lz * lz - lz) * ll) % R
+    v = (v * y + (lz_next * (ap + beta) % R * (sp + gamma) - lz * (a_in + beta) % R * (t_in + gamma)) * lact) % R
+    v = (v * y + (ap - sp) * l0) % R
+    v = (v * y + (ap - sp) * (ap - ap_prev) % R * lact) % R
+    return v
+
+
+def _shplonk_prove(keys, tr, polys, queries, n):
+    ev = o.eval_polynomial
+    y_sh = tr.squeeze_challenge()
+    rotation_sets, super_points = construct_intermediate_sets(queries)
+    v = tr.squeeze_challenge()
+    quotients = []
+    for pts, comms in rotation_sets:
+        nx, yp = [0] * n, 1
+        for key, evals in comms:
+            r_x = lagrange_interpolate(pts, evals)
+            num = list(polys[key])
+            for i, c in enumerate(r_x):
+                num[i] = (num[i] - c) % R
+            nx = [(a + yp * b) % R for a, b in zip(nx, num)]
+            yp = yp * y_sh % R
+        qx = div_by_vanishing(nx, pts)
+        quotients.append(qx + [0] * (n - len(qx)))
+    h_x, vp = [0] * n, 1
+    for qx in quotients:
+        h_x = [(a + vp * b) % R for a, b in zip(h_x, qx)]
+        vp = vp * v % R
+    tr.write_point(keys.commit(h_x))
+    u = tr.squeeze_challenge()
+    zt_eval = evaluate_vanishing_polynomial(super_points, u)
+    l_x, z_diffs, vp = [0] * n, [], 1
+    for pts, comms in rotation_sets:
+        z_i = evaluate_vanishing_polynomial([p for p in super_points if p not in pts], u)
+        z_diffs.append(z_i)
+        inner, yp = [0] * n, 1
+        for key, evals in comms:
+            lin = list(polys[key])
+            lin[0] = (lin[0] - ev(lagrange_interpolate(pts, evals), u)) % R
+            inner = [(a + yp * b) % R for a, b in zip(inner, lin)]
+            yp = yp * y_sh % R
+        l_x = [(a + vp * z_i % R * b) % R for a, b in zip(l_x, inner)]
+        vp = vp * v % R
+    l_x = [(a - zt_eval * b) % R for a, b in zip(l_x, h_x)]
+    assert ev(l_x, u) == 0
+    z0inv = pow(z_diffs[0], -1, R)
+    h2_x = [c * z0inv % R for c in div_by_vanishing(l_x, [u])] + [0]
+    tr.write_point(keys.commit(h2_x))
+
+
+def verify(keys, proof: bytes, instances, g2=None, s_g2=None) -> bool:
+    """plonk/verifier.rs verify_proof + VerifierSHPLONK for the constraint system of `keys` (only its verifying-key part:
+    cs, k, domain, commitments, transcript_repr — and s unless the SRS's G2 elements are given)."""
+    cs, n, dom = keys.cs, keys.n, keys.dom
+    bf = cs.blinding_factors
+    n_sets = -(-len(cs.perm_columns) // cs.chunk)
+    try:
+        rd = ProofReader(proof)
+        rd.tr.common_scalar(keys.transcript_repr)
+        for vals in instances:
+            for v in vals:
+                rd.tr.common_scalar(v)
+        advice_c = [rd.read_point() for _ in range(cs.n_advice)]
+        rd.squeeze()  # theta
+        lk_perm_c = [(rd.read_point(), rd.read_point()) for _ in cs.lookups]
+        beta, gamma = rd.squeeze(), rd.squeeze()
+        z_c = [rd.read_point() for _ in range(n_sets)]
+        lz_c = [rd.read_point() for _ in cs.lookups]
+        random_c = rd.read_point()
+        y = rd.squeeze()
+        h_c = [rd.read_point() for _ in range(dom.quotient_poly_degree)]
+        x = rd.squeeze()
+        advice_evals = [rd.read_scalar() for _ in cs.advice_queries]
+        fixed_evals = [rd.read_scalar() for _ in cs.fixed_queries]
+        random_eval = rd.read_scalar()
+        sigma_evals = [rd.read_scalar() for _ in cs.perm_columns]
+        z_evals = []
+        for i in range(n_sets):
+            e, en = rd.read_scalar(), rd.read_scalar()
+            z_evals.append((e, en, rd.read_scalar() if i + 1 < n_sets else None))
+        lk_evals = [tuple(rd.read_scalar() for _ in range(5)) for _ in cs.lookups]
+    except ValueError:
+        return False
+    xn = pow(x, n, R)
+    w = dom.omega
+    l_at = lambda rot: (xn - 1) * pow(n, -1, R) % R * pow(w, rot % n, R) % R * pow((x - pow(w, rot % n, R)) % R, -1, R) % R
+    l_evals = [l_at(rot) for rot in range(-(bf + 1), 1)]
+    l_last, l_blind, l_0 = l_evals[0], sum(l_evals[1 : 1 + bf]) % R, l_evals[1 + bf]
+    lact = (1 - (l_last + l_blind)) % R
+    # instance evaluations: the verifier interpolates the public inputs itself (KZG does not query instance commitments)
+    instance_evals = []
+    for c, r in cs.instance_queries:
+        pt = rotate_omega(dom, x, r)
+        ptn = pow(pt, n, R)
+        instance_evals.append(sum(v * ((ptn - 1) * pow(n, -1, R) % R * pow(w, i, R) % R * pow((pt - pow(w, i, R)) % R, -1, R) % R)
+                                  for i, v in enumerate(instances[c])) % R)
+    evals = {}
+    for qi, (c, r) in enumerate(cs.advice_queries):
+        evals[(ADVICE, c, r)] = advice_evals[qi]
+    for qi, (c, r) in enumerate(cs.fixed_queries):
+        evals[(FIXED, c, r)] = fixed_evals[qi]
+    for qi, (c, r) in enumerate(cs.instance_queries):
+        evals[(INSTANCE, c, r)] = instance_evals[qi]
+    q = lambda kind, col, r: evals[(kind, col, r)]
+    v = 0
+    for gate in cs.gates:
+        v = (v * y + gate(q)) % R
+    v = _permutation_terms(cs, v, y, beta, gamma, lambda kc: evals[(kc[0], kc[1], 0)], sigma_evals, [e[0] for e in z_evals], [e[1] for e in z_evals],
+                           [e[2] for e in z_evals], l_0, l_last, lact, x)
+    for (inp, tab), (lz, lz_next, ap, ap_inv, sp) in zip(cs.lookups, lk_evals):
+        v = _lookup_terms(v, y, beta, gamma, evals[(inp[0], inp[1], 0)], evals[(tab[0], tab[1], 0)], ap, ap_inv, sp, lz, lz_next, l_0, l_last, lact)
+    expected_h = v * pow((xn - 1) % R, -1, R) % R
+    h_commitment = None
+    for cmt in reversed(h_c):
+        h_commitment = o.g1_add(o.g1_mul(xn, h_commitment) if h_commitment else None, cmt)
+    rx = lambda r: rotate_omega(dom, x, r)
+    x_next, x_last, x_inv = rx(1), rx(-(bf + 1)), rx(-1)
+    points, queries = {}, []
+
+    def qq(key, cmt, pt, evl):
+        points[key] = cmt
+        queries.append((key, pt, evl))
+
+    for qi, (c, r) in enumerate(cs.advice_queries):
+        qq(("advice", c), advice_c[c], rx(r), advice_evals[qi])
+    for i in range(n_sets):
+        qq(("z", i), z_c[i], x, z_evals[i][0])
+        qq(("z", i), z_c[i], x_next, z_evals[i][1])
+    for i in reversed(range(n_sets - 1)):
+        qq(("z", i), z_c[i], x_last, z_evals[i][2])
+    for li, (lz, lz_next, ap, ap_inv, sp) in enumerate(lk_evals):
+        qq(("lz", li), lz_c[li], x, lz)
+        qq(("la", li), lk_perm_c[li][0], x, ap)
+        qq(("ls", li), lk_perm_c[li][1], x, sp)
+        qq(("la", li), lk_perm_c[li][0], x_inv, ap_inv)
+        qq(("lz", li), lz_c[li], x_next, lz_next)
+    for qi, (c, r) in enumerate(cs.fixed_queries):
+        qq(("fixed", c), keys.fixed_commitments[c], rx(r), fixed_evals[qi])
+    for i in range(len(cs.perm_columns)):
+        qq(("sigma", i), keys.permutation_commitments[i], x, sigma_evals[i])
+    qq(("h",), h_commitment, x, expected_h)
+    qq(("random",), random_c, x, random_eval)
+    rotation_sets, super_points = construct_intermediate_sets(queries)
+    y_sh, vv = rd.squeeze(), rd.squeeze()
+    try:
+        h1 = rd.read_point()
+        uu = rd.squeeze()
+        h2 = rd.read_point()
+    except ValueError:
+        return False
+    if rd.pos != len(proof):
+        return False
+    outer, r_outer, z_0, z_0_diff_inv, vp = None, 0, 0, 0, 1
+    for i, (pts, comms) in enumerate(rotation_sets):
+        z_diff = evaluate_vanishing_polynomial([p for p in super_points if p not in pts], uu)
+        if i == 0:
+            z_0 = evaluate_vanishing_polynomial(pts, uu)
+            z_0_diff_inv = pow(z_diff, -1, R)
+            z_diff = 1
+        else:
+            z_diff = z_diff * z_0_diff_inv % R
+        inner, r_inner, yp = None, 0, 1
+        for key, evs in comms:
+            r_inner = (r_inner + yp * o.eval_polynomial(lagrange_interpolate(pts, evs), uu)) % R
+            inner = o.g1_add(inner, o.g1_mul(yp, points[key]))
+            yp = yp * y_sh % R
+        r_outer = (r_outer + vp * r_inner % R * z_diff) % R
+        outer = o.g1_add(outer, o.g1_mul(vp * z_diff % R, inner))
+        vp = vp * vv % R
+    outer = o.g1_add(outer, o.g1_mul((-r_outer) % R, o.G1_GEN))
+    outer = o.g1_add(outer, o.g1_mul((-z_0) % R, h1))
+    outer = o.g1_add(outer, o.g1_mul(uu, h2))
+    if g2 is not None and s_g2 is not None:
+        from . import pairing
+
+        return pairing.pairing_product_is_one([(h2, s_g2), (o.g1_neg(outer), g2)]) if outer is not None else h2 is None
+    return o.g1_mul(keys.s, h2) == outer
