@@ -763,14 +763,14 @@ struct RangeCosets {
   const fe* table;
   const fe* perm_value[4];
   const fe* perm_sigma[4];
-  const fe* perm_z[2];
+  const fe* perm_z[4];
   const fe* lk_input;
   const fe* lk_table;
   const fe* lk_z;
   const fe* l0;
   const fe* l_last;
   const fe* l_active;
-  uint32_t n_perm;
+  uint32_t n_perm, chunk, has_lookup;
 };
 __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma, fe y, fe delta,
                                                            fe zeta, const fe* xlo, const fe* xhi, uint32_t xh, TInv t_inv, fe* out) {
@@ -784,25 +784,30 @@ __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_
   // gate
   fe v = fe_mul<Fr>(fe_load(&c.q[idx]), fe_sub<Fr>(fe_add<Fr>(fe_load(&c.a[idx]), fe_mul<Fr>(fe_load(&c.a[at(1)]), fe_load(&c.a[at(2)]))),
                                                    fe_load(&c.a[at(3)])));
-  // permutation argument: sets of two columns
-  const uint32_t sets = (c.n_perm + 1) >> 1;
+  // permutation argument: sets of `chunk` columns (chunk = cs.degree() - 2)
+  const uint32_t sets = (c.n_perm + c.chunk - 1) / c.chunk;
   const fe z_first = fe_load(&c.perm_z[0][idx]);
   const fe z_lastset = fe_load(&c.perm_z[sets - 1][idx]);
   v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, z_first), l0));
   v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z_lastset), z_lastset), ll));
-  if (sets == 2) v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z_lastset, fe_load(&c.perm_z[0][r_last])), l0));
+  for (uint32_t s = 1; s < sets; s++)
+    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_load(&c.perm_z[s][idx]), fe_load(&c.perm_z[s - 1][r_last])), l0));
   fe X;
   f29_to_mont256<F9>(pow2tab(xlo, xhi, xh, idx), X.v);
   fe cur = fe_mul<Fr>(beta, fe_mul<Fr>(zeta, X));
   for (uint32_t s = 0; s < sets; s++) {
-    fe left = fe_load(&c.perm_z[s][r_next]), right = s == 0 ? z_first : z_lastset;
-    for (uint32_t j = 2 * s; j < c.n_perm && j < 2 * s + 2; j++) {
+    fe left = fe_load(&c.perm_z[s][r_next]), right = fe_load(&c.perm_z[s][idx]);
+    for (uint32_t j = c.chunk * s; j < c.n_perm && j < c.chunk * (s + 1); j++) {
       const fe val = fe_load(&c.perm_value[j][idx]);
       left = fe_mul<Fr>(left, fe_add<Fr>(fe_add<Fr>(val, fe_mul<Fr>(beta, fe_load(&c.perm_sigma[j][idx]))), gamma));
       right = fe_mul<Fr>(right, fe_add<Fr>(fe_add<Fr>(val, cur), gamma));
       cur = fe_mul<Fr>(cur, delta);
     }
     v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la_));
+  }
+  if (!c.has_lookup) {
+    fe_store(&out[idx], fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]));
+    return;
   }
   // lookup argument: five terms
   const fe ap = fe_load(&c.lk_input[idx]), sp = fe_load(&c.lk_table[idx]), zl = fe_load(&c.lk_z[idx]);
@@ -1500,20 +1505,23 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
   H2_REQUIRE_INIT();
   if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
   if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
-  if (c->n_perm == 0 || c->n_perm > 4) return H2MI_EINVAL;
+  if (c->n_perm == 0 || c->n_perm > 4 || c->chunk_len == 0 || c->chunk_len > 2) return H2MI_EINVAL;
   RangeCosets rc_;
   memset(&rc_, 0, sizeof(rc_));
   rc_.a = (const fe*)c->a; rc_.la = (const fe*)c->lookup_advice; rc_.q = (const fe*)c->q; rc_.table = (const fe*)c->table;
   rc_.lk_input = (const fe*)c->lookup_permuted_input; rc_.lk_table = (const fe*)c->lookup_permuted_table; rc_.lk_z = (const fe*)c->lookup_z;
   rc_.l0 = (const fe*)c->l0; rc_.l_last = (const fe*)c->l_last; rc_.l_active = (const fe*)c->l_active;
   rc_.n_perm = c->n_perm;
-  if (!rc_.a || !rc_.la || !rc_.q || !rc_.table || !rc_.lk_input || !rc_.lk_table || !rc_.lk_z || !rc_.l0 || !rc_.l_last || !rc_.l_active) return H2MI_EINVAL;
+  rc_.chunk = c->chunk_len;
+  rc_.has_lookup = c->has_lookup ? 1u : 0u;
+  if (!rc_.a || !rc_.q || !rc_.l0 || !rc_.l_last || !rc_.l_active) return H2MI_EINVAL;
+  if (rc_.has_lookup && (!rc_.la || !rc_.table || !rc_.lk_input || !rc_.lk_table || !rc_.lk_z)) return H2MI_EINVAL;
   for (uint32_t j = 0; j < c->n_perm; j++) {
     rc_.perm_value[j] = (const fe*)c->perm_value[j];
     rc_.perm_sigma[j] = (const fe*)c->perm_sigma[j];
     if (!rc_.perm_value[j] || !rc_.perm_sigma[j]) return H2MI_EINVAL;
   }
-  for (uint32_t q = 0; q < (c->n_perm + 1) / 2; q++) {
+  for (uint32_t q = 0; q < (c->n_perm + c->chunk_len - 1) / c->chunk_len; q++) {
     rc_.perm_z[q] = (const fe*)c->perm_z[q];
     if (!rc_.perm_z[q]) return H2MI_EINVAL;
   }

@@ -1,0 +1,459 @@
+"""keygen + create_proof for the halo2-lib constraint systems the reference proves through `scaffold::prove`
+(src/scaffold.rs:246-366), with every vector resident in HBM — BASELINE configs[2] (halo2_lib.rs: x^2 + 72) and
+configs[3] (range.rs: range_check(x, 64) with a LOOKUP_BITS table).
+
+The reference builds these circuits with halo2-base (GateWithInstanceCircuitBuilder / RangeWithInstanceCircuitBuilder,
+src/scaffold.rs:379-485: FlexGate's vertical gate q (a + a(wX) a(w^2 X) - a(w^3 X)) on the advice column, a constants
+column, RangeConfig's lookup-advice column and table, and one instance column added — and equality-enabled — last,
+:394-395, :449-450).  halo2-base is an un-vendored dependency; its cell layout (load_witness, mul, add, mul_add,
+range_check's limb decomposition) is restated from memory in `halo2_lib_closure` / `range_closure` below — the witness
+generation a prover runs on the CPU.  Everything after it is the same device pipeline as prover.py, generalised:
+an instance column (public inputs are hashed into the transcript and take part in the permutation argument), advice
+queries at rotations 0..3, permutation sets of `degree - 2` columns, and for the Range builder one lookup argument
+(permuted columns by counting sort against the keygen-sorted table, lookup grand product, five more terms in
+evaluate_h; degree 4: extended domain 4n, three h pieces).  Checked against oracle/flex.py: byte-identical proofs at
+small k, accepted by its verifier at k = 16 and above (tests/test_gpu_flex.py).
+rng stand-in as in prover.py, plus streams seed+4 (blinding rows of the permuted lookup columns) and seed+5 (of the
+lookup product).
+"""
+import ctypes as C
+import hashlib
+import struct
+
+import numpy as np
+
+from . import field as F
+from . import plonk as gp
+from . import serde, synth
+from ._lib import check, lib
+from .circuits import PermutationAssembly
+from .device import DevBuf
+from .domain import EvaluationDomain
+from .keygen import FR_DELTA, _m, commit_points
+from .params import ParamsKZG
+from .prover import _Q, _RINV_Q
+from .shplonk import ProverSHPLONK
+from .transcript import Blake2bWrite
+
+R = F.FR_MODULUS
+ADVICE, FIXED, INSTANCE = "advice", "fixed", "instance"
+
+
+class FlexGateCS:
+    """the constraint system of the Gate builder (lookup = False) or the Range builder (lookup = True) at these sizes:
+    one gate advice column; fixed 0 = its selector, fixed 1 = constants, (fixed 2 = the lookup table, advice 1 = the
+    lookup advice); instance 0.  Queries in the order configure() makes them [restated]."""
+
+    def __init__(self, lookup: bool):
+        self.lookup = lookup
+        self.n_advice = 2 if lookup else 1
+        self.n_fixed = 3 if lookup else 2
+        self.perm_columns = [(ADVICE, 0)] + ([(ADVICE, 1)] if lookup else []) + [(FIXED, 1), (INSTANCE, 0)]
+        self.advice_queries = [(0, 0), (0, 1), (0, 2), (0, 3)] + ([(1, 0)] if lookup else [])
+        self.fixed_queries = [(0, 0), (1, 0)] + ([(2, 0)] if lookup else [])
+        self.degree = 4 if lookup else 3          # the lookup argument is what raises it
+        self.blinding_factors = 6                 # max(3, four queries on the gate column) + 2
+        self.chunk = self.degree - 2
+
+
+class Assignment:
+    def __init__(self, cs: FlexGateCS):
+        self.advice = [dict() for _ in range(cs.n_advice)]
+        self.fixed = [dict() for _ in range(cs.n_fixed)]
+        self.instance = []   # public inputs (column 0)
+        self.copies = []     # ((kind, column, row), (kind, column, row)) in constrain_equal order
+
+
+class Context:
+    """halo2-base `Context` on one advice column [layout restated from memory]: cells are appended in program order;
+    Existing(cell) re-assigns the value and constrains it equal to the original; Constant(v) cells are tied to one fixed
+    cell per distinct value afterwards; `cells_to_lookup` are copied into the lookup-advice column."""
+
+    def __init__(self, asg: Assignment):
+        self.asg = asg
+        self.cells, self.const_cells, self.lookup_cells = [], [], []
+
+    def load_witness(self, v: int) -> int:
+        self.cells.append(v % R)
+        return len(self.cells) - 1
+
+    def assign_region_last(self, items, gate_offsets) -> int:
+        base = len(self.cells)
+        for kind, v in items:
+            row = len(self.cells)
+            if kind == "existing":
+                self.cells.append(self.cells[v])
+                self.asg.copies.append(((ADVICE, 0, row), (ADVICE, 0, v)))
+            else:
+                self.cells.append(v % R)
+                if kind == "constant":
+                    self.const_cells.append((row, v % R))
+        for off in gate_offsets:
+            self.asg.fixed[0][base + off] = 1
+        return len(self.cells) - 1
+
+    # GateInstructions
+    def mul(self, a, b):
+        return self.assign_region_last([("constant", 0), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b])], [0])
+
+    def add(self, a, b):
+        return self.assign_region_last([("existing", a), ("existing", b), ("constant", 1), ("witness", self.cells[a] + self.cells[b])], [0])
+
+    def add_constant(self, a, c):
+        return self.assign_region_last([("existing", a), ("constant", c), ("constant", 1), ("witness", self.cells[a] + c)], [0])
+
+    def mul_add_constant(self, a, b, c):
+        return self.assign_region_last([("constant", c), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b] + c)], [0])
+
+    # RangeInstructions::range_check(a, range_bits)
+    def range_check(self, a, range_bits: int, lookup_bits: int):
+        x = self.cells[a]
+        assert x < 1 << range_bits, "witness out of range"
+        num_limbs = -(-range_bits // lookup_bits)
+        limbs = [(x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1) for i in range(num_limbs)]
+        rows = [self.load_witness(limbs[0])]  # inner_product_left_last with bases[0] = 1: the first limb is the first accumulator
+        acc, acc_row = limbs[0], rows[0]
+        for i in range(1, num_limbs):  # [acc, limb_i, 2^(b i), acc'] sharing the accumulator cell: a gate every third row
+            base = len(self.cells) - 1
+            acc += limbs[i] << (lookup_bits * i)
+            self.cells.append(limbs[i])
+            rows.append(len(self.cells) - 1)
+            self.cells.append((1 << (lookup_bits * i)) % R)
+            self.const_cells.append((len(self.cells) - 1, (1 << (lookup_bits * i)) % R))
+            self.cells.append(acc % R)
+            self.asg.fixed[0][base] = 1
+            acc_row = len(self.cells) - 1
+        self.asg.copies.append(((ADVICE, 0, a), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
+        self.lookup_cells += rows
+        rem = range_bits % lookup_bits
+        if rem:  # the top limb times 2^(lookup_bits - rem) must be in the table too
+            self.lookup_cells.append(self.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
+                                                              ("witness", limbs[-1] << (lookup_bits - rem))], [0]))
+
+    def finish(self, public_rows, lookup_column=None):
+        asg = self.asg
+        asg.advice[0] = dict(enumerate(self.cells))
+        consts = {}
+        for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, in order of first use
+            if v not in consts:
+                consts[v] = len(consts)
+                asg.fixed[1][consts[v]] = v
+            asg.copies.append(((ADVICE, 0, row), (FIXED, 1, consts[v])))
+        if lookup_column is not None:
+            for i, row in enumerate(self.lookup_cells):
+                asg.advice[lookup_column][i] = self.cells[row]
+                asg.copies.append(((ADVICE, lookup_column, i), (ADVICE, 0, row)))
+        for i, row in enumerate(public_rows):  # layouter.constrain_instance(cell, instance, i): src/scaffold.rs:411, 480
+            asg.instance.append(self.cells[row])
+            asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
+
+
+def halo2_lib_closure(cs: FlexGateCS, x: int) -> Assignment:
+    """reference examples/halo2_lib.rs:14-60 `some_algorithm_in_zk`: x^2 + 72 three ways; make_public = [x, out]"""
+    asg = Assignment(cs)
+    ctx = Context(asg)
+    xc = ctx.load_witness(x)
+    x_sq = ctx.mul(xc, xc)
+    out = ctx.add_constant(x_sq, 72)
+    ctx.assign_region_last([("constant", 72), ("existing", xc), ("existing", xc), ("witness", x * x + 72)], [0])
+    ctx.mul_add_constant(xc, xc, 72)
+    ctx.finish([xc, out])
+    return asg
+
+
+def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
+    """reference examples/range.rs:10-34: make_public = [x]; range_check(x, 64); x + x.  The table column is what
+    RangeConfig::load_lookup_table assigns: 0 .. 2^LOOKUP_BITS - 1 (src/scaffold.rs:462)."""
+    asg = Assignment(cs)
+    ctx = Context(asg)
+    xc = ctx.load_witness(x)
+    ctx.range_check(xc, 64, lookup_bits)
+    ctx.add(xc, xc)
+    ctx.finish([xc], lookup_column=1)
+    asg.fixed[2] = None  # dense: filled by keygen from `table_values`
+    asg.table_values = list(range(1 << lookup_bits))
+    return asg
+
+
+# ---- keys ------------------------------------------------------------------------------------------------------------
+def _column_from_cells(n: int, cells) -> DevBuf:
+    d = DevBuf(n * 32)
+    check(lib.h2mi_memset_zero(d.ptr, n * 32), "zero")
+    if cells:
+        rows = sorted(cells)
+        lo, hi = rows[0], rows[-1] + 1
+        if hi - lo <= 4 * len(rows) + 16:  # contiguous enough: one upload
+            arr = np.zeros((hi - lo, 4), dtype=np.uint64)
+            for r in rows:
+                arr[r - lo] = _m(cells[r])
+            d.upload(arr, offset=lo * 32)
+        else:
+            for r in rows:
+                d.upload(_m(cells[r]), offset=r * 32)
+    return d
+
+
+class FlexKeys:
+    """keygen_vk + keygen_pk (src/scaffold.rs:284,287): fixed columns, sigma polynomials from the copy constraints
+    (Assembly::copy over advice, constants and instance cells alike), l_0 / l_last / l_active, the lookup table's sorted
+    form, and the verifying key's commitments."""
+
+    def __init__(self, params: ParamsKZG, cs: FlexGateCS, asg: Assignment):
+        self.cs = cs
+        k = params.k
+        self.domain = d = EvaluationDomain(cs.degree, k)
+        n = d.n
+        self.u = u = n - (cs.blinding_factors + 1)
+        fixed_cells = list(asg.fixed)
+        self.table = None
+        if cs.lookup:
+            tv = asg.table_values
+            fixed_cells[2] = dict(enumerate(tv))
+            self.table = gp.LookupTable(tv + [0] * (u - len(tv)), u)
+        self.fixed_values = [_column_from_cells(n, cells) for cells in fixed_cells]
+        m = len(cs.perm_columns)
+        index = {col: j for j, col in enumerate(cs.perm_columns)}
+        asm = PermutationAssembly()
+        for left, right in asg.copies:
+            asm.copy((index[(left[0], left[1])], left[2]), (index[(right[0], right[1])], right[2]))
+        omega_pows = DevBuf(n * 32)
+        check(lib.h2mi_fr_powers_dev(omega_pows.ptr, n, d._omega.ctypes.data, None), "powers")
+        self.sigma_values = []
+        for j in range(m):
+            col = DevBuf(n * 32)
+            ptrs = (C.c_void_p * 1)(omega_pows.ptr)
+            sc = _m(pow(FR_DELTA, j, R))
+            check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, 1, n, col.ptr, None), "identity permutation")
+            self.sigma_values.append(col)
+        for (j, i), (tj, ti) in asm.mapping.items():
+            if (j, i) != (tj, ti):
+                self.sigma_values[j].upload(_m(pow(FR_DELTA, tj, R) * pow(d.omega, ti, R) % R), offset=i * 32)
+        check(lib.h2mi_sync(), "sync")
+        omega_pows.free()
+        self.fixed_commitments = commit_points(params, self.fixed_values, lagrange=True)
+        self.permutation_commitments = commit_points(params, self.sigma_values, lagrange=True)
+        h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+        s = self.vk_bytes()
+        h.update(struct.pack("<Q", len(s)))
+        h.update(s)
+        self.transcript_repr = int.from_bytes(h.digest(), "little") % R
+        ext = d.extended_len()
+
+        def forms(col):
+            p, e = DevBuf(n * 32), DevBuf(ext * 32)
+            d.lagrange_to_coeff_oop_dev(col, p)
+            d.coeff_to_extended_oop_dev(p, e)
+            return p, e
+
+        self.fixed_polys, self.fixed_cosets = zip(*[forms(c) for c in self.fixed_values])
+        self.sigma_polys, self.sigma_cosets = zip(*[forms(c) for c in self.sigma_values])
+        lag = [DevBuf(n * 32) for _ in range(3)]
+        for b in lag[:2]:
+            check(lib.h2mi_memset_zero(b.ptr, n * 32), "zero")
+        lag[0].upload(_m(1))
+        lag[1].upload(_m(1), offset=u * 32)
+        one = _m(1)
+        check(lib.h2mi_fr_fill_dev(lag[2].ptr, n, one.ctypes.data, None), "fill")
+        check(lib.h2mi_memset_zero(lag[2].ptr + u * 32, (n - u) * 32), "zero")
+        lforms = [forms(b) for b in lag]
+        check(lib.h2mi_sync(), "sync")
+        self.l0, self.l_last, self.l_active = (e for _, e in lforms)
+        for p, _ in lforms:
+            p.free()
+        for b in lag:
+            b.free()
+
+    def vk_bytes(self) -> bytes:
+        pts = np.concatenate([self.fixed_commitments, self.permutation_commitments])
+        return struct.pack("<II", self.domain.k, self.cs.degree) + serde.g1_to_bytes(pts).tobytes()
+
+    def release(self):
+        for b in (list(self.fixed_values) + list(self.sigma_values) + list(self.fixed_polys) + list(self.fixed_cosets) + list(self.sigma_polys)
+                  + list(self.sigma_cosets) + [self.l0, self.l_last, self.l_active]):
+            b.free()
+        if self.table is not None:
+            self.table.free()
+
+
+# ---- create_proof --------------------------------------------------------------------------------------------------------
+def _write_points(points: DevBuf, transcript, k: int):
+    jac = points.to_numpy(shape=(8, 12), nbytes=96 * 8)[:k]
+    for row in jac:
+        X, Y, Z = (sum(int(row[4 * c + i]) << (64 * i) for i in range(4)) * _RINV_Q % _Q for c in range(3))
+        if Z == 0:
+            raise ValueError("cannot write points at infinity to the transcript")
+        zi = pow(Z, -1, _Q)
+        zi2 = zi * zi % _Q
+        transcript.write_point_xy(X * zi2 % _Q, Y * zi2 % _Q * zi % _Q)
+
+
+def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, transcript: Blake2bWrite = None, trace: dict = None) -> bytes:
+    """create_proof for one circuit with one instance column: scaffold::prove's call (src/scaffold.rs:322-331,
+    `&[&[&public_io]]`).  Buffers are allocated per call (the halo2-lib examples prove once)."""
+    cs, d = pk.cs, pk.domain
+    n, ext, u, bf = d.n, d.extended_len(), pk.u, cs.blinding_factors
+    transcript = transcript or Blake2bWrite.init()
+    sq = lambda: F.fr_from_mont_limbs(transcript.squeeze_challenge())
+    points = DevBuf(96 * 8)
+    held = [points]
+
+    def dev(count):
+        b = DevBuf(count * 32)
+        held.append(b)
+        return b
+
+    def commit(buf, lagrange, slot, offset_elems=0):
+        h = params.g_lagrange_handle if lagrange else params.g_handle
+        check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + offset_elems * 32, n, points.ptr + 96 * slot, None), "commit")
+
+    def forms(col):
+        p, e = dev(n), dev(ext)
+        d.lagrange_to_coeff_oop_dev(col, p)
+        d.coeff_to_extended_oop_dev(p, e)
+        return p, e
+
+    transcript.common_scalar(_m(pk.transcript_repr))
+    for v in asg.instance:  # KZG: the public inputs are hashed as scalars, not committed
+        transcript.common_scalar(_m(v))
+    instance = _column_from_cells(n, dict(enumerate(asg.instance)))
+    held.append(instance)
+    # advice columns + blinding rows
+    blind = synth.uniform_fr(cs.n_advice * (bf + 1), seed + 1)
+    advice = []
+    for j, cells in enumerate(asg.advice):
+        assert all(r < u for r in cells), "assignment reaches into the blinding rows"
+        col = _column_from_cells(n, cells)
+        held.append(col)
+        col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
+        advice.append(col)
+    for j, col in enumerate(advice):
+        commit(col, True, j)
+    _write_points(points, transcript, len(advice))
+    theta = sq()
+    # lookup: permuted input / table columns
+    lk = None
+    if cs.lookup:
+        a_perm, s_perm = dev(n), dev(n)
+        if gp.lookup_permute(d.k, advice[1], pk.table, a_perm, s_perm):
+            raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
+        lb = synth.uniform_fr(2 * (bf + 1), seed + 4)
+        a_perm.patch(lb[: bf + 1], offset=u * 32)
+        s_perm.patch(lb[bf + 1 :], offset=u * 32)
+        commit(a_perm, True, 0)
+        commit(s_perm, True, 1)
+        _write_points(points, transcript, 2)
+        lk = [a_perm, s_perm, None]
+    beta, gamma = sq(), sq()
+    # permutation argument
+    col_of = {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: [instance]}
+    perm_values = [col_of[kind][c] for kind, c in cs.perm_columns]
+    n_sets = -(-len(perm_values) // cs.chunk)
+    zs = [dev(n) for _ in range(n_sets)]
+    gp.permutation_products(d.k, perm_values, list(pk.sigma_values), cs.chunk, beta, gamma, u, zs)
+    zblind = synth.uniform_fr(n_sets * bf, seed + 2)
+    for s, z in enumerate(zs):
+        z.patch(zblind[s * bf : (s + 1) * bf], offset=(u + 1) * 32)
+    slot = 0
+    for z in zs:
+        commit(z, True, slot)
+        slot += 1
+    if cs.lookup:
+        lz = dev(n)
+        gp.lookup_product(d.k, advice[1], pk.fixed_values[2], lk[0], lk[1], beta, gamma, u, lz)
+        lz.patch(synth.uniform_fr(bf, seed + 5), offset=(u + 1) * 32)
+        lk[2] = lz
+        commit(lz, True, slot)
+        slot += 1
+    random_poly = dev(n)
+    check(lib.h2mi_fr_random_dev(random_poly.ptr, n, seed + 3, 0, None), "random_poly")
+    commit(random_poly, False, slot)
+    slot += 1
+    # coefficient / extended forms, queued behind the commitments
+    advice_f = [forms(c) for c in advice]
+    instance_f = forms(instance)
+    z_f = [forms(z) for z in zs]
+    lk_f = [forms(b) for b in lk] if cs.lookup else None
+    _write_points(points, transcript, slot)
+    y = sq()
+    # quotient
+    h = dev(ext)
+    coset_of = {ADVICE: [e for _, e in advice_f], FIXED: list(pk.fixed_cosets), INSTANCE: [instance_f[1]]}
+    gp.evaluate_h_range(d, advice_f[0][1], advice_f[1][1] if cs.lookup else None, pk.fixed_cosets[0], pk.fixed_cosets[2] if cs.lookup else None,
+                        [coset_of[kind][c] for kind, c in cs.perm_columns], list(pk.sigma_cosets), [e for _, e in z_f],
+                        lk_f[0][1] if cs.lookup else None, lk_f[1][1] if cs.lookup else None, lk_f[2][1] if cs.lookup else None,
+                        pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf)
+    d.extended_to_coeff_dev(h)
+    pieces = d.quotient_poly_degree
+    for i in range(pieces):
+        commit(h, False, i, offset_elems=i * n)
+    _write_points(points, transcript, pieces)
+    x = sq()
+    xn = pow(x, n, R)
+    rot = lambda r: x * pow(d.omega, r % n, R) % R
+    x_next, x_last, x_inv = rot(1), rot(-(bf + 1)), rot(-1)
+    h_poly = dev(n)
+    ptrs = (C.c_void_p * pieces)(*[h.ptr + i * n * 32 for i in range(pieces)])
+    sc = np.ascontiguousarray(np.stack([_m(pow(xn, i, R)) for i in range(pieces)]))
+    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, pieces, n, h_poly.ptr, None), "h_poly")
+    advice_p, z_p = [p for p, _ in advice_f], [p for p, _ in z_f]
+    written = [(advice_p[c], rot(r)) for c, r in cs.advice_queries] + [(pk.fixed_polys[c], rot(r)) for c, r in cs.fixed_queries]
+    written.append((random_poly, x))
+    written += [(sp, x) for sp in pk.sigma_polys]
+    for i, zp in enumerate(z_p):
+        written += [(zp, x), (zp, x_next)]
+        if i + 1 < len(z_p):
+            written.append((zp, x_last))
+    if cs.lookup:
+        ap, sp_, lzp = (p for p, _ in lk_f)
+        written += [(lzp, x), (lzp, x_next), (ap, x), (ap, x_inv), (sp_, x)]
+    todo = written + [(h_poly, x)]
+    evals = dev(len(todo) + 8)
+    slot_of = {}
+    for pt in dict.fromkeys(p for _, p in todo):
+        group = list(dict.fromkeys(id(poly) for poly, p in todo if p == pt))
+        by_id = {id(poly): poly for poly, p in todo if p == pt}
+        gptrs = (C.c_void_p * len(group))(*[by_id[g].ptr for g in group])
+        pt_l = _m(pt)
+        check(lib.h2mi_fr_eval_polys_dev(gptrs, len(group), n, pt_l.ctypes.data, evals.ptr + 32 * len(slot_of), None), "eval")
+        for g in group:
+            slot_of[(g, pt)] = len(slot_of)
+    ev = evals.to_numpy(shape=(len(todo) + 8, 4))
+    value = {key: F.fr_from_mont_limbs(ev[i]) for key, i in slot_of.items()}
+    for poly, pt in written:
+        transcript.write_scalar_int(value[(id(poly), pt)])
+    queries = []
+    q = lambda poly, pt: queries.append((poly, pt, value[(id(poly), pt)]))
+    for c, r in cs.advice_queries:
+        q(advice_p[c], rot(r))
+    for zp in z_p:
+        q(zp, x)
+        q(zp, x_next)
+    for zp in reversed(z_p[:-1]):
+        q(zp, x_last)
+    if cs.lookup:
+        q(lzp, x)
+        q(ap, x)
+        q(sp_, x)
+        q(ap, x_inv)
+        q(lzp, x_next)
+    for c, r in cs.fixed_queries:
+        q(pk.fixed_polys[c], rot(r))
+    for sp in pk.sigma_polys:
+        q(sp, x)
+    q(h_poly, x)
+    q(random_poly, x)
+    shplonk = ProverSHPLONK(n)
+
+    def commit_and_write(poly):
+        commit(poly, False, 0)
+        _write_points(points, transcript, 1)
+
+    shplonk.create_proof(transcript, queries, commit_and_write)
+    proof = transcript.finalize()
+    if trace is not None:
+        trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x)
+    check(lib.h2mi_sync(), "sync")
+    shplonk.release()
+    for b in held:
+        b.free()
+    return proof

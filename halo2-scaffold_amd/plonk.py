@@ -139,27 +139,34 @@ def lookup_product(k: int, d_input: DevBuf, d_table: DevBuf, d_permuted_input: D
 
 class _RangeCosets(C.Structure):
     _fields_ = [("a", C.c_void_p), ("lookup_advice", C.c_void_p), ("q", C.c_void_p), ("table", C.c_void_p), ("perm_value", C.c_void_p * 4),
-                ("perm_sigma", C.c_void_p * 4), ("perm_z", C.c_void_p * 2), ("lookup_permuted_input", C.c_void_p), ("lookup_permuted_table", C.c_void_p),
-                ("lookup_z", C.c_void_p), ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p), ("n_perm", C.c_uint32)]
+                ("perm_sigma", C.c_void_p * 4), ("perm_z", C.c_void_p * 4), ("lookup_permuted_input", C.c_void_p), ("lookup_permuted_table", C.c_void_p),
+                ("lookup_z", C.c_void_p), ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p), ("n_perm", C.c_uint32),
+                ("chunk_len", C.c_uint32), ("has_lookup", C.c_uint32)]
 
 
 def evaluate_h_range(domain: EvaluationDomain, a: DevBuf, lookup_advice: DevBuf, q: DevBuf, table: DevBuf, perm_values, perm_sigmas, perm_zs,
                      lk_input: DevBuf, lk_table: DevBuf, lk_z: DevBuf, l0: DevBuf, l_last: DevBuf, l_active: DevBuf, beta: int, gamma: int, y: int,
-                     out: DevBuf) -> None:
-    """h(X) on the extended coset (already divided by X^n - 1) for the range-check constraint system (degree 4)"""
+                     out: DevBuf, blinding_factors: int = BLINDING_FACTORS) -> None:
+    """h(X) on the extended coset (already divided by X^n - 1) for the halo2-lib constraint systems: with a lookup
+    (lookup_advice, table, lk_* given; degree 4, permutation chunks of two) or without (all of them None; degree 3, chunks of one)"""
     m = len(perm_values)
-    assert 1 <= m <= 4 and len(perm_sigmas) == m and len(perm_zs) == (m + 1) // 2
+    has_lookup = lookup_advice is not None
+    chunk = 2 if has_lookup else 1
+    assert 1 <= m <= 4 and len(perm_sigmas) == m and len(perm_zs) == -(-m // chunk)
     cs = _RangeCosets()
-    cs.a, cs.lookup_advice, cs.q, cs.table = a.ptr, lookup_advice.ptr, q.ptr, table.ptr
+    cs.a, cs.q = a.ptr, q.ptr
+    cs.chunk_len, cs.has_lookup = chunk, 1 if has_lookup else 0
+    if has_lookup:
+        cs.lookup_advice, cs.table = lookup_advice.ptr, table.ptr
+        cs.lookup_permuted_input, cs.lookup_permuted_table, cs.lookup_z = lk_input.ptr, lk_table.ptr, lk_z.ptr
     for j in range(m):
         cs.perm_value[j], cs.perm_sigma[j] = perm_values[j].ptr, perm_sigmas[j].ptr
     for s in range(len(perm_zs)):
         cs.perm_z[s] = perm_zs[s].ptr
-    cs.lookup_permuted_input, cs.lookup_permuted_table, cs.lookup_z = lk_input.ptr, lk_table.ptr, lk_z.ptr
     cs.l0, cs.l_last, cs.l_active = l0.ptr, l_last.ptr, l_active.ptr
     cs.n_perm = m
     mm = F.fr_to_mont_limbs
     t_inv = np.ascontiguousarray(vanishing_inverses(domain))
     args = [mm(beta), mm(gamma), mm(y), mm(FR_DELTA), mm(domain.g_coset), mm(domain.extended_omega)]
-    _check(lib.h2mi_plonk_evaluate_h_range_dev(C.byref(cs), domain.k, domain.extended_k, BLINDING_FACTORS, *[x.ctypes.data for x in args],
+    _check(lib.h2mi_plonk_evaluate_h_range_dev(C.byref(cs), domain.k, domain.extended_k, blinding_factors, *[x.ctypes.data for x in args],
                                                t_inv.ctypes.data, out.ptr, None), "evaluate_h_range")

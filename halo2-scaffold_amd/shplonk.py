@@ -116,7 +116,7 @@ class ProverSHPLONK:
     def __init__(self, n: int):
         """n: number of rows (coefficients per polynomial) — the domain size, not the length of an SRS slice"""
         self.n = n
-        self._nx, self._tmp, self._q = DevBuf(n * 32), DevBuf(n * 32), [DevBuf(n * 32) for _ in range(4)]
+        self._nx, self._tmp, self._q = DevBuf(n * 32), DevBuf(n * 32), [DevBuf(n * 32) for _ in range(6)]
         self.h_x, self.l_x, self.h2_x = DevBuf(n * 32), DevBuf(n * 32), DevBuf(n * 32)
 
     def release(self):

@@ -241,9 +241,11 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
  * blinding rows untouched; one field inversion per call */
 int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,
                                   uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], void* d_z, h2mi_stream_t stream);
-/* evaluate_h + vanishing division for the range-check constraint system [halo2-base shape restated from memory]: gate
- * q (a + a(wX) a(w^2 X) - a(w^3 X)), permutation argument over n_perm <= 4 columns in chunks of two (degree 4: the
- * extended domain is 4n), one lookup of `lookup_advice` in `table`.  All vectors are extended-coset evaluations. */
+/* evaluate_h + vanishing division for the halo2-lib constraint systems [halo2-base shapes restated from memory]: gate
+ * q (a + a(wX) a(w^2 X) - a(w^3 X)), permutation argument over n_perm <= 4 columns in chunks of chunk_len (= cs.degree()
+ * - 2), and — has_lookup (the Range builder: degree 4, chunk_len 2, extended domain 4n) — one lookup of `lookup_advice`
+ * in `table`; without it (the Gate builder: degree 3, chunk_len 1, extended domain 2n) the lookup pointers are unused.
+ * All vectors are extended-coset evaluations. */
 typedef struct {
   const void* a;               /* the gate's advice column */
   const void* lookup_advice;   /* the lookup input column */
@@ -251,7 +253,7 @@ typedef struct {
   const void* table;           /* fixed lookup table */
   const void* perm_value[4];   /* equality-enabled columns in argument order */
   const void* perm_sigma[4];
-  const void* perm_z[2];       /* ceil(n_perm / 2) grand products */
+  const void* perm_z[4];       /* ceil(n_perm / chunk_len) grand products */
   const void* lookup_permuted_input;
   const void* lookup_permuted_table;
   const void* lookup_z;
@@ -259,6 +261,8 @@ typedef struct {
   const void* l_last;
   const void* l_active;
   uint32_t n_perm;
+  uint32_t chunk_len;          /* 1 or 2 */
+  uint32_t has_lookup;         /* 0: gate + permutation terms only */
 } h2mi_range_cosets;
 int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* cosets, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,
                                     const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4],

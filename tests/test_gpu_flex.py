@@ -1,0 +1,137 @@
+"""GPU tests of the halo2-lib-shaped provers (BASELINE configs[2] halo2_lib and configs[3] range):
+`flex.FlexKeys` / `flex.create_proof` on the device against the oracle's data-driven prover and verifier
+(oracle/flex.py) — key material and proof bytes equal at small k, and the oracle's verifier (transcript replay, the
+constraint identity at x, SHPLONK, the pairing when asked) accepts device proofs at larger k."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as o
+from oracle import flex as FX
+from oracle import formats as fm
+
+pytestmark = pytest.mark.gpu
+
+SRS_SECRET = 0x5EC2E7 + 0x48324D49
+
+
+def _vals(buf, count):
+    return o.unpack(buf.to_numpy(shape=(count, 4), nbytes=count * 32), o.R)
+
+
+def _oracle_keys(cs, k, oasg):
+    return FX.Keys(cs, k, SRS_SECRET, oasg.fixed, oasg.copies)
+
+
+def _check_keys(keys, okeys, n):
+    assert o.unpack_points(keys.fixed_commitments) == okeys.fixed_commitments
+    assert o.unpack_points(keys.permutation_commitments) == okeys.permutation_commitments
+    assert keys.vk_bytes() == okeys.vk_bytes() and keys.transcript_repr == okeys.transcript_repr
+    for dev, want in zip(keys.sigma_values, okeys.sigma):
+        assert _vals(dev, n) == want
+    for dev, want in zip(keys.fixed_polys, okeys.fixed_polys):
+        assert _vals(dev, n) == want
+
+
+@pytest.mark.parametrize("k", [6, 9])
+def test_halo2_lib_proof_bytes_match_oracle(gpu, k):
+    """reference examples/halo2_lib.rs through scaffold::prove (src/scaffold.rs:246-366) with DEGREE = k: the circuit's
+    cells, the keys and the proof, byte for byte; the oracle's verifier accepts it with the public inputs [x, x^2 + 72]
+    and rejects it with others."""
+    from halo2_scaffold_amd import flex
+
+    x, seed = 12, 2024
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=False)
+    asg = flex.halo2_lib_closure(cs, x)
+    ocs = FX.flex_gate_cs(False)
+    oasg = FX.halo2_lib_assignment(ocs, x)
+    assert asg.advice == oasg.advice and asg.fixed == oasg.fixed and asg.copies == oasg.copies and [asg.instance] == oasg.instance
+    assert asg.instance == [x, x * x + 72]
+    keys = flex.FlexKeys(params, cs, asg)
+    okeys = _oracle_keys(ocs, k, oasg)
+    _check_keys(keys, okeys, 1 << k)
+    trace = {}
+    proof = flex.create_proof(params, keys, asg, seed, trace=trace)
+    want = FX.prove(okeys, oasg, seed)
+    for name in ("theta", "beta", "gamma", "y", "x"):
+        assert trace[name] == want[name], name
+    assert proof == want["proof"]
+    assert len(proof) == 864
+    assert FX.verify(okeys, proof, [asg.instance])
+    assert not FX.verify(okeys, proof, [[x, x * x + 73]])
+    keys.release()
+    params.release()
+
+
+@pytest.mark.parametrize("k,lookup_bits,x", [(7, 4, 0xDEADBEEFCAFE1234), (8, 7, (1 << 64) - 1), (8, 6, 0)])
+def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
+    """reference examples/range.rs: range_check(x, 64) with LOOKUP_BITS limbs (64 is a multiple of 4 but not of 7 or 6:
+    the top-limb shift cell is exercised), lookup argument and all."""
+    from halo2_scaffold_amd import flex
+
+    seed = 99
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(cs, x, lookup_bits)
+    ocs = FX.flex_gate_cs(True)
+    oasg = FX.range_assignment(ocs, x, lookup_bits, 1 << k)
+    assert asg.advice == oasg.advice and asg.fixed[:2] == oasg.fixed[:2] and asg.copies == oasg.copies and [asg.instance] == oasg.instance
+    keys = flex.FlexKeys(params, cs, asg)
+    okeys = _oracle_keys(ocs, k, oasg)
+    _check_keys(keys, okeys, 1 << k)
+    trace = {}
+    proof = flex.create_proof(params, keys, asg, seed, trace=trace)
+    want = FX.prove(okeys, oasg, seed)
+    for name in ("theta", "beta", "gamma", "y", "x"):
+        assert trace[name] == want[name], name
+    assert proof == want["proof"]
+    assert len(proof) == 1152
+    assert FX.verify(okeys, proof, [asg.instance])
+    bad = bytearray(proof)
+    bad[700] ^= 1
+    assert not FX.verify(okeys, bytes(bad), [asg.instance])
+    keys.release()
+    params.release()
+
+
+def test_range_rejects_out_of_range_witness(gpu):
+    """a lookup-advice cell that is not a table value: the crate's permute_expression_pair fails the proof; so does
+    the device's counting sort (no proof is produced)."""
+    from halo2_scaffold_amd import flex
+
+    params = gpu.ParamsKZG.setup(7, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(cs, 1234567, 4)
+    keys = flex.FlexKeys(params, cs, asg)
+    asg.advice[1][2] = 16  # one past the 4-bit table
+    with pytest.raises(ValueError, match="not in the table"):
+        flex.create_proof(params, keys, asg, 5)
+    keys.release()
+    params.release()
+
+
+@pytest.mark.parametrize("k,lookup_bits", [(12, 11), (13, 8)])
+def test_range_proof_verifies_at_larger_k(gpu, k, lookup_bits):
+    """sizes the pure-Python prover does not reach in seconds: the oracle's verifier needs only the verifying key
+    (commitments in closed form through the SRS scalars) and the proof.  k = 13 finishes with the real pairing check
+    against the SRS's G2 elements, as the reference's verify_proof does."""
+    from halo2_scaffold_amd import flex
+
+    x, seed = 0x0123456789ABCDEF, 31337
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(cs, x, lookup_bits)
+    keys = flex.FlexKeys(params, cs, asg)
+    proof = flex.create_proof(params, keys, asg, seed)
+    ocs = FX.flex_gate_cs(True)
+    oasg = FX.range_assignment(ocs, x, lookup_bits, 1 << k)
+    okeys = _oracle_keys(ocs, k, oasg)
+    assert keys.vk_bytes() == okeys.vk_bytes()
+    if k == 13:
+        g2, s_g2 = fm.G2_GEN, fm.g2_mul(SRS_SECRET)
+        assert FX.verify(okeys, proof, [asg.instance], g2=g2, s_g2=s_g2)
+    else:
+        assert FX.verify(okeys, proof, [asg.instance])
+    assert not FX.verify(okeys, proof, [[x + 1]])
+    keys.release()
+    params.release()
