@@ -142,6 +142,20 @@ class _Ctx:
             asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
 
 
+def standard_plonk_assignment(cs, x):
+    """src/circuits/standard_plonk.rs:83-108 as cells (the same rows oracle/plonk.py::StandardPlonkInstance fills)"""
+    asg = Assignment(cs)
+    x %= R
+    asg.advice[0].update({0: x, 1: x, 2: x})
+    asg.advice[1].update({1: x, 2: x})
+    asg.advice[2].update({1: x * x % R, 2: (x * x + 72) % R})
+    asg.fixed[2].update({1: R - 1, 2: R - 1})
+    asg.fixed[3].update({1: 1, 2: 1})
+    asg.fixed[4].update({2: 72})
+    asg.copies = [((ADVICE, l[0], l[1]), (ADVICE, r[0], r[1])) for l, r in P.STANDARD_PLONK_COPIES]
+    return asg
+
+
 def halo2_lib_assignment(cs, x):
     """examples/halo2_lib.rs:14-60: x^2 + 72 three ways; public: x and out"""
     asg = Assignment(cs)
@@ -193,6 +207,69 @@ def range_assignment(cs, x, lookup_bits, n):
 
 
 # ---- keygen ----------------------------------------------------------------------------------------------------------
+def _assembly(cs, copies):
+    """permutation/keygen.rs Assembly::copy on (argument column index, row) -> {cell: next cell of its cycle}"""
+    index = {col: j for j, col in enumerate(cs.perm_columns)}
+    asm = {}
+    aux, sizes = {}, {}
+    g = lambda d, c: d.get(c, c)
+    for left, right in copies:
+        lc_, rc_ = (index[(left[0], left[1])], left[2]), (index[(right[0], right[1])], right[2])
+        lcy, rcy = g(aux, lc_), g(aux, rc_)
+        if lcy == rcy:
+            continue
+        if sizes.get(lcy, 1) < sizes.get(rcy, 1):
+            lcy, rcy = rcy, lcy
+        sizes[lcy] = sizes.get(lcy, 1) + sizes.get(rcy, 1)
+        i = rcy
+        while True:
+            aux[i] = lcy
+            i = g(asm, i)
+            if i == rcy:
+                break
+        asm[lc_], asm[rc_] = g(asm, rc_), g(asm, lc_)
+    return asm
+
+
+def _vk_transcript_repr(k, degree, commitments):
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    s = bytearray(struct.pack("<II", k, degree))
+    for c in commitments:
+        s += fmt.g1_to_bytes(c)
+    h.update(struct.pack("<Q", len(s)))
+    h.update(bytes(s))
+    return int.from_bytes(h.digest(), "little") % R
+
+
+class VerifierKeys:
+    """the verifying-key part of `Keys` in closed form, in time proportional to the assigned cells instead of n (so
+    that `verify` can check device proofs at sizes where building the columns in Python takes minutes): with
+    L_i(s) = (s^n - 1) / n * w^i / (s - w^i), a fixed column commits to sum cells[i] L_i(s), and the identity
+    permutation column j to DELTA^j s (sum_i w^i L_i(X) = X), corrected at the cells the copy constraints move."""
+
+    def __init__(self, cs, k, s, asg_fixed, copies):
+        self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
+        n = self.n
+        self.dom = o.Domain(k, cs.degree)
+        w = self.dom.omega
+        sn1 = (pow(s, n, R) - 1) * pow(n, -1, R) % R
+        cache = {}
+
+        def lag(i):
+            if i not in cache:
+                wi = pow(w, i, R)
+                cache[i] = sn1 * wi % R * pow((s - wi) % R, -1, R) % R
+            return cache[i]
+
+        self.fixed_commitments = [o.g1_mul(sum(v * lag(i) for i, v in cells.items()) % R, o.G1_GEN) for cells in asg_fixed]
+        ident = lambda j, i: pow(P.FR_DELTA, j, R) * pow(w, i, R) % R
+        acc = [pow(P.FR_DELTA, j, R) * s % R for j in range(len(cs.perm_columns))]
+        for (j, i), t in _assembly(cs, copies).items():
+            acc[j] = (acc[j] + (ident(*t) - ident(j, i)) * lag(i)) % R
+        self.permutation_commitments = [o.g1_mul(a, o.G1_GEN) for a in acc]
+        self.transcript_repr = _vk_transcript_repr(k, cs.degree, self.fixed_commitments + self.permutation_commitments)
+
+
 class Keys:
     def __init__(self, cs, k, s, asg_fixed, copies):
         self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
@@ -207,25 +284,7 @@ class Keys:
             self.omega_pows[i] = self.omega_pows[i - 1] * w % R
         m = len(cs.perm_columns)
         self.dpow = [pow(P.FR_DELTA, j, R) for j in range(m)]
-        index = {col: j for j, col in enumerate(cs.perm_columns)}
-        asm = {}
-        aux, sizes = {}, {}
-        g = lambda d, c: d.get(c, c)
-        for left, right in copies:  # permutation/keygen.rs Assembly::copy on (argument column index, row)
-            lc_, rc_ = (index[(left[0], left[1])], left[2]), (index[(right[0], right[1])], right[2])
-            lcy, rcy = g(aux, lc_), g(aux, rc_)
-            if lcy == rcy:
-                continue
-            if sizes.get(lcy, 1) < sizes.get(rcy, 1):
-                lcy, rcy = rcy, lcy
-            sizes[lcy] = sizes.get(lcy, 1) + sizes.get(rcy, 1)
-            i = rcy
-            while True:
-                aux[i] = lcy
-                i = g(asm, i)
-                if i == rcy:
-                    break
-            asm[lc_], asm[rc_] = g(asm, rc_), g(asm, lc_)
+        asm = _assembly(cs, copies)
         ident = lambda j, i: self.dpow[j] * self.omega_pows[i] % R
         self.sigma = [[ident(j, i) for i in range(n)] for j in range(m)]
         for (j, i), (tj, ti) in asm.items():

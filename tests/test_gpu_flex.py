@@ -110,11 +110,14 @@ def test_range_rejects_out_of_range_witness(gpu):
     params.release()
 
 
-@pytest.mark.parametrize("k,lookup_bits", [(12, 11), (13, 8)])
+@pytest.mark.parametrize("k,lookup_bits", [(12, 11), (13, 8), (22, 16)])
 def test_range_proof_verifies_at_larger_k(gpu, k, lookup_bits):
-    """sizes the pure-Python prover does not reach in seconds: the oracle's verifier needs only the verifying key
-    (commitments in closed form through the SRS scalars) and the proof.  k = 13 finishes with the real pairing check
-    against the SRS's G2 elements, as the reference's verify_proof does."""
+    """sizes the pure-Python prover does not reach: the oracle's verifier needs only the verifying key (closed form:
+    FX.VerifierKeys, time proportional to the assigned cells) and the proof.  k = 22 with LOOKUP_BITS = 16 is BASELINE
+    configs[3]'s circuit on one device; k = 13 finishes with the real pairing check against the SRS's G2 elements, as
+    the reference's verify_proof does."""
+    import time
+
     from halo2_scaffold_amd import flex
 
     x, seed = 0x0123456789ABCDEF, 31337
@@ -122,16 +125,42 @@ def test_range_proof_verifies_at_larger_k(gpu, k, lookup_bits):
     cs = flex.FlexGateCS(lookup=True)
     asg = flex.range_closure(cs, x, lookup_bits)
     keys = flex.FlexKeys(params, cs, asg)
+    t0 = time.perf_counter()
     proof = flex.create_proof(params, keys, asg, seed)
+    print(f"range k={k} lookup_bits={lookup_bits}: create_proof {1e3 * (time.perf_counter() - t0):.1f} ms (first call, buffers allocated inside)")
     ocs = FX.flex_gate_cs(True)
     oasg = FX.range_assignment(ocs, x, lookup_bits, 1 << k)
-    okeys = _oracle_keys(ocs, k, oasg)
-    assert keys.vk_bytes() == okeys.vk_bytes()
+    vk = FX.VerifierKeys(ocs, k, SRS_SECRET, oasg.fixed, oasg.copies)
+    assert keys.vk_bytes()[8:] == b"".join(fm.g1_to_bytes(c) for c in vk.fixed_commitments + vk.permutation_commitments)
+    assert keys.transcript_repr == vk.transcript_repr
     if k == 13:
-        g2, s_g2 = fm.G2_GEN, fm.g2_mul(SRS_SECRET)
-        assert FX.verify(okeys, proof, [asg.instance], g2=g2, s_g2=s_g2)
+        assert FX.verify(vk, proof, [asg.instance], g2=fm.G2_GEN, s_g2=fm.g2_mul(SRS_SECRET))
     else:
-        assert FX.verify(okeys, proof, [asg.instance])
-    assert not FX.verify(okeys, proof, [[x + 1]])
+        assert FX.verify(vk, proof, [asg.instance])
+    assert not FX.verify(vk, proof, [[x + 1]])
+    keys.release()
+    params.release()
+
+
+def test_halo2_lib_proof_verifies_at_degree_20(gpu):
+    """BASELINE configs[2]: examples/halo2_lib.rs at DEGREE = 20"""
+    import time
+
+    from halo2_scaffold_amd import flex
+
+    k, x, seed = 20, 0xC0FFEE, 4242
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=False)
+    asg = flex.halo2_lib_closure(cs, x)
+    keys = flex.FlexKeys(params, cs, asg)
+    t0 = time.perf_counter()
+    proof = flex.create_proof(params, keys, asg, seed)
+    print(f"halo2_lib k={k}: create_proof {1e3 * (time.perf_counter() - t0):.1f} ms")
+    ocs = FX.flex_gate_cs(False)
+    oasg = FX.halo2_lib_assignment(ocs, x)
+    vk = FX.VerifierKeys(ocs, k, SRS_SECRET, oasg.fixed, oasg.copies)
+    assert keys.transcript_repr == vk.transcript_repr
+    assert FX.verify(vk, proof, [asg.instance])
+    assert not FX.verify(vk, proof, [[x, x * x + 71]])
     keys.release()
     params.release()

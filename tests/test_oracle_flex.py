@@ -1,0 +1,91 @@
+"""CPU tests of oracle/flex.py, the data-driven restatement of keygen / create_proof / verify_proof that checks the
+device provers of the halo2-lib shapes (tests/test_gpu_flex.py).  The engine is pinned three ways: run on the
+StandardPlonk constraint system it must reproduce the committed golden proofs of the dedicated oracle byte for byte;
+its verifier accepts its proofs and rejects tampered ones / other public inputs (with the pairing too); and its
+closed-form verifying key equals the one built from full columns."""
+import json
+import os
+
+import pytest
+
+from oracle import flex as FX
+from oracle import formats as fm
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "standard_plonk_proofs.json")
+
+
+def test_engine_reproduces_standard_plonk_golden_proofs():
+    g = json.load(open(GOLDEN))
+    s = int(g["srs_secret"], 16)
+    case = next(c for c in g["cases"] if c["k"] == 5)  # the reference's own size (examples/standard_plonk.rs:26)
+    cs = FX.standard_plonk_cs()
+    asg = FX.standard_plonk_assignment(cs, int(case["witness_x"], 16) if isinstance(case["witness_x"], str) else case["witness_x"])
+    keys = FX.Keys(cs, 5, s, asg.fixed, asg.copies)
+    assert keys.vk_bytes().hex() == case["vk_bytes"]
+    out = FX.prove(keys, asg, case["seed"])
+    assert out["proof"].hex() == case["proof"]
+    assert FX.verify(keys, out["proof"], [])
+
+
+def test_halo2_lib_prove_verify():
+    """examples/halo2_lib.rs: public inputs [x, x^2 + 72]; 27 proof elements (1 advice, 3 z, random, 2 h pieces, 6 + 2 +
+    1 + 3 + 8 evaluations... = 864 bytes)"""
+    x, k, s = 12, 6, 0xABCDEF123
+    cs = FX.flex_gate_cs(False)
+    asg = FX.halo2_lib_assignment(cs, x)
+    assert asg.instance == [[12, 216]]
+    assert sorted(asg.fixed[0]) == [1, 5, 9, 13]  # the four gates: mul, add, the raw region, mul_add
+    assert asg.fixed[1] == {0: 0, 1: 72, 2: 1}   # constants in order of first use
+    keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
+    proof = FX.prove(keys, asg, 11)["proof"]
+    assert len(proof) == 864
+    assert FX.verify(keys, proof, asg.instance)
+    assert not FX.verify(keys, proof, [[12, 217]])
+    assert not FX.verify(keys, proof[:-1], asg.instance) and not FX.verify(keys, proof + b"\0", asg.instance)
+    for pos in (3, 40, 300, 700, 863):
+        bad = bytearray(proof)
+        bad[pos] ^= 4
+        assert not FX.verify(keys, bytes(bad), asg.instance), pos
+    # a witness that breaks the gate: no valid proof comes out
+    asg.advice[0][4] = (asg.advice[0][4] + 1) % FX.R
+    assert not FX.verify(keys, FX.prove(keys, asg, 11)["proof"], asg.instance)
+
+
+@pytest.mark.parametrize("lookup_bits,x", [(4, 0xDEADBEEFCAFE1234), (7, (1 << 64) - 1)])
+def test_range_prove_verify(lookup_bits, x):
+    """examples/range.rs with LOOKUP_BITS in place of the reference's (src/scaffold.rs:44-48 reads it from the
+    environment): 64 / 4 = 16 limbs, or ten 7-bit limbs with the top one shifted by 6 bits into the table as well"""
+    k, s = 8, 0x77665544
+    cs = FX.flex_gate_cs(True)
+    asg = FX.range_assignment(cs, x, lookup_bits, 1 << k)
+    limbs = -(-64 // lookup_bits)
+    assert len(asg.advice[1]) == limbs + (1 if 64 % lookup_bits else 0)
+    assert all(v < 1 << lookup_bits for v in asg.advice[1].values())
+    keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
+    vk = FX.VerifierKeys(cs, k, s, asg.fixed, asg.copies)
+    assert vk.fixed_commitments == keys.fixed_commitments and vk.permutation_commitments == keys.permutation_commitments
+    assert vk.transcript_repr == keys.transcript_repr
+    proof = FX.prove(keys, asg, 5)["proof"]
+    assert len(proof) == 1152
+    assert FX.verify(vk, proof, asg.instance)
+    assert not FX.verify(vk, proof, [[(x + 1) % (1 << 64)]])
+    bad = bytearray(proof)
+    bad[900] ^= 1
+    assert not FX.verify(vk, bytes(bad), asg.instance)
+    # a limb outside the table: permute_expression_pair refuses (the crate returns ConstraintSystemFailure)
+    asg.advice[1][0] = 1 << lookup_bits
+    with pytest.raises(Exception):
+        FX.prove(keys, asg, 5)
+
+
+def test_verify_with_pairing():
+    """the final SHPLONK equation through the SRS's G2 elements (what the reference's verifier does) agrees with the
+    known-secret form"""
+    k, s = 6, 0x1234567
+    cs = FX.flex_gate_cs(False)
+    asg = FX.halo2_lib_assignment(cs, 3)
+    keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
+    proof = FX.prove(keys, asg, 1)["proof"]
+    g2, s_g2 = fm.G2_GEN, fm.g2_mul(s)
+    assert FX.verify(keys, proof, asg.instance, g2=g2, s_g2=s_g2)
+    assert not FX.verify(keys, proof, asg.instance, g2=g2, s_g2=fm.g2_mul(s + 1))
