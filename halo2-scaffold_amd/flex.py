@@ -176,8 +176,8 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
 
 
 # ---- keys ------------------------------------------------------------------------------------------------------------
-def _column_from_cells(n: int, cells) -> DevBuf:
-    d = DevBuf(n * 32)
+def _column_from_cells(n: int, cells, into: DevBuf = None) -> DevBuf:
+    d = into if into is not None else DevBuf(n * 32)
     check(lib.h2mi_memset_zero(d.ptr, n * 32), "zero")
     if cells:
         rows = sorted(cells)
@@ -276,8 +276,45 @@ class FlexKeys:
 
 
 # ---- create_proof --------------------------------------------------------------------------------------------------------
-def _write_points(points: DevBuf, transcript, k: int):
-    jac = points.to_numpy(shape=(8, 12), nbytes=96 * 8)[:k]
+class FlexWorkspace:
+    """device buffers of one create_proof, kept for the next one against the same proving key (the reference's
+    drivers prove repeatedly against one pk / SRS, e.g. examples/linear_regression.rs:126-195): create_proof takes
+    its buffers in a fixed order with fixed sizes, so the pool hands the i-th request the i-th buffer.
+    combiner: a dist.PhaseCombiner with >= 8 slots when `params` is one rank's slice of the SRS (one process per GPU):
+    every commitment is then this rank's partial point, combined across ranks at every transcript write."""
+
+    def __init__(self, params: ParamsKZG, pk: "FlexKeys", combiner=None):
+        self.combiner = combiner
+        self.points = DevBuf(96 * 8)
+        self._pool, self._cursor = [], 0
+        self.shplonk = ProverSHPLONK(pk.domain.n)
+
+    def begin(self):
+        self._cursor = 0
+
+    def take(self, count: int) -> DevBuf:
+        if self._cursor == len(self._pool):
+            self._pool.append(DevBuf(count * 32))
+        b = self._pool[self._cursor]
+        assert b.nbytes == count * 32, "workspace reused with another proving key"
+        self._cursor += 1
+        return b
+
+    def release(self):
+        for b in self._pool + [self.points]:
+            b.free()
+        self.shplonk.release()
+
+
+def _write_points(ws: FlexWorkspace, transcript, k: int):
+    """fetch the k Jacobian results of a phase (the copy joins the MSM pipeline; with a sliced SRS: all-gather + fold of
+    the partial points first), normalise on the host, write to the transcript"""
+    if ws.combiner is not None:
+        check(lib.h2mi_join(), "join")
+        ws.combiner.combine(0, k)
+        jac = ws.combiner.combined.to_numpy(shape=(ws.combiner.slots, 12))[:k]
+    else:
+        jac = ws.points.to_numpy(shape=(8, 12), nbytes=96 * 8)[:k]
     for row in jac:
         X, Y, Z = (sum(int(row[4 * c + i]) << (64 * i) for i in range(4)) * _RINV_Q % _Q for c in range(3))
         if Z == 0:
@@ -287,24 +324,23 @@ def _write_points(points: DevBuf, transcript, k: int):
         transcript.write_point_xy(X * zi2 % _Q, Y * zi2 % _Q * zi % _Q)
 
 
-def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, transcript: Blake2bWrite = None, trace: dict = None) -> bytes:
+def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, transcript: Blake2bWrite = None, trace: dict = None,
+                 ws: FlexWorkspace = None) -> bytes:
     """create_proof for one circuit with one instance column: scaffold::prove's call (src/scaffold.rs:322-331,
-    `&[&[&public_io]]`).  Buffers are allocated per call (the halo2-lib examples prove once)."""
+    `&[&[&public_io]]`).  `params` is the whole SRS, or one rank's slice of it together with ws.combiner."""
     cs, d = pk.cs, pk.domain
     n, ext, u, bf = d.n, d.extended_len(), pk.u, cs.blinding_factors
     transcript = transcript or Blake2bWrite.init()
     sq = lambda: F.fr_from_mont_limbs(transcript.squeeze_challenge())
-    points = DevBuf(96 * 8)
-    held = [points]
-
-    def dev(count):
-        b = DevBuf(count * 32)
-        held.append(b)
-        return b
+    own_ws = ws is None
+    ws = ws or FlexWorkspace(params, pk)
+    ws.begin()
+    dev = ws.take
+    out_base = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
 
     def commit(buf, lagrange, slot, offset_elems=0):
         h = params.g_lagrange_handle if lagrange else params.g_handle
-        check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + offset_elems * 32, n, points.ptr + 96 * slot, None), "commit")
+        check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + (offset_elems + params.lo) * 32, params.n, out_base + 96 * slot, None), "commit")
 
     def forms(col):
         p, e = dev(n), dev(ext)
@@ -315,33 +351,33 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     transcript.common_scalar(_m(pk.transcript_repr))
     for v in asg.instance:  # KZG: the public inputs are hashed as scalars, not committed
         transcript.common_scalar(_m(v))
-    instance = _column_from_cells(n, dict(enumerate(asg.instance)))
-    held.append(instance)
+    instance = _column_from_cells(n, dict(enumerate(asg.instance)), into=dev(n))
     # advice columns + blinding rows
     blind = synth.uniform_fr(cs.n_advice * (bf + 1), seed + 1)
     advice = []
     for j, cells in enumerate(asg.advice):
         assert all(r < u for r in cells), "assignment reaches into the blinding rows"
-        col = _column_from_cells(n, cells)
-        held.append(col)
+        col = _column_from_cells(n, cells, into=dev(n))
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
         advice.append(col)
     for j, col in enumerate(advice):
         commit(col, True, j)
-    _write_points(points, transcript, len(advice))
+    _write_points(ws, transcript, len(advice))
     theta = sq()
     # lookup: permuted input / table columns
     lk = None
     if cs.lookup:
         a_perm, s_perm = dev(n), dev(n)
         if gp.lookup_permute(d.k, advice[1], pk.table, a_perm, s_perm):
+            if own_ws:
+                ws.release()
             raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
         lb = synth.uniform_fr(2 * (bf + 1), seed + 4)
         a_perm.patch(lb[: bf + 1], offset=u * 32)
         s_perm.patch(lb[bf + 1 :], offset=u * 32)
         commit(a_perm, True, 0)
         commit(s_perm, True, 1)
-        _write_points(points, transcript, 2)
+        _write_points(ws, transcript, 2)
         lk = [a_perm, s_perm, None]
     beta, gamma = sq(), sq()
     # permutation argument
@@ -373,7 +409,7 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     instance_f = forms(instance)
     z_f = [forms(z) for z in zs]
     lk_f = [forms(b) for b in lk] if cs.lookup else None
-    _write_points(points, transcript, slot)
+    _write_points(ws, transcript, slot)
     y = sq()
     # quotient
     h = dev(ext)
@@ -386,7 +422,7 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     pieces = d.quotient_poly_degree
     for i in range(pieces):
         commit(h, False, i, offset_elems=i * n)
-    _write_points(points, transcript, pieces)
+    _write_points(ws, transcript, pieces)
     x = sq()
     xn = pow(x, n, R)
     rot = lambda r: x * pow(d.omega, r % n, R) % R
@@ -442,18 +478,16 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         q(sp, x)
     q(h_poly, x)
     q(random_poly, x)
-    shplonk = ProverSHPLONK(n)
 
     def commit_and_write(poly):
         commit(poly, False, 0)
-        _write_points(points, transcript, 1)
+        _write_points(ws, transcript, 1)
 
-    shplonk.create_proof(transcript, queries, commit_and_write)
+    ws.shplonk.create_proof(transcript, queries, commit_and_write)
     proof = transcript.finalize()
     if trace is not None:
         trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x)
     check(lib.h2mi_sync(), "sync")
-    shplonk.release()
-    for b in held:
-        b.free()
+    if own_ws:
+        ws.release()
     return proof

@@ -164,3 +164,32 @@ def test_halo2_lib_proof_verifies_at_degree_20(gpu):
     assert not FX.verify(vk, proof, [[x, x * x + 71]])
     keys.release()
     params.release()
+
+
+def test_workspace_reuse_and_sliced_srs_world2(gpu):
+    """tools/flex_proof.py: repeated proofs against one pk reuse the workspace's buffers; with two ranks sharing this GPU
+    over gloo each commitment is a slice MSM combined at every transcript write, and both ranks end with the single-
+    process proof (BASELINE configs[3]'s partition, rehearsed at k = 13)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["tools/flex_proof.py", "--shape", "range", "--k", "13", "--lookup-bits", "8", "--proofs", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r1 = subprocess.run([sys.executable] + common, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["proof_bytes"] == 1152 and one["combines_per_proof"] == 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + common + ["--gpus", "2"]
+    r2 = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=dict(env, H2MI_DIST_BACKEND="gloo", H2MI_DEVICE="0"))
+    assert r2.returncode == 0, r2.stdout[-1000:] + r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["proof_sha256"] == one["proof_sha256"]
+    assert two["combines_per_proof"] == 6  # advice; permuted columns; z, lookup z, random; h pieces; the two SHPLONK commitments
