@@ -493,12 +493,29 @@ __global__ void __launch_bounds__(256) k_fr_random(fe* out, size_t n, uint64_t s
 
 // ---- quotient numerator of the reference's StandardPlonk circuit -------------------------
 // halo2_proofs plonk/evaluation.rs `evaluate_h` specialised to src/circuits/standard_plonk.rs: one gate
-// q_a a + q_b b + q_c c + q_ab a b + constant, three permutation sets of one column each; terms combined by
-// Horner in y; result already divided by X^n - 1 (its inverse on the coset repeats with period 2^(ext_k-k)).
-// Element-wise over the extended domain; all vectors stay in HBM.  Montgomery-2^256 throughout (fp.cuh):
-// products of two data values need one closed domain.
+// q_a a + q_b b + q_c c + q_ab a b + constant, three permutation sets of one column each; terms combined with
+// powers of y; result already divided by X^n - 1 (its inverse on the coset repeats with period 2^(ext_k-k)).
+// Element-wise over the extended domain; all vectors stay in HBM.
+//
+// Arithmetic: the lazy 29-bit-limb layer (f29.cuh) on the Montgomery-2^256 words as they lie in memory, WITHOUT
+// converting them to its own radix.  f29_mul divides by 2^261, so the product of two memory-format values
+// x 2^256, y 2^256 is x y 2^256 2^-5: every data-by-data product leaves one stray factor 2^-5.  Call a value "level L"
+// when its limbs hold x 2^256 2^(-5 L): data and plain challenges are level 0, mul(level L1, level L2) is level
+// L1 + L2 + 1, sums need equal levels.  The stray factors are paid by the HOST: h = sum_i y^(N-1-i) term_i is
+// evaluated term by term (as many multiplications as Horner's rule), and the constant y^(N-1-i) for term i is
+// handed over already multiplied by the power of 2^5 that brings this term back to level 0 — constants at negative
+// levels (level -1 = the Montgomery-2^261 form: a multiplication by it keeps the level).  Terms that share a
+// Lagrange factor (l_0, l_last, l_active) are summed before the one multiplication by it.  32 multiplications of
+// ~210 instructions per point, against 36 of ~380 in the 32-bit-limb layer this kernel used before.
 struct TInv {  // (X^n - 1)^-1 on the extended coset: 2^(extended_k - k) <= 16 distinct values
   fe v[16];
+};
+struct HConsts {
+  fe beta_m1;            // beta at level -1: beta * sigma lands on level 0
+  fe beta0, gamma0, one0;  // level 0: the plain Montgomery-2^256 words
+  fe cur[4];             // beta zeta DELTA^j at level 0: times X (level -1, straight from the power table) = level 0
+  fe y[20];              // per-term powers of y at the level each use needs (layout: see the kernels / fill_* below)
+  fe tinv[16];           // level -1
 };
 struct PlonkCosets {
   const fe* advice[3];
@@ -509,41 +526,56 @@ struct PlonkCosets {
   const fe* l_last;
   const fe* l_active;
 };
-__global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma,
-                                                                    fe y, fe delta, fe zeta, const fe* xlo, const fe* xhi, uint32_t xh,
-                                                                    TInv t_inv, fe* out) {
+__device__ __forceinline__ f29 hc(const fe& c) { return f29_unpack(c.v); }
+__device__ __forceinline__ f29 hmul(const f29& a_lazy, const f29& b_norm) { return f29_mul<F9>(a_lazy, b_norm); }
+// a - b + 2p, normalized (b normalized, value < 2p)
+__device__ __forceinline__ f29 hsub(const f29& a, const f29& b) { return f29_normalize(f29_sub(a, b, F9::K2)); }
+__device__ __forceinline__ void hstore(fe* dst, const f29& acc_lazy, const fe& tinv) {  // acc: lazy sum of <= 7 normalized values
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(f29_normalize(acc_lazy), hc(tinv))), o.v);
+  fe_store(dst, o);
+}
+
+// y[] layout: [0] gate's q.a terms (level -2), [1] its q_ab a b term (-3), [2] its constant (-1), all times y^7;
+// [3] [4] [5] the l_0 terms 1, 3, 4 (level -2); [6] the l_last term 2 (-3); [7] [8] [9] the permutation terms 5, 6, 7 (-3)
+__global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h,
+                                                                    const fe* xlo, const fe* xhi, uint32_t xh, fe* out) {
   const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
   uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= size) return;
   const uint32_t r_next = (idx + rot) & (size - 1), r_last = (idx + size - last_rot * rot) & (size - 1);
-  fe a = fe_load(&c.advice[0][idx]), b = fe_load(&c.advice[1][idx]), cc = fe_load(&c.advice[2][idx]);
-  fe v = fe_mul<Fr>(fe_load(&c.fixed[0][idx]), a);
-  v = fe_add<Fr>(v, fe_mul<Fr>(fe_load(&c.fixed[1][idx]), b));
-  v = fe_add<Fr>(v, fe_mul<Fr>(fe_load(&c.fixed[2][idx]), cc));
-  v = fe_add<Fr>(v, fe_mul<Fr>(fe_mul<Fr>(fe_load(&c.fixed[3][idx]), a), b));
-  v = fe_add<Fr>(v, fe_load(&c.fixed[4][idx]));
-  fe z0 = fe_load(&c.z[0][idx]), z1 = fe_load(&c.z[1][idx]), z2 = fe_load(&c.z[2][idx]);
-  fe l0 = fe_load(&c.l0[idx]), ll = fe_load(&c.l_last[idx]), la = fe_load(&c.l_active[idx]);
-  const fe one = fe_one<Fr>();
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, z0), l0));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z2), z2), ll));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z1, fe_load(&c.z[0][r_last])), l0));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(z2, fe_load(&c.z[1][r_last])), l0));
-  // X = zeta * extended_omega^idx ; current_delta = beta * X * DELTA^m
-  fe X;
-  f29_to_mont256<F9>(pow2tab(xlo, xhi, xh, idx), X.v);
-  fe cur = fe_mul<Fr>(beta, fe_mul<Fr>(zeta, X));
-  const fe adv[3] = {a, b, cc};
-  const fe zs[3] = {z0, z1, z2};
-#pragma unroll
-  for (int m = 0; m < 3; m++) {
-    fe left = fe_mul<Fr>(fe_load(&c.z[m][r_next]), fe_add<Fr>(fe_add<Fr>(adv[m], fe_mul<Fr>(beta, fe_load(&c.sigma[m][idx]))), gamma));
-    fe right = fe_mul<Fr>(zs[m], fe_add<Fr>(fe_add<Fr>(adv[m], cur), gamma));
-    cur = fe_mul<Fr>(cur, delta);
-    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la));
+  const f29 adv[3] = {load_unpack(&c.advice[0][idx]), load_unpack(&c.advice[1][idx]), load_unpack(&c.advice[2][idx])};
+  // gate
+  f29 g1 = f29_add(f29_add(hmul(load_unpack(&c.fixed[0][idx]), adv[0]), hmul(load_unpack(&c.fixed[1][idx]), adv[1])),
+                   hmul(load_unpack(&c.fixed[2][idx]), adv[2]));                                  // level 1, lazy
+  f29 g2 = hmul(hmul(load_unpack(&c.fixed[3][idx]), adv[0]), adv[1]);                               // level 2
+  f29 acc = f29_add(f29_add(hmul(g1, hc(h.y[0])), hmul(g2, hc(h.y[1]))), hmul(load_unpack(&c.fixed[4][idx]), hc(h.y[2])));
+  const f29 zs[3] = {load_unpack(&c.z[0][idx]), load_unpack(&c.z[1][idx]), load_unpack(&c.z[2][idx])};
+  const f29 one = hc(h.one0), gamma = hc(h.gamma0);
+  {  // l_0 terms: (1 - z_0), (z_1 - z_0(w^last X)), (z_2 - z_1(w^last X))
+    f29 s0 = hmul(hsub(one, zs[0]), hc(h.y[3]));
+    s0 = f29_add(s0, hmul(hsub(zs[1], load_unpack(&c.z[0][r_last])), hc(h.y[4])));
+    s0 = f29_add(s0, hmul(hsub(zs[2], load_unpack(&c.z[1][r_last])), hc(h.y[5])));
+    acc = f29_add(acc, hmul(s0, load_unpack(&c.l0[idx])));
   }
-  v = fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]);
-  fe_store(&out[idx], v);
+  // l_last term: z_2^2 - z_2 = z_2 (z_2 - 1)
+  acc = f29_add(acc, hmul(hmul(hmul(zs[2], hsub(zs[2], one)), hc(h.y[6])), load_unpack(&c.l_last[idx])));
+  {  // permutation terms: z_m(wX) (a_m + beta sigma_m + gamma) - z_m (a_m + beta DELTA^m X + gamma), X = zeta * extended_omega^idx
+    const f29 X = pow2tab(xlo, xhi, xh, idx);
+    f29 sa = f29_zero();
+    auto term = [&](const f29& a_m, const f29& z_m, const fe* sigma, const fe* z_col, const fe& cur, const fe& ym) {
+      f29 inner_l = f29_add(f29_add(a_m, hmul(load_unpack(&sigma[idx]), hc(h.beta_m1))), gamma);
+      f29 left = hmul(inner_l, load_unpack(&z_col[r_next]));
+      f29 inner_r = f29_add(f29_add(a_m, hmul(X, hc(cur))), gamma);
+      f29 right = hmul(inner_r, z_m);
+      sa = f29_add(sa, hmul(hsub(left, right), hc(ym)));
+    };
+    term(adv[0], zs[0], c.sigma[0], c.z[0], h.cur[0], h.y[7]);
+    term(adv[1], zs[1], c.sigma[1], c.z[1], h.cur[1], h.y[8]);
+    term(adv[2], zs[2], c.sigma[2], c.z[2], h.cur[2], h.y[9]);
+    acc = f29_add(acc, hmul(sa, load_unpack(&c.l_active[idx])));
+  }
+  hstore(&out[idx], acc, h.tinv[idx & (rot - 1)]);
 }
 
 // ---- host side: plans and table caches -----------------------------------------------------------
@@ -772,57 +804,65 @@ struct RangeCosets {
   const fe* l_active;
   uint32_t n_perm, chunk, has_lookup;
 };
-__global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, fe beta, fe gamma, fe y, fe delta,
-                                                           fe zeta, const fe* xlo, const fe* xhi, uint32_t xh, TInv t_inv, fe* out) {
+// Same arithmetic scheme as k_evaluate_h_standard_plonk (levels, host-scaled powers of y).  h.y[i] belongs to term i
+// in evaluate_h's order: 0 the gate (expression at level 2: y[0] at level -3); 1 (1 - z_first) l_0 and the other l_0
+// terms (level-0 expressions: -2); 2 the l_last term (level 1: -3); 3 .. the chain terms (l_0); then one term per
+// permutation set (expression level = columns in the set: -2 - columns); then the lookup's five: l_0 (-2), l_last (-3),
+// the product rule (level 2: -4), l_0 (-2), the ordering rule (level 1: -3).
+__global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h, const fe* xlo,
+                                                           const fe* xhi, uint32_t xh, fe* out) {
   const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= size) return;
   auto at = [&](int r) { return (idx + size + (uint32_t)(r * (int)rot)) & (size - 1); };
   const uint32_t r_next = at(1), r_prev = at(-1), r_last = at(-(int)last_rot);
-  const fe one = fe_one<Fr>();
-  const fe l0 = fe_load(&c.l0[idx]), ll = fe_load(&c.l_last[idx]), la_ = fe_load(&c.l_active[idx]);
-  // gate
-  fe v = fe_mul<Fr>(fe_load(&c.q[idx]), fe_sub<Fr>(fe_add<Fr>(fe_load(&c.a[idx]), fe_mul<Fr>(fe_load(&c.a[at(1)]), fe_load(&c.a[at(2)]))),
-                                                   fe_load(&c.a[at(3)])));
-  // permutation argument: sets of `chunk` columns (chunk = cs.degree() - 2)
-  const uint32_t sets = (c.n_perm + c.chunk - 1) / c.chunk;
-  const fe z_first = fe_load(&c.perm_z[0][idx]);
-  const fe z_lastset = fe_load(&c.perm_z[sets - 1][idx]);
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, z_first), l0));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z_lastset), z_lastset), ll));
-  for (uint32_t s = 1; s < sets; s++)
-    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_load(&c.perm_z[s][idx]), fe_load(&c.perm_z[s - 1][r_last])), l0));
-  fe X;
-  f29_to_mont256<F9>(pow2tab(xlo, xhi, xh, idx), X.v);
-  fe cur = fe_mul<Fr>(beta, fe_mul<Fr>(zeta, X));
-  for (uint32_t s = 0; s < sets; s++) {
-    fe left = fe_load(&c.perm_z[s][r_next]), right = fe_load(&c.perm_z[s][idx]);
-    for (uint32_t j = c.chunk * s; j < c.n_perm && j < c.chunk * (s + 1); j++) {
-      const fe val = fe_load(&c.perm_value[j][idx]);
-      left = fe_mul<Fr>(left, fe_add<Fr>(fe_add<Fr>(val, fe_mul<Fr>(beta, fe_load(&c.perm_sigma[j][idx]))), gamma));
-      right = fe_mul<Fr>(right, fe_add<Fr>(fe_add<Fr>(val, cur), gamma));
-      cur = fe_mul<Fr>(cur, delta);
-    }
-    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la_));
-  }
-  if (!c.has_lookup) {
-    fe_store(&out[idx], fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]));
-    return;
-  }
-  // lookup argument: five terms
-  const fe ap = fe_load(&c.lk_input[idx]), sp = fe_load(&c.lk_table[idx]), zl = fe_load(&c.lk_z[idx]);
-  const fe table_value = fe_mul<Fr>(fe_add<Fr>(fe_load(&c.la[idx]), beta), fe_add<Fr>(fe_load(&c.table[idx]), gamma));
-  const fe a_minus_s = fe_sub<Fr>(ap, sp);
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(one, zl), l0));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(zl), zl), ll));
+  const f29 one = hc(h.one0), gamma = hc(h.gamma0), beta = hc(h.beta0);
+  // gate: q (a + a(wX) a(w^2 X) - a(w^3 X))
+  f29 acc;
   {
-    const fe lhs = fe_mul<Fr>(fe_mul<Fr>(fe_load(&c.lk_z[r_next]), fe_add<Fr>(ap, beta)), fe_add<Fr>(sp, gamma));
-    v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_sub<Fr>(lhs, fe_mul<Fr>(zl, table_value)), la_));
+    f29 w = hmul(load_unpack(&c.a[at(1)]), load_unpack(&c.a[at(2)]));                  // level 1
+    f29 u = hmul(hsub(load_unpack(&c.a[idx]), load_unpack(&c.a[at(3)])), one);        // level 0 -> 1
+    acc = hmul(hmul(f29_add(w, u), load_unpack(&c.q[idx])), hc(h.y[0]));
   }
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(a_minus_s, l0));
-  v = fe_add<Fr>(fe_mul<Fr>(v, y), fe_mul<Fr>(fe_mul<Fr>(a_minus_s, fe_sub<Fr>(ap, fe_load(&c.lk_input[r_prev]))), la_));
-  v = fe_mul<Fr>(v, t_inv.v[idx & (rot - 1)]);
-  fe_store(&out[idx], v);
+  const uint32_t sets = (c.n_perm + c.chunk - 1) / c.chunk;
+  const f29 z_first = load_unpack(&c.perm_z[0][idx]);
+  const f29 z_lastset = load_unpack(&c.perm_z[sets - 1][idx]);
+  f29 s0 = hmul(hsub(one, z_first), hc(h.y[1]));                                      // l_0 group (level -1 after the y factor)
+  f29 sl = hmul(hmul(z_lastset, hsub(z_lastset, one)), hc(h.y[2]));                   // l_last group
+  for (uint32_t s = 1; s < sets; s++)
+    s0 = f29_add(s0, hmul(hsub(load_unpack(&c.perm_z[s][idx]), load_unpack(&c.perm_z[s - 1][r_last])), hc(h.y[2 + s])));
+  const f29 X = pow2tab(xlo, xhi, xh, idx);
+  f29 sa = f29_zero();                                                                // l_active group
+  const uint32_t p0 = 2 + sets;
+  for (uint32_t s = 0; s < sets; s++) {
+    f29 left = load_unpack(&c.perm_z[s][r_next]), right = load_unpack(&c.perm_z[s][idx]);
+    for (uint32_t j = c.chunk * s; j < c.n_perm && j < c.chunk * (s + 1); j++) {
+      const f29 val = load_unpack(&c.perm_value[j][idx]);
+      left = hmul(f29_add(f29_add(val, hmul(load_unpack(&c.perm_sigma[j][idx]), hc(h.beta_m1))), gamma), left);
+      right = hmul(f29_add(f29_add(val, hmul(X, hc(h.cur[j]))), gamma), right);
+    }
+    sa = f29_add(sa, hmul(hsub(left, right), hc(h.y[p0 + s])));
+  }
+  if (c.has_lookup) {
+    const uint32_t lb = p0 + sets;
+    const f29 ap = load_unpack(&c.lk_input[idx]), sp = load_unpack(&c.lk_table[idx]), zl = load_unpack(&c.lk_z[idx]);
+    s0 = f29_add(s0, hmul(hsub(one, zl), hc(h.y[lb])));
+    sl = f29_add(sl, hmul(hmul(zl, hsub(zl, one)), hc(h.y[lb + 1])));
+    {  // z(wX) (A' + beta) (S' + gamma) - z (A + beta) (S + gamma)
+      f29 lhs = hmul(f29_add(sp, gamma), hmul(f29_add(ap, beta), load_unpack(&c.lk_z[r_next])));
+      f29 tv = hmul(f29_add(load_unpack(&c.la[idx]), beta), f29_normalize(f29_add(load_unpack(&c.table[idx]), gamma)));
+      f29 rhs = hmul(tv, zl);
+      sa = f29_add(sa, hmul(hsub(lhs, rhs), hc(h.y[lb + 2])));
+    }
+    const f29 a_minus_s = hsub(ap, sp);
+    s0 = f29_add(s0, hmul(a_minus_s, hc(h.y[lb + 3])));
+    sa = f29_add(sa, hmul(hmul(a_minus_s, hsub(ap, load_unpack(&c.lk_input[r_prev]))), hc(h.y[lb + 4])));
+  }
+  // l_0 group: up to 1 + 3 + 2 = 6 normalized addends (limbs < 6 * 2^29 exceeds the multiplier's 1.9 * 2^30 bound)
+  acc = f29_add(acc, hmul(f29_normalize(s0), load_unpack(&c.l0[idx])));
+  acc = f29_add(acc, hmul(sl, load_unpack(&c.l_last[idx])));
+  acc = f29_add(acc, hmul(f29_normalize(sa), load_unpack(&c.l_active[idx])));
+  hstore(&out[idx], acc, h.tinv[idx & (rot - 1)]);
 }
 
 // the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
@@ -859,6 +899,46 @@ static fe host_fe(const uint64_t w[4]) {
   fe r;
   memcpy(r.v, w, 32);
   return r;
+}
+
+// host-side Fr arithmetic for the handful of per-call constants of evaluate_h (HConsts): Montgomery-2^256 words in,
+// canonical words out, through the same f29 layer the device uses (plain C++ there)
+static fe h_canon(const f29& x_lt2p) {
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(x_lt2p), o.v);
+  return o;
+}
+static fe h_mul256(const fe& a, const fe& b) {  // (a 2^256, b 2^256) -> a b 2^256
+  return h_canon(f29_mul<F9>(f29_from_mont256<F9>(a.v), f29_unpack(b.v)));
+}
+static fe h_level(const fe& a, int level) {  // a 2^256 -> a 2^256 2^(-5 level)
+  fe r = a;
+  const fe up = h_canon(f29_mul<F9>(f29_const<F9>(F9::ONE), f29_const<F9>(F9::ONE)));   // 2^261: times it = * 2^5 in the 2^256 domain
+  // 2^-5 in the 2^256 domain = the memory word 2^251 = mul(2^256, 2^256) in f29 (divides by 2^261)
+  const fe down = h_canon(f29_mul<F9>(f29_const<F9>(F9::TO256), f29_const<F9>(F9::TO256)));
+  for (int i = 0; i < (level < 0 ? -level : level); i++) r = h_mul256(r, level < 0 ? up : down);
+  return r;
+}
+struct HostY {  // y^0 .. y^(count-1), Montgomery-2^256
+  fe p[24];
+  HostY(const fe& y, uint32_t count) {
+    memcpy(p[0].v, h_canon(f29_const<F9>(F9::TO256)).v, 32);
+    for (uint32_t i = 1; i < count && i < 24; i++) p[i] = h_mul256(p[i - 1], y);
+  }
+};
+static void fill_common(HConsts& h, const fe& beta, const fe& gamma, const fe& delta, const fe& zeta, uint32_t n_cur, const uint64_t* t_inv,
+                        uint32_t rot) {
+  memset(&h, 0, sizeof(h));
+  h.beta0 = beta;
+  h.beta_m1 = h_level(beta, -1);
+  h.gamma0 = gamma;
+  h.one0 = h_canon(f29_const<F9>(F9::TO256));
+  fe cur = h_mul256(beta, zeta);
+  for (uint32_t j = 0; j < n_cur; j++) {
+    h.cur[j] = cur;
+    cur = h_mul256(cur, delta);
+  }
+  for (uint32_t i = 0; i < rot; i++) h.tinv[i] = h_level(host_fe(t_inv + 4 * i), -1);
 }
 
 // `full`: one table entry per power (32 B x 2^log_n) so that a kernel fetches base^e instead of multiplying
@@ -1532,12 +1612,33 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
   int rc = get_powtab(extended_omega, extended_k, s, &px);
   if (rc) return rc;
   const uint32_t rot = 1u << (extended_k - k);
-  TInv tinv;
-  memset(&tinv, 0, sizeof(tinv));
-  for (uint32_t i = 0; i < rot; i++) tinv.v[i] = host_fe(t_inv + 4 * i);
+  HConsts hcst;
+  fill_common(hcst, host_fe(beta), host_fe(gamma), host_fe(delta), host_fe(zeta), c->n_perm, t_inv, rot);
+  {  // term i carries y^(N-1-i) at the level its expression needs (see the kernel's header)
+    const uint32_t sets = (c->n_perm + c->chunk_len - 1) / c->chunk_len;
+    const uint32_t N = 2 + 2 * sets + (rc_.has_lookup ? 5 : 0);
+    const HostY yp(host_fe(y), N);
+    auto put = [&](uint32_t term, int level) { hcst.y[term] = h_level(yp.p[N - 1 - term], level); };
+    put(0, -3);
+    put(1, -2);
+    put(2, -3);
+    for (uint32_t q = 1; q < sets; q++) put(2 + q, -2);
+    for (uint32_t q = 0; q < sets; q++) {
+      const uint32_t cols = std::min(c->chunk_len, c->n_perm - q * c->chunk_len);
+      put(2 + sets + q, -2 - (int)cols);
+    }
+    if (rc_.has_lookup) {
+      const uint32_t lb = 2 + 2 * sets;
+      put(lb, -2);
+      put(lb + 1, -3);
+      put(lb + 2, -4);
+      put(lb + 3, -2);
+      put(lb + 4, -3);
+    }
+  }
   const uint32_t size = 1u << extended_k;
-  H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, host_fe(beta),
-            host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, tinv, (fe*)d_h_out);
+  H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
+            (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
   return H2MI_OK;
 }
 
@@ -1561,14 +1662,22 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* c, uint
   PowTab px;
   int rc = get_powtab(extended_omega, extended_k, s, &px);
   if (rc) return rc;
-  const uint32_t rot = 1u << (extended_k - k);
-  TInv tinv;  // <= 16 values, passed by value: no staging buffer shared between streams
-  memset(&tinv, 0, sizeof(tinv));
-  for (uint32_t i = 0; i < rot; i++) tinv.v[i] = host_fe(t_inv + 4 * i);
+  HConsts hcst;
+  fill_common(hcst, host_fe(beta), host_fe(gamma), host_fe(delta), host_fe(zeta), 3, t_inv, 1u << (extended_k - k));
+  {
+    const HostY yp(host_fe(y), 8);  // eight terms: term i carries y^(7-i)
+    hcst.y[0] = h_level(yp.p[7], -2);
+    hcst.y[1] = h_level(yp.p[7], -3);
+    hcst.y[2] = h_level(yp.p[7], -1);
+    hcst.y[3] = h_level(yp.p[6], -2);  // term 1
+    hcst.y[4] = h_level(yp.p[4], -2);  // term 3
+    hcst.y[5] = h_level(yp.p[3], -2);  // term 4
+    hcst.y[6] = h_level(yp.p[5], -3);  // term 2
+    for (int m = 0; m < 3; m++) hcst.y[7 + m] = h_level(yp.p[2 - m], -3);  // terms 5, 6, 7
+  }
   const uint32_t size = 1u << extended_k;
   H2_LAUNCH("k_evaluate_h_standard_plonk", k_evaluate_h_standard_plonk, ceil_div_u32(size, 256), 256, 0, s, pc, extended_k, k, blinding_factors + 1,
-            host_fe(beta), host_fe(gamma), host_fe(y), host_fe(delta), host_fe(zeta), (const fe*)px.lo, (const fe*)px.hi, px.h, tinv,
-            (fe*)d_h_out);
+            hcst, (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
   return H2MI_OK;
 }
 
