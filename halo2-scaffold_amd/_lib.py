@@ -64,6 +64,9 @@ def _load():
         "h2mi_g1_fold_groups_dev": ([vp, sz, sz, vp, vp], C.c_int),
         "h2mi_g1_batch_normalize_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_library_stream": ([C.POINTER(vp)], C.c_int),
+        "h2mi_stream_create": ([C.POINTER(vp)], C.c_int),
+        "h2mi_stream_destroy": ([vp], C.c_int),
+        "h2mi_stream_wait": ([vp, vp], C.c_int),
         "h2mi_fr_add_head_dev": ([vp, vp, sz, vp], C.c_int),
         "h2mi_fr_fill_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_fr_random_dev": ([vp, sz, C.c_uint64, C.c_uint64, vp], C.c_int),

@@ -489,6 +489,39 @@ int h2mi_g1_batch_normalize_dev(const void* d_jac, size_t k, void* d_affine_out,
   return H2MI_OK;
 }
 
+// ---- side streams: work that does not depend on the next challenge (the coefficient / extended forms of committed
+// columns) can run beside the library stream's chain of small kernels instead of queueing behind it ----------------------
+int h2mi_stream_create(h2mi_stream_t* stream_out) {
+  H2_REQUIRE_INIT();
+  if (!stream_out) return H2MI_EINVAL;
+  hipStream_t s = nullptr;
+  H2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream_out = (h2mi_stream_t)s;
+  return H2MI_OK;
+}
+int h2mi_stream_destroy(h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!stream) return H2MI_EINVAL;
+  H2_HIP(hipStreamSynchronize((hipStream_t)stream));
+  H2_HIP(hipStreamDestroy((hipStream_t)stream));
+  return H2MI_OK;
+}
+int h2mi_stream_wait(h2mi_stream_t waiter, h2mi_stream_t signaller) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t w = pick_stream(waiter), g = pick_stream(signaller);
+  if (w == g) return H2MI_OK;
+  // a ring of events: re-recording one only matters to waits issued after the re-record, and a wait issued 32 calls ago
+  // has long been consumed by its stream's front end
+  static hipEvent_t ring[32] = {};
+  static unsigned next = 0;
+  hipEvent_t& ev = ring[next++ & 31u];
+  if (!ev) H2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  H2_HIP(hipEventRecord(ev, g));
+  H2_HIP(hipStreamWaitEvent(w, ev, 0));
+  return H2MI_OK;
+}
+
 int h2mi_library_stream(void** stream_out) {
   H2_REQUIRE_INIT();
   if (!stream_out) return H2MI_EINVAL;

@@ -609,13 +609,24 @@ struct Plan {
 
 static std::map<Key, PowTab> g_powtabs;
 static std::map<Key, Plan> g_plans;
-// one scratch vector shared by the NTT passes and the polynomial helpers; calls are serialised by the
-// library mutex, and an event orders consecutive users that run on different streams
+// scratch vectors for the NTT passes and the polynomial helpers: one per stream that issues them (the library's own
+// stream, plus a caller's side stream that runs transforms beside it — see h2mi_stream_create), so that calls on
+// different streams do not serialise on a shared buffer.  Calls are serialised by the library mutex: ensure_tmp() points
+// g_tmp at the scratch of the calling stream for the duration of the call; release_tmp() records the event that orders
+// a later user of the same scratch on another stream (only when more streams than scratches are in play).
+struct Scratch {
+  fe* p = nullptr;
+  size_t elems = 0;
+  hipEvent_t event = nullptr;
+  hipStream_t stream = nullptr;
+  bool used = false;
+  uint64_t last = 0;
+};
+constexpr int N_SCRATCH = 3;
+static Scratch g_scratch[N_SCRATCH];
+static Scratch* g_cur = nullptr;
+static uint64_t g_scratch_clock = 0;
 static fe* g_tmp = nullptr;
-static size_t g_tmp_elems = 0;
-static hipEvent_t g_tmp_event = nullptr;
-static hipStream_t g_tmp_stream = nullptr;
-static bool g_tmp_used = false;
 
 // ---- permutation argument: the grand-product column z -------------------------------------
 // create_proof builds, per chunk of columns, z[0] = start, z[i+1] = z[i] * prod_j (v_j[i] + beta delta^j omega^i
@@ -1101,27 +1112,43 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
 }
 
 static int ensure_tmp(size_t elems, hipStream_t s) {
-  if (g_tmp_used && g_tmp_stream != s) H2_HIP(hipStreamWaitEvent(s, g_tmp_event, 0));  // previous user on another stream
-  if (g_tmp_elems < elems) {
-    if (g_tmp) {
-      H2_HIP(hipDeviceSynchronize());
-      H2_HIP(hipFree(g_tmp));
-      g_tmp = nullptr;
-      g_tmp_elems = 0;
-    }
-    hipError_t e = hipMalloc(&g_tmp, elems * 32);
-    if (e == hipErrorOutOfMemory) return H2MI_ENOMEM;
-    H2_HIP(e);
-    g_tmp_elems = elems;
+  Scratch* e = nullptr;
+  for (Scratch& c : g_scratch)
+    if (c.used && c.stream == s) { e = &c; break; }
+  if (!e)
+    for (Scratch& c : g_scratch)
+      if (!c.used) { e = &c; break; }
+  if (!e) {  // more streams than scratches: take over the least recently used one, behind its last user
+    e = &g_scratch[0];
+    for (Scratch& c : g_scratch)
+      if (c.last < e->last) e = &c;
+    H2_HIP(hipStreamWaitEvent(s, e->event, 0));
   }
+  if (e->elems < elems) {
+    if (e->p) {
+      H2_HIP(hipDeviceSynchronize());
+      H2_HIP(hipFree(e->p));
+      e->p = nullptr;
+      e->elems = 0;
+    }
+    hipError_t err = hipMalloc(&e->p, elems * 32);
+    if (err == hipErrorOutOfMemory) return H2MI_ENOMEM;
+    H2_HIP(err);
+    e->elems = elems;
+  }
+  e->last = ++g_scratch_clock;
+  g_cur = e;
+  g_tmp = e->p;
   return H2MI_OK;
 }
 // call after the last kernel that touches g_tmp has been queued on `s`
 static int release_tmp(hipStream_t s) {
-  if (!g_tmp_event) H2_HIP(hipEventCreateWithFlags(&g_tmp_event, hipEventDisableTiming));
-  H2_HIP(hipEventRecord(g_tmp_event, s));
-  g_tmp_stream = s;
-  g_tmp_used = true;
+  Scratch* e = g_cur;
+  if (!e) return H2MI_EHIP;
+  if (!e->event) H2_HIP(hipEventCreateWithFlags(&e->event, hipEventDisableTiming));
+  H2_HIP(hipEventRecord(e->event, s));
+  e->stream = s;
+  e->used = true;
   return H2MI_OK;
 }
 

@@ -51,3 +51,26 @@ class DevBuf:
             self.free()
         except Exception:
             pass
+
+
+class SideStream:
+    """a second device stream (h2mi_stream_create) for work that need not queue behind the library stream's chain:
+    `after_library()` orders it behind everything issued so far on the library stream (e.g. the column uploads it
+    reads), `join_library()` makes the library stream wait for it.  `.handle` goes into the `stream` argument of the
+    *_dev entry points."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib.h2mi_stream_create(C.byref(h)), "stream_create")
+        self.handle = h.value
+
+    def after_library(self):
+        check(lib.h2mi_stream_wait(self.handle, None), "stream_wait")
+
+    def join_library(self):
+        check(lib.h2mi_stream_wait(None, self.handle), "stream_wait")
+
+    def free(self):
+        if self.handle:
+            lib.h2mi_stream_destroy(self.handle)
+            self.handle = None

@@ -27,7 +27,7 @@ from . import plonk as gp
 from . import serde, synth
 from ._lib import check, lib
 from .circuits import PermutationAssembly
-from .device import DevBuf
+from .device import DevBuf, SideStream
 from .domain import EvaluationDomain
 from .keygen import FR_DELTA, _m, commit_points
 from .params import ParamsKZG
@@ -288,6 +288,7 @@ class FlexWorkspace:
         self.points = DevBuf(96 * 8)
         self._pool, self._cursor = [], 0
         self.shplonk = ProverSHPLONK(pk.domain.n)
+        self.side = SideStream()  # transforms that wait for no challenge run here, beside the library stream's chain
 
     def begin(self):
         self._cursor = 0
@@ -304,6 +305,7 @@ class FlexWorkspace:
         for b in self._pool + [self.points]:
             b.free()
         self.shplonk.release()
+        self.side.free()
 
 
 def _write_points(ws: FlexWorkspace, transcript, k: int):
@@ -342,10 +344,10 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         h = params.g_lagrange_handle if lagrange else params.g_handle
         check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + (offset_elems + params.lo) * 32, params.n, out_base + 96 * slot, None), "commit")
 
-    def forms(col):
+    def forms(col, stream=None):
         p, e = dev(n), dev(ext)
-        d.lagrange_to_coeff_oop_dev(col, p)
-        d.coeff_to_extended_oop_dev(p, e)
+        d.lagrange_to_coeff_oop_dev(col, p, stream=stream)
+        d.coeff_to_extended_oop_dev(p, e, stream=stream)
         return p, e
 
     transcript.common_scalar(_m(pk.transcript_repr))
@@ -362,6 +364,12 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         advice.append(col)
     for j, col in enumerate(advice):
         commit(col, True, j)
+    # coefficient / extended forms of the advice and instance columns: no challenge enters them, so they run on the side
+    # stream beside the transcript round trips, the lookup's counting sort and the grand products (see prover.py)
+    side = ws.side
+    side.after_library()
+    advice_f = [forms(c, side.handle) for c in advice]
+    instance_f = forms(instance, side.handle)
     _write_points(ws, transcript, len(advice))
     theta = sq()
     # lookup: permuted input / table columns
@@ -377,9 +385,17 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         s_perm.patch(lb[bf + 1 :], offset=u * 32)
         commit(a_perm, True, 0)
         commit(s_perm, True, 1)
+        side.after_library()
+        lk_f = [forms(a_perm, side.handle), forms(s_perm, side.handle)]
         _write_points(ws, transcript, 2)
         lk = [a_perm, s_perm, None]
     beta, gamma = sq(), sq()
+    # vanishing argument's random polynomial: written after the grand products' commitments but dependent on nothing, so
+    # its dense MSM is queued first and accumulates beside their latency-bound scans.  Result slot: after the
+    # permutation sets and the lookup product, where the transcript expects it.
+    random_poly = dev(n)
+    check(lib.h2mi_fr_random_dev(random_poly.ptr, n, seed + 3, 0, None), "random_poly")
+    commit(random_poly, False, -(-len(cs.perm_columns) // cs.chunk) + (1 if cs.lookup else 0))
     # permutation argument
     col_of = {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: [instance]}
     perm_values = [col_of[kind][c] for kind, c in cs.perm_columns]
@@ -400,15 +416,12 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         lk[2] = lz
         commit(lz, True, slot)
         slot += 1
-    random_poly = dev(n)
-    check(lib.h2mi_fr_random_dev(random_poly.ptr, n, seed + 3, 0, None), "random_poly")
-    commit(random_poly, False, slot)
-    slot += 1
+    slot += 1  # the random polynomial's commitment, queued before the grand products (RANDOM_SLOT)
     # coefficient / extended forms, queued behind the commitments
-    advice_f = [forms(c) for c in advice]
-    instance_f = forms(instance)
     z_f = [forms(z) for z in zs]
-    lk_f = [forms(b) for b in lk] if cs.lookup else None
+    if cs.lookup:
+        lk_f.append(forms(lk[2]))
+    side.join_library()  # evaluate_h and the openings read the side stream's forms
     _write_points(ws, transcript, slot)
     y = sq()
     # quotient

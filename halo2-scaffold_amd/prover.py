@@ -26,7 +26,7 @@ from . import field as F
 from . import plonk as gp
 from . import synth
 from ._lib import check, lib
-from .device import DevBuf
+from .device import DevBuf, SideStream
 from .keygen import ProvingKey, _m, _patch
 from .params import ParamsKZG
 from .shplonk import ProverSHPLONK
@@ -59,12 +59,14 @@ class ProverWorkspace:
         self.points = DevBuf(96 * 4)     # Jacobian results of the commitments of one phase
         self.evals = DevBuf(32 * 32)
         self.shplonk = ProverSHPLONK(n)
+        self.side = SideStream()         # transforms of the advice columns, beside the permutation argument's chain
 
     def release(self):
         for b in (self.advice + self.advice_polys + self.advice_cosets + self.z + self.z_polys + self.z_cosets +
                   [self.random_poly, self.h, self.h_poly, self.points, self.evals]):
             b.free()
         self.shplonk.release()
+        self.side.free()
 
 
 _Q = F.FQ_MODULUS
@@ -138,26 +140,39 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
                 cells[r - lo] = _m(syn.advice[j][r])
             col.patch(cells, offset=lo * 32)
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
-    _commit_phase(params, ws, transcript, [(c, 0) for c in ws.advice], lagrange=True)
+    for i, c in enumerate(ws.advice):
+        _commit(params, ws, c, 0, True, i)
+    # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
+    # y): on a side stream they run beside the commitments' bucket reductions, the transcript round trip and the
+    # permutation argument's chain of small scans — a stretch in which the device is otherwise nearly idle, because the
+    # advice columns of this circuit are almost empty — instead of queueing behind the z commitments (2 ms of 16 at k = 20)
+    ws.side.after_library()
+    for col, p, e in zip(ws.advice, ws.advice_polys, ws.advice_cosets):
+        d.lagrange_to_coeff_oop_dev(col, p, stream=ws.side.handle)
+        d.coeff_to_extended_oop_dev(p, e, stream=ws.side.handle)
+    _write_phase_points(ws, transcript, len(ws.advice))
     mark("advice committed")
     theta = sq()  # drawn even without lookups
     beta, gamma = sq(), sq()
+    # ---- vanishing argument: random polynomial (n coefficients from the prover's rng).  Its commitment is written after
+    # the z commitments but depends on nothing: queued here, the one dense MSM of this phase accumulates beside the
+    # permutation argument's latency-bound scans instead of after them
+    check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
+    _commit(params, ws, ws.random_poly, 0, False, len(ws.z))
 
     # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1), one device pass ---
     zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
     gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z)
     for m, z in enumerate(ws.z):
         z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
-    # ---- vanishing argument: random polynomial (n coefficients from the prover's rng) ------------------------------
-    check(lib.h2mi_fr_random_dev(ws.random_poly.ptr, n, seed + 3, 0, None), "random_poly")
     for i, z in enumerate(ws.z):
         _commit(params, ws, z, 0, True, i)
-    _commit(params, ws, ws.random_poly, 0, False, len(ws.z))
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
     # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products
-    for col, p, e in list(zip(ws.advice, ws.advice_polys, ws.advice_cosets)) + list(zip(ws.z, ws.z_polys, ws.z_cosets)):
+    for col, p, e in zip(ws.z, ws.z_polys, ws.z_cosets):
         d.lagrange_to_coeff_oop_dev(col, p)
         d.coeff_to_extended_oop_dev(p, e)
+    ws.side.join_library()  # evaluate_h and the openings read the advice forms
     mark("queued z/random commits")
     _write_phase_points(ws, transcript, len(ws.z) + 1)
     mark("z, random committed")

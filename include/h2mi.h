@@ -80,6 +80,15 @@ int h2mi_sync(void); /* wait for all work queued on the library's streams */
  * h2mi_memcpy_d2h (or when eight reductions are pending).  A prover calls h2mi_join where the transcript
  * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream. */
 int h2mi_join(void);
+/* ---- side streams.  Every *_dev entry point takes a stream (NULL = the library's own, on which calls execute in issue
+ * order).  A second stream lets work that does not depend on the next transcript challenge — e.g. the coefficient and
+ * extended forms of the advice columns, needed only by evaluate_h — run beside the library stream's chain instead of
+ * queueing behind it.  h2mi_stream_wait(waiter, signaller) makes everything queued later on `waiter` start after
+ * everything queued so far on `signaller` (NULL = the library stream on either side); it does not block the host. */
+int h2mi_stream_create(h2mi_stream_t* stream_out);
+int h2mi_stream_destroy(h2mi_stream_t stream);
+int h2mi_stream_wait(h2mi_stream_t waiter, h2mi_stream_t signaller);
+
 /* the library's own stream (a hipStream_t), so that a host can order foreign work — an RCCL collective, its own
  * kernels — against the library's without a host synchronisation */
 int h2mi_library_stream(void** stream_out);
