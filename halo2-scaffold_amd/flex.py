@@ -177,16 +177,27 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
 
 # ---- keys ------------------------------------------------------------------------------------------------------------
 def _column_from_cells(n: int, cells, into: DevBuf = None) -> DevBuf:
+    """a column with the given {row: value} cells, zero elsewhere.  A long run of cells (a witness of thousands of
+    cells, a lookup table) is uploaded as canonical 32-byte integers and brought to Montgomery form on the device
+    (h2mi_fe_from_repr_dev, in place); the host only packs bytes."""
     d = into if into is not None else DevBuf(n * 32)
     check(lib.h2mi_memset_zero(d.ptr, n * 32), "zero")
     if cells:
         rows = sorted(cells)
         lo, hi = rows[0], rows[-1] + 1
         if hi - lo <= 4 * len(rows) + 16:  # contiguous enough: one upload
-            arr = np.zeros((hi - lo, 4), dtype=np.uint64)
-            for r in rows:
-                arr[r - lo] = _m(cells[r])
-            d.upload(arr, offset=lo * 32)
+            if len(rows) > 64:
+                get = cells.get
+                raw = b"".join((get(r, 0) % R).to_bytes(32, "little") for r in range(lo, hi))
+                d.upload(np.frombuffer(raw, dtype=np.uint8), offset=lo * 32)
+                bad = C.c_uint64()
+                check(lib.h2mi_fe_from_repr_dev(1, d.ptr + lo * 32, hi - lo, d.ptr + lo * 32, C.byref(bad)), "from_repr")
+                assert bad.value == 0
+            else:
+                arr = np.zeros((hi - lo, 4), dtype=np.uint64)
+                for r in rows:
+                    arr[r - lo] = _m(cells[r])
+                d.upload(arr, offset=lo * 32)
         else:
             for r in rows:
                 d.upload(_m(cells[r]), offset=r * 32)

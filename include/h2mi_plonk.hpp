@@ -314,11 +314,12 @@ inline void to_poly_and_coset(const poly::EvaluationDomain& dom, const DeviceVec
   Fr zeta = fr::zeta();
   check(h2mi_ntt_bn254_fr_oop_dev(poly->p, n, coset->p, dom.extended_k(), dom.get_extended_omega().l, zeta.l, nullptr, nullptr), "coeff_to_extended");
 }
-inline void to_poly_and_coset_into(const poly::EvaluationDomain& dom, const DeviceVec& lagr, DeviceVec& poly, DeviceVec& coset) {
+inline void to_poly_and_coset_into(const poly::EvaluationDomain& dom, const DeviceVec& lagr, DeviceVec& poly, DeviceVec& coset,
+                                   h2mi_stream_t stream = nullptr) {
   const size_t n = (size_t)1 << dom.k();
   Fr n_inv = fr::invert(fr::from_u64(n)), zeta = fr::zeta();
-  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly.p, dom.k(), dom.get_omega_inv().l, nullptr, n_inv.l, nullptr), "lagrange_to_coeff");
-  check(h2mi_ntt_bn254_fr_oop_dev(poly.p, n, coset.p, dom.extended_k(), dom.get_extended_omega().l, zeta.l, nullptr, nullptr), "coeff_to_extended");
+  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly.p, dom.k(), dom.get_omega_inv().l, nullptr, n_inv.l, stream), "lagrange_to_coeff");
+  check(h2mi_ntt_bn254_fr_oop_dev(poly.p, n, coset.p, dom.extended_k(), dom.get_extended_omega().l, zeta.l, nullptr, stream), "coeff_to_extended");
 }
 // commit columns (device-resident, n elements) -> affine points on the host
 inline std::vector<G1Affine> commit_points(uint64_t handle, const std::vector<const void*>& cols, size_t n) {
@@ -553,6 +554,12 @@ struct ProverWorkspace {
   size_t n, ext;
   std::vector<Dev> advice, advice_polys, advice_cosets, z, z_polys, z_cosets, shplonk_q;
   Dev random_poly, h, h_poly, points, evals, nx, tmp, h_x, l_x, h2_x;
+  h2mi_stream_t side = nullptr;  // transforms of the advice columns run here, beside the permutation argument's chain
+  ProverWorkspace(const ProverWorkspace&) = delete;
+  ProverWorkspace& operator=(const ProverWorkspace&) = delete;
+  ~ProverWorkspace() {
+    if (side) h2mi_stream_destroy(side);
+  }
   ProverWorkspace(const poly::kzg::ParamsKZG& params, const ProvingKey& pk) : n(params.n()), ext(pk.domain.extended_len()) {
     auto vec = [&](size_t cnt) { return Dev(new DeviceVec(cnt)); };
     for (uint32_t j = 0; j < StandardPlonk::N_ADVICE; j++) {
@@ -562,6 +569,7 @@ struct ProverWorkspace {
     for (int i = 0; i < 4; i++) shplonk_q.push_back(vec(n));
     random_poly = vec(n); h = vec(ext); h_poly = vec(n); points = vec(12); evals = vec(32);
     nx = vec(n); tmp = vec(n); h_x = vec(n); l_x = vec(n); h2_x = vec(n);
+    check(h2mi_stream_create(&side), "stream_create");
   }
 };
 
@@ -602,9 +610,18 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     check(h2mi_memcpy_h2d_async((char*)col.p + (size_t)u * 32, &blind[(size_t)j * (bf + 1)], (bf + 1) * 32), "blinding rows");
   }
   for (uint32_t j = 0; j < na; j++) commit(params.g_lagrange_handle(), advice[j]->p, j);
+  // the advice columns' coefficient / extended forms wait for no challenge: on the side stream they run beside the
+  // transcript round trip and the permutation argument's latency-bound scans
+  check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
+  for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *advice[j], *advice_polys[j], *advice_cosets[j], ws.side);
   write_phase_points(na);
   (void)tr.squeeze_challenge();  // theta: drawn even without lookups
   const Fr beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
+  // vanishing argument's random polynomial: written after the z commitments, dependent on nothing — its dense MSM is
+  // queued first and accumulates beside the grand products
+  DeviceVec& random_poly = *ws.random_poly;
+  check(h2mi_fr_random_dev(random_poly.p, n, seed + 3, 0, nullptr), "random_poly");
+  commit(params.g_handle(), random_poly.p, na);
 
   // permutation argument: every set in one device pass (chunk length cs.degree() - 2 = 1)
   const Fr delta = fr_delta();
@@ -622,14 +639,10 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)na * bf);
   for (uint32_t m = 0; m < na; m++)
     check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");
-  // vanishing argument: random polynomial
-  DeviceVec& random_poly = *ws.random_poly;
-  check(h2mi_fr_random_dev(random_poly.p, n, seed + 3, 0, nullptr), "random_poly");
   for (uint32_t m = 0; m < na; m++) commit(params.g_lagrange_handle(), z[m]->p, m);
-  commit(params.g_handle(), random_poly.p, na);
-  // coefficient / extended forms, queued behind the commitments
-  for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *advice[j], *advice_polys[j], *advice_cosets[j]);
+  // coefficient / extended forms of z, queued behind the commitments
   for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *z[j], *z_polys[j], *z_cosets[j]);
+  check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");  // evaluate_h and the openings read the advice forms
   write_phase_points(na + 1);
   const Fr y = tr.squeeze_challenge();
 

@@ -193,3 +193,57 @@ def test_workspace_reuse_and_sliced_srs_world2(gpu):
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["proof_sha256"] == one["proof_sha256"]
     assert two["combines_per_proof"] == 6  # advice; permuted columns; z, lookup z, random; h pieces; the two SHPLONK commitments
+
+
+def _oracle_assignment(ocs, asg):
+    oa = FX.Assignment(ocs)
+    oa.advice = [dict(c) for c in asg.advice]
+    oa.fixed = [dict(c) for c in asg.fixed]
+    oa.instance = [list(asg.instance)]
+    oa.copies = list(asg.copies)
+    return oa
+
+
+def test_poseidon_proof_bytes_match_oracle(gpu):
+    """reference examples/poseidon.rs `hash_two` (T = 3, RATE = 2, R_F = 8, R_P = 57) as ~7.4 k FlexGate cells at k = 13:
+    the public hash equals the oracle's Poseidon sponge (pinned by circomlib's published constants), and the device proof
+    equals the oracle engine's proof of the same cells byte for byte."""
+    from oracle import poseidon as OPS
+
+    from halo2_scaffold_amd import flex, poseidon
+
+    k, x, y, seed = 13, 0xFEEDFACE, 0xC0DE, 17
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=False)
+    asg = poseidon.hash_two_closure(cs, x, y)
+    assert asg.instance == [x, y, OPS.sponge_hash([x, y])]
+    keys = flex.FlexKeys(params, cs, asg)
+    proof = flex.create_proof(params, keys, asg, seed)
+    ocs = FX.flex_gate_cs(False)
+    oasg = _oracle_assignment(ocs, asg)
+    okeys = _oracle_keys(ocs, k, oasg)
+    assert keys.vk_bytes() == okeys.vk_bytes()
+    assert proof == FX.prove(okeys, oasg, seed)["proof"]
+    assert FX.verify(okeys, proof, [asg.instance])
+    assert not FX.verify(okeys, proof, [[x, y, asg.instance[2] ^ 1]])
+    keys.release()
+    params.release()
+
+
+def test_poseidon_proof_verifies_at_degree_20(gpu):
+    """BASELINE configs[4]: examples/poseidon.rs at DEGREE = 20 on one device"""
+    from halo2_scaffold_amd import flex, poseidon
+
+    k, x, y, seed = 20, 3, 4, 99
+    params = gpu.ParamsKZG.setup(k, SRS_SECRET)
+    cs = flex.FlexGateCS(lookup=False)
+    asg = poseidon.hash_two_closure(cs, x, y)
+    keys = flex.FlexKeys(params, cs, asg)
+    proof = flex.create_proof(params, keys, asg, seed)
+    ocs = FX.flex_gate_cs(False)
+    oasg = _oracle_assignment(ocs, asg)
+    vk = FX.VerifierKeys(ocs, k, SRS_SECRET, oasg.fixed, oasg.copies)
+    assert keys.transcript_repr == vk.transcript_repr
+    assert FX.verify(vk, proof, [asg.instance])
+    keys.release()
+    params.release()
