@@ -622,7 +622,7 @@ struct Scratch {
   bool used = false;
   uint64_t last = 0;
 };
-constexpr int N_SCRATCH = 3;
+constexpr int N_SCRATCH = 4;
 static Scratch g_scratch[N_SCRATCH];
 static Scratch* g_cur = nullptr;
 static uint64_t g_scratch_clock = 0;

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import field as F
 from ._lib import check, lib
-from .device import DevBuf
+from .device import DevBuf, SideStream
 
 R = F.FR_MODULUS
 _m = F.fr_to_mont_limbs
@@ -87,41 +87,48 @@ def construct_intermediate_sets(queries):
     return sets, sorted({pt for _, pt, _ in queries})
 
 
-def _lincomb(polys, scalars, n, out: DevBuf):
+def _lincomb(polys, scalars, n, out: DevBuf, stream=None):
     assert len(polys) == len(scalars) <= 24
     ptrs = (C.c_void_p * len(polys))(*[p.ptr for p in polys])
     sc = np.ascontiguousarray(np.stack([_m(s) for s in scalars]))
-    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, len(polys), n, out.ptr, None), "lincomb")
+    check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, len(polys), n, out.ptr, stream), "lincomb")
 
 
-def _add_head(poly: DevBuf, coeffs):
+def _add_head(poly: DevBuf, coeffs, stream=None):
     hd = np.ascontiguousarray(np.stack([_m(c) for c in coeffs]))
-    check(lib.h2mi_fr_add_head_dev(poly.ptr, hd.ctypes.data, len(coeffs), None), "add_head")
+    check(lib.h2mi_fr_add_head_dev(poly.ptr, hd.ctypes.data, len(coeffs), stream), "add_head")
 
 
-def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf):
-    """out = src / prod (X - root), zero-padded to n coefficients; src is clobbered when there are >= 2 roots"""
-    check(lib.h2mi_memset_zero(out.ptr, n * 32), "zero")
+def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf, stream=None):
+    """out = src / prod (X - root); src is clobbered when there are >= 2 roots.  `out` must have been zeroed (the
+    quotient has n - len(roots) coefficients; the rest of the n stay zero)"""
     cur, length = src, n
     bufs = [tmp, src]
     for i, root in enumerate(roots):
         last = i == len(roots) - 1
         dst = out if last else bufs[i % 2]
         b, b_inv = _m(root), _m(pow(root, -1, R))  # named: the arrays must outlive the call that reads their memory
-        check(lib.h2mi_fr_kate_division_dev(cur.ptr, length, b.ctypes.data, b_inv.ctypes.data, dst.ptr, None), "kate_division")
+        check(lib.h2mi_fr_kate_division_dev(cur.ptr, length, b.ctypes.data, b_inv.ctypes.data, dst.ptr, stream), "kate_division")
         cur, length = dst, length - 1
 
 
 class ProverSHPLONK:
+    LANES = 3  # rotation sets worked on at once: the library stream and two side streams, each with its own scratch
+
     def __init__(self, n: int):
         """n: number of rows (coefficients per polynomial) — the domain size, not the length of an SRS slice"""
         self.n = n
-        self._nx, self._tmp, self._q = DevBuf(n * 32), DevBuf(n * 32), [DevBuf(n * 32) for _ in range(6)]
+        self._nx = [DevBuf(n * 32) for _ in range(self.LANES)]
+        self._tmp = [DevBuf(n * 32) for _ in range(self.LANES)]
+        self._q = [DevBuf(n * 32) for _ in range(6)]
+        self._side = [None] + [SideStream() for _ in range(self.LANES - 1)]
         self.h_x, self.l_x, self.h2_x = DevBuf(n * 32), DevBuf(n * 32), DevBuf(n * 32)
 
     def release(self):
-        for b in [self._nx, self._tmp, self.h_x, self.l_x, self.h2_x] + self._q:
+        for b in self._nx + self._tmp + [self.h_x, self.l_x, self.h2_x] + self._q:
             b.free()
+        for st in self._side[1:]:
+            st.free()
 
     def create_proof(self, transcript, queries, commit_and_write) -> None:
         """`commit_and_write(d_poly)` commits a coefficient vector (ParamsKZG::commit), writes the point to the
@@ -131,16 +138,27 @@ class ProverSHPLONK:
         sets, super_points = construct_intermediate_sets(queries)
         assert len(sets) <= len(self._q)
         v = F.fr_from_mont_limbs(transcript.squeeze_challenge())
-        # quotient contributions Q_i = (sum_j y^j (P_ij - R_ij)) / Z_i
+        # quotient contributions Q_i = (sum_j y^j (P_ij - R_ij)) / Z_i.  The sets are independent chains of small
+        # launches (one linear combination, one division per point of the set): set i runs on lane i mod 3, so the
+        # longest chain, not their sum, is what the proof waits for.
+        for i in range(len(sets)):
+            check(lib.h2mi_memset_zero(self._q[i].ptr, n * 32), "zero")
+        for st in self._side[1:]:
+            st.after_library()
         for i, rs in enumerate(sets):
+            lane = i % self.LANES
+            stream = self._side[lane].handle if lane else None
+            nx, tmp = self._nx[lane], self._tmp[lane]
             ypow = [pow(y, j, R) for j in range(len(rs.members))]
-            _lincomb([p for p, _ in rs.members], ypow, n, self._nx)
+            _lincomb([p for p, _ in rs.members], ypow, n, nx, stream)
             rsum = [0] * len(rs.points)
             for (_, evals), yp in zip(rs.members, ypow):
                 for t, c in enumerate(_interpolate(rs.points, evals)):
                     rsum[t] = (rsum[t] - yp * c) % R
-            _add_head(self._nx, rsum)
-            _kate_chain(self._nx, n, rs.points, self._tmp, self._q[i])
+            _add_head(nx, rsum, stream)
+            _kate_chain(nx, n, rs.points, tmp, self._q[i], stream)
+        for st in self._side[1:]:
+            st.join_library()
         _lincomb(self._q[: len(sets)], [pow(v, i, R) for i in range(len(sets))], n, self.h_x)
         commit_and_write(self.h_x)
         u = F.fr_from_mont_limbs(transcript.squeeze_challenge())
@@ -160,5 +178,6 @@ class ProverSHPLONK:
         scalars.append((-zt_eval * norm) % R)
         _lincomb(polys, scalars, n, self.l_x)
         _add_head(self.l_x, [const])
-        _kate_chain(self.l_x, n, [u], self._tmp, self.h2_x)
+        check(lib.h2mi_memset_zero(self.h2_x.ptr, n * 32), "zero")
+        _kate_chain(self.l_x, n, [u], self._tmp[0], self.h2_x)
         commit_and_write(self.h2_x)
