@@ -231,3 +231,51 @@ def test_adhoc_bases_are_cached_not_rebuilt(gpu):
         sj = np.ascontiguousarray(sc[0][:1000])
         assert o.unpack_jacobian(h2.best_multiexp(sj, bj)) == o.unpack_jacobian(cref.msm(sj, bj, 1))
     assert nbuilds() == b0 + 7
+
+
+def test_side_streams_run_transforms_and_divisions_beside_the_library_stream(gpu):
+    """h2mi_stream_create / h2mi_stream_wait: six side streams (more than the library keeps scratch vectors for, so the
+    least-recently-used scratch is handed on behind its last user) each run lagrange_to_coeff -> coeff_to_extended of
+    their own column and a kate_division, interleaved with the same work on the library stream; every result equals the
+    oracle's.  Ordering across streams is only what after_library() / join_library() state."""
+    h2 = gpu
+    from halo2_scaffold_amd.device import DevBuf, SideStream
+
+    k = 12
+    n = 1 << k
+    dom = h2.EvaluationDomain(3, k)
+    odom = o.Domain(k, 3)
+    ext = dom.extended_len()
+    sides = [SideStream() for _ in range(6)]
+    lanes = [None] + [s.handle for s in sides]
+    cols, polys, cosets, quots, want = [], [], [], [], []
+    for i in range(len(lanes)):
+        vals = o.random_field_limbs(n, o.SEED + 100 + i)
+        cols.append(DevBuf.from_numpy(vals))
+        polys.append(DevBuf(n * 32))
+        cosets.append(DevBuf(ext * 32))
+        quots.append(DevBuf(n * 32))
+        coeffs = odom.lagrange_to_coeff(o.unpack(vals, o.R))
+        want.append((coeffs, odom.coeff_to_extended(coeffs), o.kate_division(coeffs, 1234567 + i)))
+    for s in sides:
+        s.after_library()  # the uploads above went through the library stream
+    for rnd in range(2):  # twice: the second round reuses scratches that changed hands in the first
+        for i, st in enumerate(lanes):
+            dom.lagrange_to_coeff_oop_dev(cols[i], polys[i], stream=st)
+            dom.coeff_to_extended_oop_dev(polys[i], cosets[i], stream=st)
+            b, b_inv = _fr(h2, 1234567 + i), _fr(h2, pow(1234567 + i, -1, o.R))
+            assert h2.lib.h2mi_fr_kate_division_dev(polys[i].ptr, n, b.ctypes.data, b_inv.ctypes.data, quots[i].ptr, st) == 0
+    for s in sides:
+        s.join_library()
+    for i in range(len(lanes)):
+        coeffs, coset, quot = want[i]
+        assert o.unpack(polys[i].to_numpy(shape=(n, 4)), o.R) == coeffs, i
+        assert o.unpack(cosets[i].to_numpy(shape=(ext, 4)), o.R) == coset, i
+        assert o.unpack(quots[i].to_numpy(shape=(n, 4)), o.R)[: n - 1] == quot, i
+    for b in cols + polys + cosets + quots:
+        b.free()
+    for s in sides:
+        s.free()
+    # waiting on oneself and on the library stream from the library stream are no-ops, a null stream handle is refused
+    assert h2.lib.h2mi_stream_wait(None, None) == 0
+    assert h2.lib.h2mi_stream_destroy(None) != 0
