@@ -753,9 +753,10 @@ __global__ void __launch_bounds__(256) k_perm_numden(PermArgs a, size_t n, uint3
 // the same for every set of a permutation argument at once: t = set * u + i over the concatenated usable rows
 // (set = chunk of `chunk` consecutive columns); the running product then chains the sets by itself
 __global__ void __launch_bounds__(256) k_perm_numden_sets(PermArgs a, uint32_t chunk, size_t total, uint32_t u, const fe* wlo, const fe* whi, uint32_t wh,
-                                                           fe* num, fe* den) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+                                                           const uint32_t* active, fe* num, fe* den) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // element of the (compacted) concatenation
+  if (e >= total) return;
+  const size_t t = active ? active[e] : e;
   const uint32_t set = (uint32_t)(t / u), i = (uint32_t)(t - (size_t)set * u);
   const f29 w = pow2tab(wlo, whi, wh, i);  // omega^i (Mont261)
   f29 pn = f29_const<F9>(F9::ONE), pd = pn;
@@ -765,17 +766,28 @@ __global__ void __launch_bounds__(256) k_perm_numden_sets(PermArgs a, uint32_t c
     pn = f29_mul<F9>(nf, pn);
     pd = f29_mul<F9>(df, pd);
   }
-  fe_store(&num[t], pack261(pn));
-  fe_store(&den[t], pack261(pd));
+  fe_store(&num[e], pack261(pn));
+  fe_store(&den[e], pack261(pd));
 }
 struct ZOut {
   fe* z[8];
 };
-// z_set[i] = product of every ratio before (set, i) in the concatenated order: R[set * u + i - 1], one at the very start
-__global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u, ZOut out) {
+// z_set[i] = product of every ratio before (set, i) in the concatenated order: R[set * u + i - 1], one at the very start.
+// With an `active` list (sorted positions whose ratio can differ from one, see h2mi_plonk_permutation_products_sparse_dev)
+// R holds the prefix products over those positions only: z = R[c - 1], c = number of active positions before (set, i).
+__global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u, ZOut out, const uint32_t* active, uint32_t n_active) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, set = blockIdx.y;
   if (i > u) return;
-  const size_t t = (size_t)set * u + i;
+  size_t t = (size_t)set * u + i;
+  if (active) {
+    uint32_t lo = 0, hi = n_active;  // first index with active[idx] >= t
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (active[mid] < t) lo = mid + 1;
+      else hi = mid;
+    }
+    t = lo;
+  }
   fe o = fe_one<Fr>();
   if (t) f29_to_mont256<F9>(ld261(&R[t - 1]), o.v);
   fe_store(&out.z[set][i], o);
@@ -1517,9 +1529,9 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
   return release_tmp(s);
 }
 
-int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
-                                        uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows,
-                                        const uint64_t omega[4], void* const* d_z, h2mi_stream_t stream) {
+static int perm_products(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k, uint32_t usable_rows,
+                         const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows, const uint64_t omega[4],
+                         const uint32_t* d_active, uint32_t n_active, void* const* d_z, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
   if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8 || chunk_len == 0) return H2MI_EINVAL;
   if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
@@ -1527,6 +1539,7 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
   CallScope scope_;
   hipStream_t s = pick_stream(stream);
   const uint32_t sets = (m + chunk_len - 1) / chunk_len;
+  if (d_active && (uint64_t)sets * usable_rows >= ((uint64_t)1 << 32)) return H2MI_ERANGE;  // positions are 32-bit
   PermArgs a;
   memset(&a, 0, sizeof(a));
   a.m = m;
@@ -1544,10 +1557,15 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
     if (!d_z[q]) return H2MI_EINVAL;
     zo.z[q] = (fe*)d_z[q];
   }
+  const dim3 wgrid(ceil_div_u32((uint64_t)usable_rows + 1, 256), sets);
+  if (d_active && n_active == 0) {  // no copy constraint touches a usable row: every product is one
+    H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, wgrid, 256, 0, s, (const fe*)nullptr, usable_rows, zo, d_active, 0u);
+    return H2MI_OK;
+  }
   PowTab pw;
   int rc = get_powtab(omega, k, s, &pw);
   if (rc) return rc;
-  const size_t total = (size_t)sets * usable_rows;
+  const size_t total = d_active ? (size_t)n_active : (size_t)sets * usable_rows;  // elements the scans run over
   const uint32_t nblocks = ceil_div_u32(total, MS_TILE);
   rc = ensure_tmp(3 * total + 2 * (size_t)nblocks + 2, s);
   if (rc) return rc;
@@ -1558,7 +1576,7 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
   fe* offsets = totals + nblocks;
   fe* inv_total = offsets + nblocks;
   H2_LAUNCH("k_perm_numden_sets", k_perm_numden_sets, ceil_div_u32(total, 256), 256, 0, s, a, chunk_len, total, usable_rows, (const fe*)pw.lo, (const fe*)pw.hi,
-            pw.h, num, P);
+            pw.h, d_active, num, P);
   H2_HIP(hipMemcpyAsync(S, P, total * 32, hipMemcpyDeviceToDevice, s));
   rc = mulscan(P, total, 0, totals, offsets, s);
   if (!rc) rc = mulscan(S, total, 1, totals, offsets, s);
@@ -1567,8 +1585,22 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
   H2_LAUNCH("k_perm_ratio", k_perm_ratio, ceil_div_u32(total, 256), 256, 0, s, (const fe*)num, (const fe*)P, (const fe*)S, (const fe*)inv_total, total, num);
   rc = mulscan(num, total, 0, totals, offsets, s);
   if (rc) return rc;
-  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), sets), 256, 0, s, (const fe*)num, usable_rows, zo);
+  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, wgrid, 256, 0, s, (const fe*)num, usable_rows, zo, d_active, n_active);
   return release_tmp(s);
+}
+
+int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
+                                        uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows,
+                                        const uint64_t omega[4], void* const* d_z, h2mi_stream_t stream) {
+  return perm_products(d_values, d_sigmas, m, chunk_len, k, usable_rows, beta, gamma, beta_delta_pows, omega, nullptr, 0, d_z, stream);
+}
+
+int h2mi_plonk_permutation_products_sparse_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
+                                               uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows,
+                                               const uint64_t omega[4], const void* d_active, uint32_t n_active, void* const* d_z, h2mi_stream_t stream) {
+  if (!d_active) return H2MI_EINVAL;
+  return perm_products(d_values, d_sigmas, m, chunk_len, k, usable_rows, beta, gamma, beta_delta_pows, omega, (const uint32_t*)d_active, n_active, d_z,
+                       stream);
 }
 
 int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,
@@ -1602,7 +1634,7 @@ int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, cons
   ZOut zo;
   memset(&zo, 0, sizeof(zo));
   zo.z[0] = (fe*)d_z;
-  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), 1), 256, 0, s, (const fe*)num, usable_rows, zo);
+  H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, dim3(ceil_div_u32((uint64_t)usable_rows + 1, 256), 1), 256, 0, s, (const fe*)num, usable_rows, zo, (const uint32_t*)nullptr, 0u);
   return release_tmp(s);
 }
 

@@ -241,6 +241,7 @@ class FlexKeys:
                 self.sigma_values[j].upload(_m(pow(FR_DELTA, tj, R) * pow(d.omega, ti, R) % R), offset=i * 32)
         check(lib.h2mi_sync(), "sync")
         omega_pows.free()
+        self.active_rows = gp.ActiveRows(asm.mapping, cs.chunk, u)  # the support of the copy constraints (sparse grand products)
         self.fixed_commitments = commit_points(params, self.fixed_values, lagrange=True)
         self.permutation_commitments = commit_points(params, self.sigma_values, lagrange=True)
         h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
@@ -284,6 +285,7 @@ class FlexKeys:
             b.free()
         if self.table is not None:
             self.table.free()
+        self.active_rows.free()
 
 
 # ---- create_proof --------------------------------------------------------------------------------------------------------
@@ -412,7 +414,7 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     perm_values = [col_of[kind][c] for kind, c in cs.perm_columns]
     n_sets = -(-len(perm_values) // cs.chunk)
     zs = [dev(n) for _ in range(n_sets)]
-    gp.permutation_products(d.k, perm_values, list(pk.sigma_values), cs.chunk, beta, gamma, u, zs)
+    gp.permutation_products(d.k, perm_values, list(pk.sigma_values), cs.chunk, beta, gamma, u, zs, active=pk.active_rows)
     zblind = synth.uniform_fr(n_sets * bf, seed + 2)
     for s, z in enumerate(zs):
         z.patch(zblind[s * bf : (s + 1) * bf], offset=(u + 1) * 32)

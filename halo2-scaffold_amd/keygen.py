@@ -22,6 +22,7 @@ from . import serde
 from ._lib import check, lib
 from .circuits import PermutationAssembly
 from .device import DevBuf
+from . import plonk as gp
 from .domain import EvaluationDomain
 from .params import ParamsKZG
 
@@ -127,13 +128,13 @@ def _sigma_columns(circuit, syn, domain: EvaluationDomain):
             _patch(cols[col], row, pow(FR_DELTA, tc, R) * pow(domain.omega, tr, R) % R)
     check(lib.h2mi_sync(), "sync")
     omega_pows.free()
-    return cols
+    return cols, asm.mapping
 
 
 def keygen_vk(params: ParamsKZG, circuit) -> VerifyingKey:
     domain = EvaluationDomain(circuit.CS_DEGREE, params.k)
     fixed, syn = _fixed_columns(circuit, domain.n)
-    sigma = _sigma_columns(circuit, syn, domain)
+    sigma, _ = _sigma_columns(circuit, syn, domain)
     fc = commit_points(params, fixed, lagrange=True)
     pc = commit_points(params, sigma, lagrange=True)
     for b in fixed + sigma:
@@ -148,6 +149,7 @@ class ProvingKey:
         self.fixed = fixed              # fixed_polys / fixed_cosets
         self.permutation = permutation  # permutations (Lagrange: the grand product reads them), polys, cosets
         self.l0, self.l_last, self.l_active = l0, l_last, l_active
+        self.active_rows = None
 
     def get_vk(self) -> VerifyingKey:
         return self.vk
@@ -157,13 +159,15 @@ class ProvingKey:
         self.permutation.free()
         for b in (self.l0, self.l_last, self.l_active):
             b.free()
+        if self.active_rows is not None:
+            self.active_rows.free()
 
 
 def keygen_pk(params: ParamsKZG, vk: VerifyingKey, circuit) -> ProvingKey:
     domain = vk.domain
     n, ext = domain.n, domain.extended_len()
     fixed, syn = _fixed_columns(circuit, n)
-    sigma = _sigma_columns(circuit, syn, domain)
+    sigma, mapping = _sigma_columns(circuit, syn, domain)
     fcols = _Columns(domain, fixed, keep_lagrange=False)
     pcols = _Columns(domain, sigma, keep_lagrange=True)
     # l_0, l_last (row n - blinding_factors - 1), l_active = 1 - (l_last + l_blind): ones on the usable rows
@@ -179,4 +183,7 @@ def keygen_pk(params: ParamsKZG, vk: VerifyingKey, circuit) -> ProvingKey:
     lcols = _Columns(domain, lag, keep_lagrange=False)
     for p in lcols.polys:
         p.free()
-    return ProvingKey(vk, circuit, fcols, pcols, *lcols.cosets)
+    pk = ProvingKey(vk, circuit, fcols, pcols, *lcols.cosets)
+    # the rows the copy constraints touch: the only ones at which a permutation grand product changes
+    pk.active_rows = gp.ActiveRows(mapping, circuit.CS_DEGREE - 2, u)
+    return pk

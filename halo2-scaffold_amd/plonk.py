@@ -73,10 +73,26 @@ def permutation_product(k: int, values, sigmas, column_indices, beta: int, gamma
                                                  d_last.ptr if d_last is not None else None, None), "permutation_product")
 
 
-def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamma: int, usable_rows: int, d_zs) -> None:
+class ActiveRows:
+    """keygen-time support of the copy constraints for h2mi_plonk_permutation_products_sparse_dev: the sorted positions
+    set * usable_rows + row at which some column of the set is moved by the permutation (`mapping`: the non-identity
+    entries of permutation/keygen.rs `Assembly`, keyed (column index in the argument, row)).  Rows the permutation leaves
+    alone contribute num / den = 1 exactly, so the grand products only change at these positions."""
+
+    def __init__(self, mapping, chunk_len: int, usable_rows: int):
+        pos = sorted({(col // chunk_len) * usable_rows + row for (col, row), target in mapping.items() if target != (col, row) and row < usable_rows})
+        self.count = len(pos)
+        self.buf = DevBuf.from_numpy(np.array(pos if pos else [0], dtype=np.uint32))
+
+    def free(self):
+        self.buf.free()
+
+
+def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamma: int, usable_rows: int, d_zs, active: ActiveRows = None) -> None:
     """Every set of the permutation argument in one device pass (plonk/permutation/prover.rs `Argument::commit`):
     `values` / `sigmas` are the equality-enabled columns in argument order, chunked by `chunk_len` = cs.degree() - 2;
-    d_zs[s] receives rows 0 .. usable_rows of set s, chained through the previous set's last value."""
+    d_zs[s] receives rows 0 .. usable_rows of set s, chained through the previous set's last value.  With `active`
+    (ActiveRows from keygen) the products are computed over the constrained positions only — same values."""
     m = len(values)
     sets = -(-m // chunk_len)
     assert m == len(sigmas) and 1 <= m <= 8 and len(d_zs) == sets
@@ -87,6 +103,10 @@ def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamm
     bd = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(beta * pow(FR_DELTA, j, r) % r) for j in range(m)]))
     b_, g_ = F.fr_to_mont_limbs(beta), F.fr_to_mont_limbs(gamma)
     w = F.fr_to_mont_limbs(F.omega_for(k))
+    if active is not None and active.count * 8 <= sets * usable_rows:  # dense supports gain nothing from the indirection
+        check(lib.h2mi_plonk_permutation_products_sparse_dev(vp, sp, m, chunk_len, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data,
+                                                             w.ctypes.data, active.buf.ptr, active.count, zp, None), "permutation_products_sparse")
+        return
     check(lib.h2mi_plonk_permutation_products_dev(vp, sp, m, chunk_len, k, usable_rows, b_.ctypes.data, g_.ctypes.data, bd.ctypes.data, w.ctypes.data,
                                                   zp, None), "permutation_products")
 

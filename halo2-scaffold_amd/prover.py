@@ -162,7 +162,8 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
 
     # ---- permutation argument: one grand product per column (chunk length cs.degree() - 2 = 1), one device pass ---
     zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
-    gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z)
+    gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z,
+                            active=pk.active_rows)
     for m, z in enumerate(ws.z):
         z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
     for i, z in enumerate(ws.z):

@@ -233,6 +233,16 @@ int h2mi_plonk_permutation_products_dev(const void* const* d_values, const void*
                                         uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4],
                                         const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4], void* const* d_z,
                                         h2mi_stream_t stream);
+/* The same with the support of the copy constraints known (a keygen-time fact): `d_active` holds, sorted ascending, the
+ * positions set * usable_rows + row (uint32) at which some column of the set has sigma != the identity permutation — the
+ * only rows whose ratio can differ from one.  Numerators, denominators, the inversion and the scans then run over these
+ * n_active positions only and every z row is filled from the prefix product of the positions before it: same values, work
+ * proportional to the constrained cells plus one write per row (the halo2-lib examples constrain 10 .. 10^4 of 2^20 rows).
+ * n_active = 0: every product is one. */
+int h2mi_plonk_permutation_products_sparse_dev(const void* const* d_values, const void* const* d_sigmas, uint32_t m, uint32_t chunk_len, uint32_t k,
+                                               uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4],
+                                               const uint64_t* beta_delta_pows, const uint64_t omega[4], const void* d_active, uint32_t n_active,
+                                               void* const* d_z, h2mi_stream_t stream);
 
 /* ---- lookup argument (plonk/lookup/prover.rs), single-expression lookups: the range check the reference's
  * RangeWithInstanceCircuitBuilder configures with LOOKUP_BITS (src/scaffold.rs:44-48,434-485; examples/range.rs:10-34).

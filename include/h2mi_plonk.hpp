@@ -264,6 +264,10 @@ struct ProvingKey {
   poly::EvaluationDomain domain;
   Columns fixed, permutation;
   Dev l0, l_last, l_active;
+  // support of the copy constraints: sorted positions set * usable_rows + row (uint32) at which a column of the set is
+  // moved by the permutation — what h2mi_plonk_permutation_products_sparse_dev runs over
+  Dev active_rows;
+  uint32_t n_active = 0;
   explicit ProvingKey(const VerifyingKey& v) : vk(v), domain(v.cs_degree, v.k) {}
   const VerifyingKey& get_vk() const { return vk; }
 };
@@ -384,6 +388,19 @@ inline std::unique_ptr<ProvingKey> keygen_pk(const poly::kzg::ParamsKZG& params,
   detail::to_poly_and_coset(dom, *l0, unused, pk->l0);
   detail::to_poly_and_coset(dom, *ll, unused, pk->l_last);
   detail::to_poly_and_coset(dom, *la, unused, pk->l_active);
+  {
+    PermutationAssembly asm_;
+    for (const auto& c : syn.copies) asm_.copy(c.first, c.second);
+    const uint32_t chunk = StandardPlonk::CS_DEGREE - 2;
+    std::vector<uint32_t> pos;
+    for (const auto& kv : asm_.mapping())
+      if (kv.first != kv.second && kv.first.second < u) pos.push_back((kv.first.first / chunk) * u + kv.first.second);
+    std::sort(pos.begin(), pos.end());
+    pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
+    pk->n_active = (uint32_t)pos.size();
+    pk->active_rows.reset(new DeviceVec(pos.size() / 8 + 1));
+    if (!pos.empty()) check(h2mi_memcpy_h2d(pk->active_rows->p, pos.data(), pos.size() * 4), "active rows");
+  }
   check(h2mi_sync(), "sync");
   return pk;
 }
@@ -634,8 +651,9 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     zs.push_back(z[j]->p);
     bd.push_back(fr::mul(beta, fr::pow_u64(delta, j)));
   }
-  check(h2mi_plonk_permutation_products_dev(vals.data(), sigs.data(), na, StandardPlonk::CS_DEGREE - 2, d.k(), u, beta.l, gamma.l, (const uint64_t*)bd.data(),
-                                            omega.l, zs.data(), nullptr), "permutation_products");
+  check(h2mi_plonk_permutation_products_sparse_dev(vals.data(), sigs.data(), na, StandardPlonk::CS_DEGREE - 2, d.k(), u, beta.l, gamma.l,
+                                                   (const uint64_t*)bd.data(), omega.l, pk.active_rows->p, pk.n_active, zs.data(), nullptr),
+        "permutation_products");
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)na * bf);
   for (uint32_t m = 0; m < na; m++)
     check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");

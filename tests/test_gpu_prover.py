@@ -249,7 +249,28 @@ def test_permutation_products_all_sets_match_formula(gpu, k, m, chunk):
     gp.permutation_products(k, dv, ds, chunk, beta, gamma, u, dz)
     for s in range(sets):
         assert _vals(dz[s], n) == want[s], s
-    for b in dv + ds + dz:
+    # the sparse form (h2mi_plonk_permutation_products_sparse_dev): the support of the permutation handed over as keygen
+    # knows it — here read off sigma — gives the same columns from the ~40 constrained rows alone
+    mapping = {(j, i): None for j in range(m) for i in range(u) if sig[j][i] != ident(j, i)}
+    active = gp.ActiveRows(mapping, chunk, u)
+    assert 0 < active.count <= 40
+    for b in dz:
+        b.upload(o.pack([0xDEAD] * n, o.R))
+    gp.permutation_products(k, dv, ds, chunk, beta, gamma, u, dz, active=active)
+    for s in range(sets):
+        assert _vals(dz[s], n) == want[s], s
+    active.free()
+    # no constrained row at all (identity permutation): every product is one on rows 0 .. u, the rest untouched
+    di = [gpu.DevBuf.from_numpy(o.pack([ident(j, i) for i in range(n)], o.R)) for j in range(m)]
+    empty = gp.ActiveRows({}, chunk, u)
+    assert empty.count == 0
+    for b in dz:
+        b.upload(o.pack([0xDEAD] * n, o.R))
+    gp.permutation_products(k, dv, di, chunk, beta, gamma, u, dz, active=empty)
+    for s in range(sets):
+        assert _vals(dz[s], n) == [1] * (u + 1) + [0xDEAD] * (n - u - 1), s
+    empty.free()
+    for b in dv + ds + dz + di:
         b.free()
 
 
