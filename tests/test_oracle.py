@@ -231,6 +231,12 @@ def test_eip196_vectors_python_oracle():
         assert o.jac_to_affine(o.jac_mul(k % o.R, o.jac_from_affine(p))) == want, v["name"]
     assert o.FR_ROOT_OF_UNITY == int(EIP196["fr_root_of_unity"], 16) and o.FR_S == EIP196["fr_two_adicity"]
     assert pow(o.FR_ROOT_OF_UNITY, 1 << 28, o.R) == 1 and pow(o.FR_ROOT_OF_UNITY, 1 << 27, o.R) == o.R - 1
+    # Fr::DELTA and Fr::ZETA as recalled from the crate (see the file's provenance): the coset generator and the
+    # permutation argument's column separator the whole prover rests on
+    from oracle import plonk as P
+
+    assert o.FR_ZETA == int(EIP196["fr_zeta"], 16) and P.FR_DELTA == int(EIP196["fr_delta"], 16)
+    assert o.FR_ZETA * o.FR_ZETA % o.R == int(EIP196["fr_zeta_squared_other_root"], 16) and pow(o.FR_ZETA, 3, o.R) == 1
 
 
 def test_eip196_vectors_c_restatement():
