@@ -219,6 +219,8 @@ class FlexKeys:
         self.table = None
         if cs.lookup:
             tv = asg.table_values
+            if len(tv) > u:
+                raise ValueError(f"lookup table of {len(tv)} rows does not fit the {u} usable rows of a 2^{k} circuit (LOOKUP_BITS must be below DEGREE)")
             fixed_cells[2] = dict(enumerate(tv))
             self.table = gp.LookupTable(tv + [0] * (u - len(tv)), u)
         self.fixed_values = [_column_from_cells(n, cells) for cells in fixed_cells]
