@@ -69,6 +69,7 @@ def _load():
         "h2mi_stream_wait": ([vp, vp], C.c_int),
         "h2mi_fr_add_head_dev": ([vp, vp, sz, vp], C.c_int),
         "h2mi_fr_fill_dev": ([vp, sz, vp, vp], C.c_int),
+        "h2mi_fr_mul_dev": ([vp, vp, sz, vp, vp], C.c_int),
         "h2mi_fr_random_dev": ([vp, sz, C.c_uint64, C.c_uint64, vp], C.c_int),
         "h2mi_ntt_bn254_fr": ([vp, vp, C.c_uint32], C.c_int),
         "h2mi_ntt_ext_bn254_fr": ([vp, C.c_uint32, vp, vp, vp], C.c_int),

@@ -456,6 +456,13 @@ __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe*
 }
 
 // out[i] = value
+// out[i] = a[i] * b[i] (Montgomery-2^256 in and out): the row values of a product expression, e.g. selector * advice as a
+// lookup's input (mixed-domain product: one operand converted, the other taken as it lies in memory)
+__global__ void __launch_bounds__(256) k_fr_mul(const fe* a, const fe* b, size_t n, fe* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pack_store(&out[i], f29_mul<F9>(f29_from_mont256<F9>(fe_load(&a[i]).v), load_unpack(&b[i])));
+}
 __global__ void __launch_bounds__(256) k_fr_fill(fe* out, size_t n, fe value) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) fe_store(&out[i], value);
@@ -513,6 +520,7 @@ struct TInv {  // (X^n - 1)^-1 on the extended coset: 2^(extended_k - k) <= 16 d
 struct HConsts {
   fe beta_m1;            // beta at level -1: beta * sigma lands on level 0
   fe beta0, gamma0, one0;  // level 0: the plain Montgomery-2^256 words
+  fe one_m2;             // one at level -2: brings a level-1 product (selector * advice) back to level 0
   fe cur[4];             // beta zeta DELTA^j at level 0: times X (level -1, straight from the power table) = level 0
   fe y[20];              // per-term powers of y at the level each use needs (layout: see the kernels / fill_* below)
   fe tinv[16];           // level -1
@@ -808,12 +816,13 @@ __global__ void __launch_bounds__(256) k_lookup_numden(const fe* input, const fe
 // ---- quotient numerator of the range-check constraint system (BASELINE config 3) -------------------
 // What the reference's RangeWithInstanceCircuitBuilder produces (src/scaffold.rs:434-485) [halo2-base shape restated
 // from memory]: one vertical gate q (a + a(wX) a(w^2 X) - a(w^3 X)) on the advice column, a permutation argument over
-// n_perm <= 4 equality-enabled columns in chunks of two (constraint-system degree 4), one single-expression lookup of
-// the lookup-advice column in the fixed table.  Terms in evaluate_h's order (gates, permutation, lookups), Horner in y,
+// n_perm <= 4 equality-enabled columns in chunks of one to three (constraint-system degree 3 .. 5), one single-expression
+// lookup in the fixed table of either a lookup-advice column or selector * advice (halo2-base with one advice column).  Terms in evaluate_h's order (gates, permutation, lookups), Horner in y,
 // divided by X^n - 1; extended domain 4n.
 struct RangeCosets {
   const fe* a;
-  const fe* la;
+  const fe* la;   // lookup input: a dedicated lookup-advice column ...
+  const fe* ql;   // ... or, when non-null, the selector of the single-advice-column form: input = ql * a
   const fe* q;
   const fe* table;
   const fe* perm_value[4];
@@ -873,7 +882,8 @@ __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_
     sl = f29_add(sl, hmul(hmul(zl, hsub(zl, one)), hc(h.y[lb + 1])));
     {  // z(wX) (A' + beta) (S' + gamma) - z (A + beta) (S + gamma)
       f29 lhs = hmul(f29_add(sp, gamma), hmul(f29_add(ap, beta), load_unpack(&c.lk_z[r_next])));
-      f29 tv = hmul(f29_add(load_unpack(&c.la[idx]), beta), f29_normalize(f29_add(load_unpack(&c.table[idx]), gamma)));
+      const f29 a_in = c.ql ? hmul(hmul(load_unpack(&c.ql[idx]), load_unpack(&c.a[idx])), hc(h.one_m2)) : load_unpack(&c.la[idx]);
+      f29 tv = hmul(f29_add(a_in, beta), f29_normalize(f29_add(load_unpack(&c.table[idx]), gamma)));
       f29 rhs = hmul(tv, zl);
       sa = f29_add(sa, hmul(hsub(lhs, rhs), hc(h.y[lb + 2])));
     }
@@ -956,6 +966,7 @@ static void fill_common(HConsts& h, const fe& beta, const fe& gamma, const fe& d
   h.beta_m1 = h_level(beta, -1);
   h.gamma0 = gamma;
   h.one0 = h_canon(f29_const<F9>(F9::TO256));
+  h.one_m2 = h_level(h.one0, -2);
   fe cur = h_mul256(beta, zeta);
   for (uint32_t j = 0; j < n_cur; j++) {
     h.cur[j] = cur;
@@ -1438,6 +1449,15 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, siz
 }
 
 
+int h2mi_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_a || !d_b || !d_out || n == 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  H2_LAUNCH("k_fr_mul", k_fr_mul, ceil_div_u32(n, 256), 256, 0, s, (const fe*)d_a, (const fe*)d_b, n, (fe*)d_out);
+  return H2MI_OK;
+}
+
 int h2mi_fr_fill_dev(void* d_out, size_t n, const uint64_t value[4], h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
   if (!d_out || !value || n == 0) return H2MI_EINVAL;
@@ -1644,17 +1664,17 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
   H2_REQUIRE_INIT();
   if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
   if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
-  if (c->n_perm == 0 || c->n_perm > 4 || c->chunk_len == 0 || c->chunk_len > 2) return H2MI_EINVAL;
+  if (c->n_perm == 0 || c->n_perm > 4 || c->chunk_len == 0 || c->chunk_len > 3) return H2MI_EINVAL;
   RangeCosets rc_;
   memset(&rc_, 0, sizeof(rc_));
-  rc_.a = (const fe*)c->a; rc_.la = (const fe*)c->lookup_advice; rc_.q = (const fe*)c->q; rc_.table = (const fe*)c->table;
+  rc_.a = (const fe*)c->a; rc_.la = (const fe*)c->lookup_advice; rc_.ql = (const fe*)c->lookup_selector; rc_.q = (const fe*)c->q; rc_.table = (const fe*)c->table;
   rc_.lk_input = (const fe*)c->lookup_permuted_input; rc_.lk_table = (const fe*)c->lookup_permuted_table; rc_.lk_z = (const fe*)c->lookup_z;
   rc_.l0 = (const fe*)c->l0; rc_.l_last = (const fe*)c->l_last; rc_.l_active = (const fe*)c->l_active;
   rc_.n_perm = c->n_perm;
   rc_.chunk = c->chunk_len;
   rc_.has_lookup = c->has_lookup ? 1u : 0u;
   if (!rc_.a || !rc_.q || !rc_.l0 || !rc_.l_last || !rc_.l_active) return H2MI_EINVAL;
-  if (rc_.has_lookup && (!rc_.la || !rc_.table || !rc_.lk_input || !rc_.lk_table || !rc_.lk_z)) return H2MI_EINVAL;
+  if (rc_.has_lookup && ((!rc_.la && !rc_.ql) || !rc_.table || !rc_.lk_input || !rc_.lk_table || !rc_.lk_z)) return H2MI_EINVAL;
   for (uint32_t j = 0; j < c->n_perm; j++) {
     rc_.perm_value[j] = (const fe*)c->perm_value[j];
     rc_.perm_sigma[j] = (const fe*)c->perm_sigma[j];

@@ -4,14 +4,15 @@ configs[3] (range.rs: range_check(x, 64) with a LOOKUP_BITS table).
 
 The reference builds these circuits with halo2-base (GateWithInstanceCircuitBuilder / RangeWithInstanceCircuitBuilder,
 src/scaffold.rs:379-485: FlexGate's vertical gate q (a + a(wX) a(w^2 X) - a(w^3 X)) on the advice column, a constants
-column, RangeConfig's lookup-advice column and table, and one instance column added — and equality-enabled — last,
-:394-395, :449-450).  halo2-base is an un-vendored dependency; its cell layout (load_witness, mul, add, mul_add,
+column, RangeConfig's table and — these circuits fit one advice column, so — its complex selector q_lookup on the
+looked-up cells' own rows (`range.q_lookup`, :464-469) instead of a lookup-advice column, and one instance column added —
+and equality-enabled — last, :394-395, :449-450).  halo2-base is an un-vendored dependency; its cell layout (load_witness, mul, add, mul_add,
 range_check's limb decomposition) is restated from memory in `halo2_lib_closure` / `range_closure` below — the witness
 generation a prover runs on the CPU.  Everything after it is the same device pipeline as prover.py, generalised:
 an instance column (public inputs are hashed into the transcript and take part in the permutation argument), advice
-queries at rotations 0..3, permutation sets of `degree - 2` columns, and for the Range builder one lookup argument
-(permuted columns by counting sort against the keygen-sorted table, lookup grand product, five more terms in
-evaluate_h; degree 4: extended domain 4n, three h pieces).  Checked against oracle/flex.py: byte-identical proofs at
+queries at rotations 0..3, permutation sets of `degree - 2` columns, and for the Range builder one lookup argument with
+the input expression q_lookup * a (row values by one element-wise product, permuted columns by counting sort against the
+keygen-sorted table, lookup grand product, five more terms in evaluate_h; degree 5: extended domain 4n, four h pieces).  Checked against oracle/flex.py: byte-identical proofs at
 small k, accepted by its verifier at k = 16 and above (tests/test_gpu_flex.py).
 rng stand-in as in prover.py, plus streams seed+4 (blinding rows of the permuted lookup columns) and seed+5 (of the
 lookup product).
@@ -40,24 +41,38 @@ ADVICE, FIXED, INSTANCE = "advice", "fixed", "instance"
 
 
 class FlexGateCS:
-    """the constraint system of the Gate builder (lookup = False) or the Range builder (lookup = True) at these sizes:
-    one gate advice column; fixed 0 = its selector, fixed 1 = constants, (fixed 2 = the lookup table, advice 1 = the
-    lookup advice); instance 0.  Queries in the order configure() makes them [restated]."""
+    """the constraint system of the Gate builder (lookup = False) or the Range builder (lookup = True) when the circuit
+    fits ONE advice column (every example of the reference at its DEGREE).  Columns in configure()'s allocation order
+    [RECALL halo2-base]: RangeConfig takes the lookup table column first; FlexGateConfig the constants column
+    (enable_equality at once: it leads the permutation argument), then the gate advice column and its simple selector;
+    the scaffold adds the instance column last.  With a single advice column RangeConfig looks up q_lookup * a (complex
+    selector) instead of adding a lookup-advice column.  keygen appends the selector columns: complex ones first.
+      Gate:  fixed 0 constants, 1 q_enable                          degree 3: permutation sets of one, 2 h pieces
+      Range: fixed 0 table, 1 constants, 2 q_lookup, 3 q_enable     degree 2 + 2 + 1 = 5: sets of three, 4 h pieces
+    Queries in creation order (enable_equality queries its column at Rotation::cur)."""
 
     def __init__(self, lookup: bool):
         self.lookup = lookup
-        self.n_advice = 2 if lookup else 1
-        self.n_fixed = 3 if lookup else 2
-        self.perm_columns = [(ADVICE, 0)] + ([(ADVICE, 1)] if lookup else []) + [(FIXED, 1), (INSTANCE, 0)]
-        self.advice_queries = [(0, 0), (0, 1), (0, 2), (0, 3)] + ([(1, 0)] if lookup else [])
-        self.fixed_queries = [(0, 0), (1, 0)] + ([(2, 0)] if lookup else [])
-        self.degree = 4 if lookup else 3          # the lookup argument is what raises it
+        self.n_advice = 1
+        if lookup:
+            self.col_table, self.col_const, self.col_qlookup, self.col_q = 0, 1, 2, 3
+            self.n_fixed = 4
+            self.fixed_queries = [(1, 0), (0, 0), (2, 0), (3, 0)]
+        else:
+            self.col_table = self.col_qlookup = None
+            self.col_const, self.col_q = 0, 1
+            self.n_fixed = 2
+            self.fixed_queries = [(0, 0), (1, 0)]
+        self.perm_columns = [(FIXED, self.col_const), (ADVICE, 0), (INSTANCE, 0)]
+        self.advice_queries = [(0, 0), (0, 1), (0, 2), (0, 3)]
+        self.degree = 5 if lookup else 3          # the lookup of a degree-2 input is what raises it
         self.blinding_factors = 6                 # max(3, four queries on the gate column) + 2
         self.chunk = self.degree - 2
 
 
 class Assignment:
     def __init__(self, cs: FlexGateCS):
+        self.cs = cs
         self.advice = [dict() for _ in range(cs.n_advice)]
         self.fixed = [dict() for _ in range(cs.n_fixed)]
         self.instance = []   # public inputs (column 0)
@@ -67,7 +82,7 @@ class Assignment:
 class Context:
     """halo2-base `Context` on one advice column [layout restated from memory]: cells are appended in program order;
     Existing(cell) re-assigns the value and constrains it equal to the original; Constant(v) cells are tied to one fixed
-    cell per distinct value afterwards; `cells_to_lookup` are copied into the lookup-advice column."""
+    cell per distinct value afterwards; `cells_to_lookup` get q_lookup enabled on their own rows (single-column form)."""
 
     def __init__(self, asg: Assignment):
         self.asg = asg
@@ -89,7 +104,7 @@ class Context:
                 if kind == "constant":
                     self.const_cells.append((row, v % R))
         for off in gate_offsets:
-            self.asg.fixed[0][base + off] = 1
+            self.asg.fixed[self.asg.cs.col_q][base + off] = 1
         return len(self.cells) - 1
 
     # GateInstructions
@@ -121,7 +136,7 @@ class Context:
             self.cells.append((1 << (lookup_bits * i)) % R)
             self.const_cells.append((len(self.cells) - 1, (1 << (lookup_bits * i)) % R))
             self.cells.append(acc % R)
-            self.asg.fixed[0][base] = 1
+            self.asg.fixed[self.asg.cs.col_q][base] = 1
             acc_row = len(self.cells) - 1
         self.asg.copies.append(((ADVICE, 0, a), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
         self.lookup_cells += rows
@@ -130,19 +145,18 @@ class Context:
             self.lookup_cells.append(self.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
                                                               ("witness", limbs[-1] << (lookup_bits - rem))], [0]))
 
-    def finish(self, public_rows, lookup_column=None):
+    def finish(self, public_rows):
         asg = self.asg
+        cs = asg.cs
         asg.advice[0] = dict(enumerate(self.cells))
         consts = {}
         for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, in order of first use
             if v not in consts:
                 consts[v] = len(consts)
-                asg.fixed[1][consts[v]] = v
-            asg.copies.append(((ADVICE, 0, row), (FIXED, 1, consts[v])))
-        if lookup_column is not None:
-            for i, row in enumerate(self.lookup_cells):
-                asg.advice[lookup_column][i] = self.cells[row]
-                asg.copies.append(((ADVICE, lookup_column, i), (ADVICE, 0, row)))
+                asg.fixed[cs.col_const][consts[v]] = v
+            asg.copies.append(((ADVICE, 0, row), (FIXED, cs.col_const, consts[v])))
+        for row in self.lookup_cells:
+            asg.fixed[cs.col_qlookup][row] = 1
         for i, row in enumerate(public_rows):  # layouter.constrain_instance(cell, instance, i): src/scaffold.rs:411, 480
             asg.instance.append(self.cells[row])
             asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
@@ -169,8 +183,8 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
     xc = ctx.load_witness(x)
     ctx.range_check(xc, 64, lookup_bits)
     ctx.add(xc, xc)
-    ctx.finish([xc], lookup_column=1)
-    asg.fixed[2] = None  # dense: filled by keygen from `table_values`
+    ctx.finish([xc])
+    asg.fixed[cs.col_table] = None  # dense: filled by keygen from `table_values`
     asg.table_values = list(range(1 << lookup_bits))
     return asg
 
@@ -221,7 +235,7 @@ class FlexKeys:
             tv = asg.table_values
             if len(tv) > u:
                 raise ValueError(f"lookup table of {len(tv)} rows does not fit the {u} usable rows of a 2^{k} circuit (LOOKUP_BITS must be below DEGREE)")
-            fixed_cells[2] = dict(enumerate(tv))
+            fixed_cells[cs.col_table] = dict(enumerate(tv))
             self.table = gp.LookupTable(tv + [0] * (u - len(tv)), u)
         self.fixed_values = [_column_from_cells(n, cells) for cells in fixed_cells]
         m = len(cs.perm_columns)
@@ -390,8 +404,11 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     # lookup: permuted input / table columns
     lk = None
     if cs.lookup:
+        # the input expression's row values: q_lookup * a (one element-wise product; zero wherever the selector is off)
+        lk_input = dev(n)
+        check(lib.h2mi_fr_mul_dev(pk.fixed_values[cs.col_qlookup].ptr, advice[0].ptr, n, lk_input.ptr, None), "lookup input")
         a_perm, s_perm = dev(n), dev(n)
-        if gp.lookup_permute(d.k, advice[1], pk.table, a_perm, s_perm):
+        if gp.lookup_permute(d.k, lk_input, pk.table, a_perm, s_perm):
             if own_ws:
                 ws.release()
             raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
@@ -426,7 +443,7 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         slot += 1
     if cs.lookup:
         lz = dev(n)
-        gp.lookup_product(d.k, advice[1], pk.fixed_values[2], lk[0], lk[1], beta, gamma, u, lz)
+        gp.lookup_product(d.k, lk_input, pk.fixed_values[cs.col_table], lk[0], lk[1], beta, gamma, u, lz)
         lz.patch(synth.uniform_fr(bf, seed + 5), offset=(u + 1) * 32)
         lk[2] = lz
         commit(lz, True, slot)
@@ -442,10 +459,11 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     # quotient
     h = dev(ext)
     coset_of = {ADVICE: [e for _, e in advice_f], FIXED: list(pk.fixed_cosets), INSTANCE: [instance_f[1]]}
-    gp.evaluate_h_range(d, advice_f[0][1], advice_f[1][1] if cs.lookup else None, pk.fixed_cosets[0], pk.fixed_cosets[2] if cs.lookup else None,
+    gp.evaluate_h_range(d, advice_f[0][1], None, pk.fixed_cosets[cs.col_q], pk.fixed_cosets[cs.col_table] if cs.lookup else None,
                         [coset_of[kind][c] for kind, c in cs.perm_columns], list(pk.sigma_cosets), [e for _, e in z_f],
                         lk_f[0][1] if cs.lookup else None, lk_f[1][1] if cs.lookup else None, lk_f[2][1] if cs.lookup else None,
-                        pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf)
+                        pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf,
+                        lookup_selector=pk.fixed_cosets[cs.col_qlookup] if cs.lookup else None, chunk_len=cs.chunk)
     d.extended_to_coeff_dev(h)
     pieces = d.quotient_poly_degree
     for i in range(pieces):

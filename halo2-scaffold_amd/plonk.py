@@ -158,26 +158,31 @@ def lookup_product(k: int, d_input: DevBuf, d_table: DevBuf, d_permuted_input: D
 
 
 class _RangeCosets(C.Structure):
-    _fields_ = [("a", C.c_void_p), ("lookup_advice", C.c_void_p), ("q", C.c_void_p), ("table", C.c_void_p), ("perm_value", C.c_void_p * 4),
-                ("perm_sigma", C.c_void_p * 4), ("perm_z", C.c_void_p * 4), ("lookup_permuted_input", C.c_void_p), ("lookup_permuted_table", C.c_void_p),
-                ("lookup_z", C.c_void_p), ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p), ("n_perm", C.c_uint32),
-                ("chunk_len", C.c_uint32), ("has_lookup", C.c_uint32)]
+    _fields_ = [("a", C.c_void_p), ("lookup_advice", C.c_void_p), ("lookup_selector", C.c_void_p), ("q", C.c_void_p), ("table", C.c_void_p),
+                ("perm_value", C.c_void_p * 4), ("perm_sigma", C.c_void_p * 4), ("perm_z", C.c_void_p * 4), ("lookup_permuted_input", C.c_void_p),
+                ("lookup_permuted_table", C.c_void_p), ("lookup_z", C.c_void_p), ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p),
+                ("n_perm", C.c_uint32), ("chunk_len", C.c_uint32), ("has_lookup", C.c_uint32)]
 
 
 def evaluate_h_range(domain: EvaluationDomain, a: DevBuf, lookup_advice: DevBuf, q: DevBuf, table: DevBuf, perm_values, perm_sigmas, perm_zs,
                      lk_input: DevBuf, lk_table: DevBuf, lk_z: DevBuf, l0: DevBuf, l_last: DevBuf, l_active: DevBuf, beta: int, gamma: int, y: int,
-                     out: DevBuf, blinding_factors: int = BLINDING_FACTORS) -> None:
-    """h(X) on the extended coset (already divided by X^n - 1) for the halo2-lib constraint systems: with a lookup
-    (lookup_advice, table, lk_* given; degree 4, permutation chunks of two) or without (all of them None; degree 3, chunks of one)"""
+                     out: DevBuf, blinding_factors: int = BLINDING_FACTORS, lookup_selector: DevBuf = None, chunk_len: int = None) -> None:
+    """h(X) on the extended coset (already divided by X^n - 1) for the halo2-lib constraint systems.  Lookup input: the
+    column `lookup_advice` (chunks of two by default), or `lookup_selector` * a (halo2-base with one advice column: degree
+    5, chunks of three), or none (all lookup arguments None: degree 3, chunks of one)."""
     m = len(perm_values)
-    has_lookup = lookup_advice is not None
-    chunk = 2 if has_lookup else 1
+    has_lookup = lookup_advice is not None or lookup_selector is not None
+    chunk = chunk_len if chunk_len is not None else (3 if lookup_selector is not None else 2 if has_lookup else 1)
     assert 1 <= m <= 4 and len(perm_sigmas) == m and len(perm_zs) == -(-m // chunk)
     cs = _RangeCosets()
     cs.a, cs.q = a.ptr, q.ptr
     cs.chunk_len, cs.has_lookup = chunk, 1 if has_lookup else 0
     if has_lookup:
-        cs.lookup_advice, cs.table = lookup_advice.ptr, table.ptr
+        cs.table = table.ptr
+        if lookup_selector is not None:
+            cs.lookup_selector = lookup_selector.ptr
+        else:
+            cs.lookup_advice = lookup_advice.ptr
         cs.lookup_permuted_input, cs.lookup_permuted_table, cs.lookup_z = lk_input.ptr, lk_table.ptr, lk_z.ptr
     for j in range(m):
         cs.perm_value[j], cs.perm_sigma[j] = perm_values[j].ptr, perm_sigmas[j].ptr

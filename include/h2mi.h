@@ -184,6 +184,9 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars /* c
  * from a (linear combination of) opened polynomial(s) — poly/kzg/multiopen/shplonk/prover.rs
  * `quotient_contribution` / `linearisation_contribution`. */
 int h2mi_fr_add_head_dev(void* d_poly, const uint64_t* head /* count*4 */, size_t count, h2mi_stream_t stream);
+/* out[i] = a[i] * b[i] over n elements (in place allowed): the row values of a product of columns, e.g. the lookup input
+ * q_lookup * a of halo2-base's single-advice-column range check */
+int h2mi_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, h2mi_stream_t stream);
 /* out[i] = value for i < n (Lagrange vectors such as l_active of keygen_pk) */
 int h2mi_fr_fill_dev(void* d_out, size_t n, const uint64_t value[4], h2mi_stream_t stream);
 /* Seeded stand-in for the prover's sweeps of `Scalar::random(rng)` (blinding rows; the vanishing argument's random
@@ -262,12 +265,15 @@ int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, cons
                                   uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], void* d_z, h2mi_stream_t stream);
 /* evaluate_h + vanishing division for the halo2-lib constraint systems [halo2-base shapes restated from memory]: gate
  * q (a + a(wX) a(w^2 X) - a(w^3 X)), permutation argument over n_perm <= 4 columns in chunks of chunk_len (= cs.degree()
- * - 2), and — has_lookup (the Range builder: degree 4, chunk_len 2, extended domain 4n) — one lookup of `lookup_advice`
- * in `table`; without it (the Gate builder: degree 3, chunk_len 1, extended domain 2n) the lookup pointers are unused.
- * All vectors are extended-coset evaluations. */
+ * - 2 = 1 .. 3), and — has_lookup (the Range builder, extended domain 4n) — one lookup in `table` of either
+ * `lookup_selector` * a (halo2-base with a single advice column: a complex selector on the looked-up cells' own rows,
+ * lookup degree 5, chunk_len 3) or, when `lookup_selector` is NULL, of the dedicated column `lookup_advice` (degree 4,
+ * chunk_len 2); without has_lookup (the Gate builder: degree 3, chunk_len 1, extended domain 2n) the lookup pointers are
+ * unused.  All vectors are extended-coset evaluations. */
 typedef struct {
   const void* a;               /* the gate's advice column */
-  const void* lookup_advice;   /* the lookup input column */
+  const void* lookup_advice;   /* the lookup input column (NULL when lookup_selector is given) */
+  const void* lookup_selector; /* q_lookup: the lookup input is q_lookup * a (NULL: lookup_advice) */
   const void* q;               /* gate selector */
   const void* table;           /* fixed lookup table */
   const void* perm_value[4];   /* equality-enabled columns in argument order */
@@ -280,7 +286,7 @@ typedef struct {
   const void* l_last;
   const void* l_active;
   uint32_t n_perm;
-  uint32_t chunk_len;          /* 1 or 2 */
+  uint32_t chunk_len;          /* 1, 2 or 3 */
   uint32_t has_lookup;         /* 0: gate + permutation terms only */
 } h2mi_range_cosets;
 int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* cosets, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,

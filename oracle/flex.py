@@ -12,7 +12,8 @@ consistent proofs (every challenge re-derived, gate / permutation / lookup expre
 evaluations, SHPLONK's final equation by pairing or by the known SRS secret).
 
 A constraint system here = columns (advice / fixed / instance), gates (Python callables over a query function), the
-equality-enabled columns in argument order, single-expression lookups (input column in table column), the explicit
+equality-enabled columns in argument order, single-expression lookups (input = a product of columns, e.g. selector *
+advice, in a table column), the explicit
 query lists (their order is the order create_proof writes evaluations in), degree and blinding_factors.
 rng stand-in (the reference passes OsRng): SplitMix64 streams seed+1 advice blinding (column-major, bf + 1 rows),
 seed+2 permutation-product blinding (set-major, bf rows), seed+3 random polynomial, seed+4 permuted lookup columns
@@ -41,7 +42,7 @@ class ConstraintSystem:
         self.n_advice, self.n_fixed, self.n_instance = n_advice, n_fixed, n_instance
         self.gates = gates                    # callables g(q) -> value, q(kind, column, rotation)
         self.perm_columns = perm_columns      # [(kind, column)] in the order enable_equality was called
-        self.lookups = lookups                # [((kind, column) input, (kind, column) table)]
+        self.lookups = lookups                # [([(kind, column) factors of the input expression], (kind, column) table)]
         self.advice_queries, self.fixed_queries, self.instance_queries = advice_queries, fixed_queries, instance_queries
         self.degree, self.blinding_factors = degree, blinding_factors
 
@@ -58,22 +59,40 @@ def standard_plonk_cs():
 
 
 def flex_gate_cs(lookup: bool):
-    """halo2-base at these sizes: advice 0 = the gate column (vertical gate, selector = fixed 0), fixed 1 = constants,
-    instance 0; with `lookup`: advice 1 = lookup advice, fixed 2 = the table.  enable_equality order: gate advice,
-    (lookup advice,) constants, instance (the scaffold adds it last: src/scaffold.rs:394-395, 449-450)."""
-    gate = lambda q: q(FIXED, 0, 0) * (q(ADVICE, 0, 0) + q(ADVICE, 0, 1) * q(ADVICE, 0, 2) - q(ADVICE, 0, 3)) % R
-    perm = [(ADVICE, 0)] + ([(ADVICE, 1)] if lookup else []) + [(FIXED, 1), (INSTANCE, 0)]
-    adv_q = [(0, 0), (0, 1), (0, 2), (0, 3)] + ([(1, 0)] if lookup else [])
-    fix_q = [(0, 0), (1, 0)] + ([(2, 0)] if lookup else [])
+    """halo2-base's builders at the sizes of the reference's examples: ONE gate advice column.  Column order as configure()
+    allocates them [RECALL]: RangeConfig::configure takes the lookup table column first, FlexGateConfig::configure then the
+    constants column (enable_equality at once: first column of the permutation argument) and the gate advice column with
+    its simple selector; the scaffold adds the instance column last (src/scaffold.rs:394-395, 449-450).  With a single
+    advice column the Range builder does not add a lookup-advice column: it looks up q_lookup * a with a complex selector
+    enabled on the rows of the cells to look up (the reference hands `range.q_lookup` to sub_synthesize:
+    src/scaffold.rs:464-469).  keygen appends the selectors' fixed columns: complex selectors first (own column each),
+    then the combined simple selectors.
+      Gate builder:  fixed 0 = constants, 1 = q_enable;                          degree 3, permutation sets of 1
+      Range builder: fixed 0 = table, 1 = constants, 2 = q_lookup, 3 = q_enable;  lookup degree 2 + 2 + 1 = 5: sets of 3, 4 h pieces
+    Queries in creation order: enable_equality queries its column at Rotation::cur, the gate queries a at 0..3, the lookup
+    its table; selector columns are queried when keygen substitutes them."""
+    if lookup:
+        TABLE, CONST, QL, QE = 0, 1, 2, 3
+        fix_q = [(CONST, 0), (TABLE, 0), (QL, 0), (QE, 0)]
+    else:
+        CONST, QE = 0, 1
+        fix_q = [(CONST, 0), (QE, 0)]
+    gate = lambda q: q(FIXED, QE, 0) * (q(ADVICE, 0, 0) + q(ADVICE, 0, 1) * q(ADVICE, 0, 2) - q(ADVICE, 0, 3)) % R
+    perm = [(FIXED, CONST), (ADVICE, 0), (INSTANCE, 0)]
+    adv_q = [(0, 0), (0, 1), (0, 2), (0, 3)]
     # blinding_factors = max(3, most queries on one advice column = 4) + 2
-    return ConstraintSystem("range" if lookup else "flex_gate", 2 if lookup else 1, 3 if lookup else 2, 1, [gate], perm,
-                            [((ADVICE, 1), (FIXED, 2))] if lookup else [], adv_q, fix_q, [(0, 0)], 4 if lookup else 3, 6)
+    cs = ConstraintSystem("range" if lookup else "flex_gate", 1, 4 if lookup else 2, 1, [gate], perm,
+                          [([(FIXED, QL), (ADVICE, 0)], (FIXED, TABLE))] if lookup else [], adv_q, fix_q, [(0, 0)], 5 if lookup else 3, 6)
+    cs.col_const, cs.col_q = CONST, QE
+    cs.col_table, cs.col_qlookup = (TABLE, QL) if lookup else (None, None)
+    return cs
 
 
 class Assignment:
     """what synthesize leaves: sparse cells per column, copy constraints in call order, the public inputs"""
 
     def __init__(self, cs):
+        self.cs = cs
         self.advice = [dict() for _ in range(cs.n_advice)]
         self.fixed = [dict() for _ in range(cs.n_fixed)]
         self.instance = [[] for _ in range(cs.n_instance)]
@@ -108,7 +127,7 @@ class _Ctx:
             else:
                 self.cells.append(v % R)
         for off in gate_offsets:
-            self.asg.fixed[0][base + off] = 1
+            self.asg.fixed[self.asg.cs.col_q][base + off] = 1
         return len(self.cells) - 1
 
     def mul(self, a, b):
@@ -123,20 +142,19 @@ class _Ctx:
     def mul_add_const(self, a, b, c):
         return self.assign_region_last([("constant", c), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b] + c)], [0])
 
-    def finish(self, public_rows, lookup_column=None):
+    def finish(self, public_rows):
         asg = self.asg
+        cs = asg.cs
         for row, v in enumerate(self.cells):
             asg.advice[0][row] = v
         consts = {}
         for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, then constrain_equal
             if v not in consts:
                 consts[v] = len(consts)
-                asg.fixed[1][consts[v]] = v
-            asg.copies.append(((ADVICE, 0, row), (FIXED, 1, consts[v])))
-        if lookup_column is not None:  # cells_to_lookup: copied into the lookup-advice column, top down
-            for i, row in enumerate(self.lookup_cells):
-                asg.advice[lookup_column][i] = self.cells[row]
-                asg.copies.append(((ADVICE, lookup_column, i), (ADVICE, 0, row)))
+                asg.fixed[cs.col_const][consts[v]] = v
+            asg.copies.append(((ADVICE, 0, row), (FIXED, cs.col_const, consts[v])))
+        for row in self.lookup_cells:  # single advice column: q_lookup is enabled on the cell's own row, nothing is copied
+            asg.fixed[cs.col_qlookup][row] = 1
         for i, row in enumerate(public_rows):  # constrain_instance(cell, instance, i)
             asg.instance[0].append(self.cells[row])
             asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
@@ -190,7 +208,7 @@ def range_assignment(cs, x, lookup_bits, n):
         ctx.cells.append((1 << (lookup_bits * i)) % R)
         ctx.const_cells.append((len(ctx.cells) - 1, (1 << (lookup_bits * i)) % R))
         ctx.cells.append(acc % R)
-        asg.fixed[0][base] = 1
+        asg.fixed[cs.col_q][base] = 1
         acc_row = len(ctx.cells) - 1
     asg.copies.append(((ADVICE, 0, xc), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
     ctx.lookup_cells += rows
@@ -200,9 +218,9 @@ def range_assignment(cs, x, lookup_bits, n):
                                       ("witness", limbs[-1] << (lookup_bits - rem))], [0])
         ctx.lookup_cells.append(top)
     ctx.add(xc, xc)
-    ctx.finish([xc], lookup_column=1)
+    ctx.finish([xc])
     for i in range(1 << lookup_bits):
-        asg.fixed[2][i] = i
+        asg.fixed[cs.col_table][i] = i
     return asg
 
 
@@ -351,10 +369,17 @@ def prove(keys: Keys, asg: Assignment, seed: int) -> dict:
         tr.write_point(keys.commit_lagrange(c))
     theta = tr.squeeze_challenge()
     col_of = lambda kc: _column(keys, kc[0], kc[1], advice, instance_cols)
+
+    def input_of(factors):  # the lookup's input expression on the rows: a product of columns (selector * advice)
+        out = [1] * n
+        for kc in factors:
+            out = [a * b % R for a, b in zip(out, col_of(kc))]
+        return out
+
     lk_blind = iter(_rand(2 * (bf + 1) * max(len(cs.lookups), 1), seed + 4))
     permuted = []
     for inp, tab in cs.lookups:
-        a_in, t_in = col_of(inp), col_of(tab)
+        a_in, t_in = input_of(inp), col_of(tab)
         ap, sp = L.permute_expression_pair(a_in, t_in, u, [next(lk_blind) for _ in range(bf + 1)], [next(lk_blind) for _ in range(bf + 1)])
         permuted.append((ap, sp))
         tr.write_point(keys.commit_lagrange(ap))
@@ -383,7 +408,7 @@ def prove(keys: Keys, asg: Assignment, seed: int) -> dict:
     lz_blind = iter(_rand(bf * max(len(cs.lookups), 1), seed + 5))
     lzs = []
     for (inp, tab), (ap, sp) in zip(cs.lookups, permuted):
-        lz = L.lookup_product(col_of(inp), col_of(tab), ap, sp, beta, gamma, u, [next(lz_blind) for _ in range(bf)])
+        lz = L.lookup_product(input_of(inp), col_of(tab), ap, sp, beta, gamma, u, [next(lz_blind) for _ in range(bf)])
         lzs.append(lz)
         tr.write_point(keys.commit_lagrange(lz))
     random_poly = _rand(n, seed + 3)
@@ -410,7 +435,10 @@ def prove(keys: Keys, asg: Assignment, seed: int) -> dict:
                                [z[rn(1)] for z in z_c], [z[rn(-(bf + 1))] for z in z_c], l0[idx], ll[idx], lact[idx],
                                dom.g_coset * pow(dom.extended_omega, idx, R) % R)
         for (inp, tab), (ap, sp, lz) in zip(cs.lookups, lk_c):
-            v = _lookup_terms(v, y, beta, gamma, cosets[inp[0]][inp[1]][idx], cosets[tab[0]][tab[1]][idx], ap[idx], ap[rn(-1)], sp[idx], lz[idx],
+            a_val = 1
+            for kc in inp:
+                a_val = a_val * cosets[kc[0]][kc[1]][idx] % R
+            v = _lookup_terms(v, y, beta, gamma, a_val, cosets[tab[0]][tab[1]][idx], ap[idx], ap[rn(-1)], sp[idx], lz[idx],
                               lz[rn(1)], l0[idx], ll[idx], lact[idx])
         h_ext[idx] = v * tinv[idx % rot] % R
     h_coeffs = dom.extended_to_coeff(h_ext)
@@ -606,7 +634,10 @@ def verify(keys, proof: bytes, instances, g2=None, s_g2=None) -> bool:
     v = _permutation_terms(cs, v, y, beta, gamma, lambda kc: evals[(kc[0], kc[1], 0)], sigma_evals, [e[0] for e in z_evals], [e[1] for e in z_evals],
                            [e[2] for e in z_evals], l_0, l_last, lact, x)
     for (inp, tab), (lz, lz_next, ap, ap_inv, sp) in zip(cs.lookups, lk_evals):
-        v = _lookup_terms(v, y, beta, gamma, evals[(inp[0], inp[1], 0)], evals[(tab[0], tab[1], 0)], ap, ap_inv, sp, lz, lz_next, l_0, l_last, lact)
+        a_val = 1
+        for kc in inp:
+            a_val = a_val * evals[(kc[0], kc[1], 0)] % R
+        v = _lookup_terms(v, y, beta, gamma, a_val, evals[(tab[0], tab[1], 0)], ap, ap_inv, sp, lz, lz_next, l_0, l_last, lact)
     expected_h = v * pow((xn - 1) % R, -1, R) % R
     h_commitment = None
     for cmt in reversed(h_c):

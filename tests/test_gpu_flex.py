@@ -66,7 +66,7 @@ def test_halo2_lib_proof_bytes_match_oracle(gpu, k):
 @pytest.mark.parametrize("k,lookup_bits,x", [(7, 4, 0xDEADBEEFCAFE1234), (8, 7, (1 << 64) - 1), (8, 6, 0)])
 def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
     """reference examples/range.rs: range_check(x, 64) with LOOKUP_BITS limbs (64 is a multiple of 4 but not of 7 or 6:
-    the top-limb shift cell is exercised), lookup argument and all."""
+    the top-limb shift cell is exercised), lookup argument — input expression q_lookup * a — and all."""
     from halo2_scaffold_amd import flex
 
     seed = 99
@@ -75,7 +75,9 @@ def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
     asg = flex.range_closure(cs, x, lookup_bits)
     ocs = FX.flex_gate_cs(True)
     oasg = FX.range_assignment(ocs, x, lookup_bits, 1 << k)
-    assert asg.advice == oasg.advice and asg.fixed[:2] == oasg.fixed[:2] and asg.copies == oasg.copies and [asg.instance] == oasg.instance
+    assert asg.advice == oasg.advice and asg.copies == oasg.copies and [asg.instance] == oasg.instance
+    assert all(asg.fixed[c] == oasg.fixed[c] for c in (cs.col_const, cs.col_qlookup, cs.col_q)) and asg.fixed[cs.col_table] is None
+    assert (cs.col_table, cs.col_const, cs.col_qlookup, cs.col_q) == (ocs.col_table, ocs.col_const, ocs.col_qlookup, ocs.col_q)
     keys = flex.FlexKeys(params, cs, asg)
     okeys = _oracle_keys(ocs, k, oasg)
     _check_keys(keys, okeys, 1 << k)
@@ -85,7 +87,7 @@ def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
     for name in ("theta", "beta", "gamma", "y", "x"):
         assert trace[name] == want[name], name
     assert proof == want["proof"]
-    assert len(proof) == 1152
+    assert len(proof) == 992  # 12 commitments + 19 evaluations (degree 5: one permutation set, four h pieces)
     assert FX.verify(okeys, proof, [asg.instance])
     bad = bytearray(proof)
     bad[700] ^= 1
@@ -95,7 +97,7 @@ def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
 
 
 def test_range_rejects_out_of_range_witness(gpu):
-    """a lookup-advice cell that is not a table value: the crate's permute_expression_pair fails the proof; so does
+    """a looked-up cell that is not a table value: the crate's permute_expression_pair fails the proof; so does
     the device's counting sort (no proof is produced)."""
     from halo2_scaffold_amd import flex
 
@@ -103,7 +105,7 @@ def test_range_rejects_out_of_range_witness(gpu):
     cs = flex.FlexGateCS(lookup=True)
     asg = flex.range_closure(cs, 1234567, 4)
     keys = flex.FlexKeys(params, cs, asg)
-    asg.advice[1][2] = 16  # one past the 4-bit table
+    asg.advice[0][sorted(asg.fixed[cs.col_qlookup])[2]] = 16  # one past the 4-bit table, on a row with q_lookup enabled
     with pytest.raises(ValueError, match="not in the table"):
         flex.create_proof(params, keys, asg, 5)
     keys.release()
@@ -182,7 +184,7 @@ def test_workspace_reuse_and_sliced_srs_world2(gpu):
     r1 = subprocess.run([sys.executable] + common, cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r1.returncode == 0, r1.stderr[-2000:]
     one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
-    assert one["proof_bytes"] == 1152 and one["combines_per_proof"] == 0
+    assert one["proof_bytes"] == 992 and one["combines_per_proof"] == 0
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -34,8 +34,8 @@ def test_halo2_lib_prove_verify():
     cs = FX.flex_gate_cs(False)
     asg = FX.halo2_lib_assignment(cs, x)
     assert asg.instance == [[12, 216]]
-    assert sorted(asg.fixed[0]) == [1, 5, 9, 13]  # the four gates: mul, add, the raw region, mul_add
-    assert asg.fixed[1] == {0: 0, 1: 72, 2: 1}   # constants in order of first use
+    assert sorted(asg.fixed[cs.col_q]) == [1, 5, 9, 13]  # the four gates: mul, add, the raw region, mul_add
+    assert asg.fixed[cs.col_const] == {0: 0, 1: 72, 2: 1}   # constants in order of first use
     keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
     proof = FX.prove(keys, asg, 11)["proof"]
     assert len(proof) == 864
@@ -59,21 +59,23 @@ def test_range_prove_verify(lookup_bits, x):
     cs = FX.flex_gate_cs(True)
     asg = FX.range_assignment(cs, x, lookup_bits, 1 << k)
     limbs = -(-64 // lookup_bits)
-    assert len(asg.advice[1]) == limbs + (1 if 64 % lookup_bits else 0)
-    assert all(v < 1 << lookup_bits for v in asg.advice[1].values())
+    looked_up = sorted(asg.fixed[cs.col_qlookup])  # single advice column: q_lookup on the cells' own rows
+    assert len(looked_up) == limbs + (1 if 64 % lookup_bits else 0) and len(asg.advice) == 1
+    assert all(asg.advice[0][r] < 1 << lookup_bits for r in looked_up)
+    assert cs.degree == 5 and cs.chunk == 3
     keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
     vk = FX.VerifierKeys(cs, k, s, asg.fixed, asg.copies)
     assert vk.fixed_commitments == keys.fixed_commitments and vk.permutation_commitments == keys.permutation_commitments
     assert vk.transcript_repr == keys.transcript_repr
     proof = FX.prove(keys, asg, 5)["proof"]
-    assert len(proof) == 1152
+    assert len(proof) == 992  # 12 commitments (1 advice, A', S', z, lookup z, random, 4 h pieces, 2 SHPLONK) + 19 evaluations
     assert FX.verify(vk, proof, asg.instance)
     assert not FX.verify(vk, proof, [[(x + 1) % (1 << 64)]])
     bad = bytearray(proof)
     bad[900] ^= 1
     assert not FX.verify(vk, bytes(bad), asg.instance)
     # a limb outside the table: permute_expression_pair refuses (the crate returns ConstraintSystemFailure)
-    asg.advice[1][0] = 1 << lookup_bits
+    asg.advice[0][looked_up[0]] = 1 << lookup_bits
     with pytest.raises(Exception):
         FX.prove(keys, asg, 5)
 

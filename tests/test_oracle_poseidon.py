@@ -47,7 +47,7 @@ def test_product_witness_generator_matches_oracle():
     assert asg.instance == [x, y, OP.sponge_hash([x, y])]
     cells = asg.advice[0]
     assert 7000 < len(cells) < 8000
-    for r in asg.fixed[0]:
+    for r in asg.fixed[cs.col_q]:
         assert (cells[r] + cells[r + 1] * cells[r + 2] - cells[r + 3]) % o.R == 0, r
     value = {"advice": lambda c, r: asg.advice[c][r], "fixed": lambda c, r: asg.fixed[c][r], "instance": lambda c, r: asg.instance[r]}
     for (k1, c1, r1), (k2, c2, r2) in asg.copies:
