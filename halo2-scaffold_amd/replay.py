@@ -11,8 +11,9 @@ Shapes:
   HALO2_LIB_GATE  reference src/scaffold.rs:379-421 GateWithInstanceCircuitBuilder (halo2_lib.rs /
                   poseidon.rs closures): one FlexGate advice column at these sizes, one instance column,
                   degree-3 basic gate  [column counts restated from memory of halo2-base: SURVEY 3.3].
-  RANGE_LOOKUP    reference src/scaffold.rs:434-485 RangeWithInstanceCircuitBuilder (range.rs): adds one
-                  lookup-advice column and one lookup argument => constraint degree 4, extended domain 4n.
+  RANGE_LOOKUP    reference src/scaffold.rs:434-485 RangeWithInstanceCircuitBuilder (range.rs): with a single advice
+                  column the lookup's input is q_lookup * a (no lookup-advice column) => constraint degree 5: one
+                  permutation set of three columns, four h pieces, extended domain 4n (see flex.FlexGateCS).
 
 Multi-GPU: every rank owns one contiguous slice of every base set; each MSM runs on the slice and the
 96-byte partial points are combined at EVERY transcript join (all-gather + device fold, dist.PhaseCombiner): a
@@ -40,7 +41,7 @@ class ProofShape:
     n_instance: int
     n_perm_columns: int  # columns with equality enabled
     n_lookups: int
-    cs_degree: int       # max(gate degree, 3, lookup => 4)
+    cs_degree: int       # max(gate degree, 3, lookup: 2 + input degree + table degree)
 
     @property
     def n_perm_z(self) -> int:  # permutation columns are chunked by (degree - 2)
@@ -60,7 +61,7 @@ class ProofShape:
 
 STANDARD_PLONK = ProofShape("standard_plonk", n_advice=3, n_instance=0, n_perm_columns=3, n_lookups=0, cs_degree=3)
 HALO2_LIB_GATE = ProofShape("halo2_lib_gate", n_advice=1, n_instance=1, n_perm_columns=3, n_lookups=0, cs_degree=3)
-RANGE_LOOKUP = ProofShape("range_lookup", n_advice=2, n_instance=1, n_perm_columns=4, n_lookups=1, cs_degree=4)
+RANGE_LOOKUP = ProofShape("range_lookup", n_advice=1, n_instance=1, n_perm_columns=3, n_lookups=1, cs_degree=5)
 SHAPES = {s.name: s for s in (STANDARD_PLONK, HALO2_LIB_GATE, RANGE_LOOKUP)}
 
 # StandardPlonk constants kept for callers / tests that name them

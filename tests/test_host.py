@@ -93,9 +93,9 @@ def test_replay_shape_matches_reference_circuit(h2):
     # halo2-lib gate circuit: 1 advice + 1 instance, 3 equality columns in chunks of 1, no lookups
     g = replay.HALO2_LIB_GATE
     assert g.msm_per_proof == 1 + 3 + 1 + 2 + 2 and g.ntt_per_proof["intt_n"] == 1 + 1 + 3
-    # range circuit: one lookup => degree 4: permutation chunks of 2, 3 h pieces, 3 extra commitments
+    # range circuit, single advice column: the lookup of q_lookup * a => degree 5: one permutation set of 3, 4 h pieces
     r = replay.RANGE_LOOKUP
-    assert r.n_perm_z == 2 and r.msm_per_proof == 2 + 2 + 2 + 1 + 1 + 3 + 2
+    assert r.n_perm_z == 1 and r.msm_per_proof == 1 + 2 + 1 + 1 + 1 + 4 + 2
 
 
 def test_slice_bounds(h2):
