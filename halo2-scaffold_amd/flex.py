@@ -141,7 +141,9 @@ class Context:
         self.asg.copies.append(((ADVICE, 0, a), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
         self.lookup_cells += rows
         rem = range_bits % lookup_bits
-        if rem:  # the top limb times 2^(lookup_bits - rem) must be in the table too
+        if rem == 1:  # the top limb is one bit: assert_bit, 0 + x * x - x = 0 on [0, x, x, x]
+            self.assign_region_last([("constant", 0), ("existing", rows[-1]), ("existing", rows[-1]), ("existing", rows[-1])], [0])
+        elif rem:  # the top limb times 2^(lookup_bits - rem) must be in the table too
             self.lookup_cells.append(self.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
                                                               ("witness", limbs[-1] << (lookup_bits - rem))], [0]))
 

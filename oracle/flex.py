@@ -213,7 +213,9 @@ def range_assignment(cs, x, lookup_bits, n):
     asg.copies.append(((ADVICE, 0, xc), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
     ctx.lookup_cells += rows
     rem = 64 % lookup_bits
-    if rem:  # the top limb must fit the remaining bits: limb * 2^(lookup_bits - rem) is looked up too
+    if rem == 1:  # range.rs `match rem_bits.cmp(&1)`: a one-bit top limb is checked by assert_bit: | 0 | x | x | x |
+        ctx.assign_region_last([("constant", 0), ("existing", rows[-1]), ("existing", rows[-1]), ("existing", rows[-1])], [0])
+    elif rem:  # the top limb must fit the remaining bits: limb * 2^(lookup_bits - rem) is looked up too
         top = ctx.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
                                       ("witness", limbs[-1] << (lookup_bits - rem))], [0])
         ctx.lookup_cells.append(top)

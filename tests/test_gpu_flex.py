@@ -65,8 +65,9 @@ def test_halo2_lib_proof_bytes_match_oracle(gpu, k):
 
 @pytest.mark.parametrize("k,lookup_bits,x", [(7, 4, 0xDEADBEEFCAFE1234), (8, 7, (1 << 64) - 1), (8, 6, 0)])
 def test_range_proof_bytes_match_oracle(gpu, k, lookup_bits, x):
-    """reference examples/range.rs: range_check(x, 64) with LOOKUP_BITS limbs (64 is a multiple of 4 but not of 7 or 6:
-    the top-limb shift cell is exercised), lookup argument — input expression q_lookup * a — and all."""
+    """reference examples/range.rs: range_check(x, 64) with LOOKUP_BITS limbs (64 is a multiple of 4; with 7 the top limb
+    is one bit: assert_bit; with 6 it is four bits: the shifted cell is looked up too), lookup argument — input expression
+    q_lookup * a — and all."""
     from halo2_scaffold_amd import flex
 
     seed = 99

@@ -54,13 +54,13 @@ def test_halo2_lib_prove_verify():
 @pytest.mark.parametrize("lookup_bits,x", [(4, 0xDEADBEEFCAFE1234), (7, (1 << 64) - 1)])
 def test_range_prove_verify(lookup_bits, x):
     """examples/range.rs with LOOKUP_BITS in place of the reference's (src/scaffold.rs:44-48 reads it from the
-    environment): 64 / 4 = 16 limbs, or ten 7-bit limbs with the top one shifted by 6 bits into the table as well"""
+    environment): 64 / 4 = 16 limbs, or ten 7-bit limbs whose one-bit top limb is constrained by assert_bit"""
     k, s = 8, 0x77665544
     cs = FX.flex_gate_cs(True)
     asg = FX.range_assignment(cs, x, lookup_bits, 1 << k)
     limbs = -(-64 // lookup_bits)
     looked_up = sorted(asg.fixed[cs.col_qlookup])  # single advice column: q_lookup on the cells' own rows
-    assert len(looked_up) == limbs + (1 if 64 % lookup_bits else 0) and len(asg.advice) == 1
+    assert len(looked_up) == limbs + (1 if 64 % lookup_bits > 1 else 0) and len(asg.advice) == 1  # a one-bit top limb: assert_bit instead
     assert all(asg.advice[0][r] < 1 << lookup_bits for r in looked_up)
     assert cs.degree == 5 and cs.chunk == 3
     keys = FX.Keys(cs, k, s, asg.fixed, asg.copies)
