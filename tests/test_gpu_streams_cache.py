@@ -279,3 +279,24 @@ def test_side_streams_run_transforms_and_divisions_beside_the_library_stream(gpu
     # waiting on oneself and on the library stream from the library stream are no-ops, a null stream handle is refused
     assert h2.lib.h2mi_stream_wait(None, None) == 0
     assert h2.lib.h2mi_stream_destroy(None) != 0
+
+
+def test_fr_mul_elementwise_matches_oracle(gpu):
+    """h2mi_fr_mul_dev (the row values of a product expression such as q_lookup * a): out of place, in place, odd lengths,
+    zeros and p - 1; argument checking"""
+    h2 = gpu
+    for n in (1, 257, 5000):
+        a = o.unpack(o.random_field_limbs(n, o.SEED + 40), o.R)
+        b = o.unpack(o.random_field_limbs(n, o.SEED + 41), o.R)
+        a[0], b[0] = o.R - 1, o.R - 1
+        if n > 2:
+            a[1], b[2] = 0, 0
+        da, db, dc = h2.DevBuf.from_numpy(o.pack(a, o.R)), h2.DevBuf.from_numpy(o.pack(b, o.R)), h2.DevBuf(n * 32)
+        assert h2.lib.h2mi_fr_mul_dev(da.ptr, db.ptr, n, dc.ptr, None) == 0
+        want = [x * y % o.R for x, y in zip(a, b)]
+        assert o.unpack(dc.to_numpy(shape=(n, 4)), o.R) == want
+        assert h2.lib.h2mi_fr_mul_dev(da.ptr, db.ptr, n, da.ptr, None) == 0  # in place
+        assert o.unpack(da.to_numpy(shape=(n, 4)), o.R) == want
+        for buf in (da, db, dc):
+            buf.free()
+    assert h2.lib.h2mi_fr_mul_dev(None, None, 4, None, None) != 0
