@@ -191,6 +191,27 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
     return asg
 
 
+def mock(asg: Assignment) -> None:
+    """scaffold::mock (src/scaffold.rs:205-243: MockProver::run(..).assert_satisfied()) for these constraint systems, on the
+    host: every enabled row satisfies the vertical gate, every copy constraint joins equal cells, every looked-up cell is
+    a table value.  Raises ValueError naming the first violation — what the reference's users run before `prove`."""
+    cs = asg.cs
+    a = asg.advice[0]
+    for r in sorted(asg.fixed[cs.col_q]):
+        if (a.get(r, 0) + a.get(r + 1, 0) * a.get(r + 2, 0) - a.get(r + 3, 0)) % R:
+            raise ValueError(f"gate not satisfied at row {r}")
+    value = {ADVICE: lambda c, r: asg.advice[c].get(r, 0), FIXED: lambda c, r: asg.fixed[c].get(r, 0),
+             INSTANCE: lambda c, r: asg.instance[r] if r < len(asg.instance) else 0}
+    for left, right in asg.copies:
+        if value[left[0]](left[1], left[2]) % R != value[right[0]](right[1], right[2]) % R:
+            raise ValueError(f"copy constraint {left} == {right} not satisfied")
+    if cs.lookup:
+        table = set(v % R for v in asg.table_values) | {0}
+        for r in sorted(asg.fixed[cs.col_qlookup]):
+            if a.get(r, 0) % R not in table:
+                raise ValueError(f"lookup not satisfied at row {r}")
+
+
 # ---- keys ------------------------------------------------------------------------------------------------------------
 def _column_from_cells(n: int, cells, into: DevBuf = None) -> DevBuf:
     """a column with the given {row: value} cells, zero elsewhere.  A long run of cells (a witness of thousands of

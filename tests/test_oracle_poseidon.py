@@ -52,3 +52,29 @@ def test_product_witness_generator_matches_oracle():
     value = {"advice": lambda c, r: asg.advice[c][r], "fixed": lambda c, r: asg.fixed[c][r], "instance": lambda c, r: asg.instance[r]}
     for (k1, c1, r1), (k2, c2, r2) in asg.copies:
         assert value[k1](c1, r1) == value[k2](c2, r2)
+
+
+def test_mock_accepts_the_example_closures_and_names_violations():
+    """flex.mock = scaffold::mock for the halo2-lib shapes (host-side constraint check before proving)"""
+    import pytest
+
+    _load_pkg.load()
+    from halo2_scaffold_amd import flex, poseidon
+
+    gate, rng = flex.FlexGateCS(lookup=False), flex.FlexGateCS(lookup=True)
+    for asg in (flex.halo2_lib_closure(gate, 7), poseidon.hash_two_closure(gate, 1, 2), flex.range_closure(rng, 0xFFFF0000FFFF, 8),
+                flex.range_closure(rng, (1 << 64) - 1, 7)):
+        flex.mock(asg)
+    bad = flex.halo2_lib_closure(gate, 7)
+    bad.advice[0][4] += 1  # the product cell of x * x
+    with pytest.raises(ValueError, match="gate not satisfied at row 1"):
+        flex.mock(bad)
+    bad = flex.halo2_lib_closure(gate, 7)
+    bad.instance[1] += 1
+    with pytest.raises(ValueError, match="copy constraint"):
+        flex.mock(bad)
+    bad = flex.range_closure(rng, 12345, 4)
+    row = sorted(bad.fixed[rng.col_qlookup])[0]
+    bad.advice[0][row] = 16
+    with pytest.raises(ValueError):  # the limb no longer recomposes (gate) — and is outside the table
+        flex.mock(bad)
