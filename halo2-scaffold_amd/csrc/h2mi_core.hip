@@ -233,6 +233,9 @@ int h2mi_device_count(void) {
   return ctx().inited ? (int)ctx().devs.size() : 0;
 }
 
+static hipEvent_t g_wait_ring[32] = {};  // h2mi_stream_wait's events; destroyed by h2mi_shutdown (they belong to its device)
+static unsigned g_wait_next = 0;
+
 void h2mi_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   if (!ctx().inited) return;
@@ -240,6 +243,8 @@ void h2mi_shutdown(void) {
   msm_join_all(ctx().stream);
   hipStreamSynchronize(ctx().stream);
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; g_fixed_built.destroy(); }
+  for (hipEvent_t& ev : g_wait_ring)
+    if (ev) { hipEventDestroy(ev); ev = nullptr; }
   for (DevCtx& d : ctx().devs) {
     hipSetDevice(d.device);
     hipDeviceSynchronize();
@@ -513,9 +518,7 @@ int h2mi_stream_wait(h2mi_stream_t waiter, h2mi_stream_t signaller) {
   if (w == g) return H2MI_OK;
   // a ring of events: re-recording one only matters to waits issued after the re-record, and a wait issued 32 calls ago
   // has long been consumed by its stream's front end
-  static hipEvent_t ring[32] = {};
-  static unsigned next = 0;
-  hipEvent_t& ev = ring[next++ & 31u];
+  hipEvent_t& ev = g_wait_ring[g_wait_next++ & 31u];
   if (!ev) H2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   H2_HIP(hipEventRecord(ev, g));
   H2_HIP(hipStreamWaitEvent(w, ev, 0));
