@@ -1,0 +1,84 @@
+// C++ counterpart of the reference's halo2-lib examples proved through scaffold::prove (src/scaffold.rs:246-366) over
+// include/h2mi_flex.hpp: examples/halo2_lib.rs (x^2 + 72 through the Gate builder) and examples/range.rs
+// (range_check(x, 64) through the Range builder with a LOOKUP_BITS table) — keygen, then create_proof with every vector in
+// HBM; public inputs and proof bytes printed.  The proof bytes are checked by the test-suite against the oracle engine
+// and the Python host (tests/test_gpu_flex.py).
+//
+// Usage: halo2_lib <halo2_lib | range> [k [lookup_bits [x [srs_secret_hex [seed]]]]]
+//        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
+#include <chrono>
+#include <cstdio>
+#include <string>
+
+#include "../include/h2mi_flex.hpp"
+
+using namespace h2mi;
+using Clock = std::chrono::steady_clock;
+
+struct Timer {
+  const char* name;
+  Clock::time_point t0;
+  explicit Timer(const char* n) : name(n), t0(Clock::now()) { std::printf("Start:   %s\n", name); }
+  ~Timer() { std::printf("End:     %s ...%.3fms\n", name, std::chrono::duration<double, std::milli>(Clock::now() - t0).count()); }
+};
+static Fr fr_from_hex(std::string h) {
+  if (h.rfind("0x", 0) == 0) h = h.substr(2);
+  while (h.size() < 64) h = "0" + h;
+  if (h.size() > 64) h = h.substr(h.size() - 64);
+  Fr raw;
+  for (int i = 0; i < 4; i++) raw.l[i] = std::stoull(h.substr(64 - 16 * (i + 1), 16), nullptr, 16);
+  return fr::mul(raw, fr::R2);
+}
+static std::string hex(const std::vector<uint8_t>& b) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t c : b) {
+    s.push_back(d[c >> 4]);
+    s.push_back(d[c & 15]);
+  }
+  return s;
+}
+
+int main(int argc, char** argv) {
+  const std::string shape = argc > 1 ? argv[1] : "halo2_lib";
+  const uint32_t k = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 10;  // DEGREE
+  const uint32_t lookup_bits = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 8;
+  const uint64_t x = argc > 4 ? std::stoull(argv[4], nullptr, 0) : 12;
+  const Fr s = fr_from_hex(argc > 5 ? argv[5] : "5ec2e7");
+  const uint64_t seed = argc > 6 ? std::stoull(argv[6]) : 11;
+  const bool lookup = shape == "range";
+  if (!lookup && shape != "halo2_lib") {
+    std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
+    return 1;
+  }
+  try {
+    init();
+    auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
+    const flex::FlexGateCS cs(lookup);
+    auto closure = [&](uint64_t v) { return lookup ? flex::range_closure(cs, v, lookup_bits) : flex::halo2_lib_closure(cs, fr::from_u64(v)); };
+    // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape
+    auto pk = [&] { Timer t("Generating verifying and proving key"); return flex::keygen(params, cs, closure(0)); }();
+    flex::Assignment asg = closure(x);
+    std::vector<uint8_t> proof;
+    flex::FlexWorkspace ws(*pk);
+    for (int run = 0; run < 3; run++) {
+      Timer t(run ? "Creating proof" : "Creating proof (first call: builds the domain's tables)");
+      auto transcript = transcript::Blake2bWrite::init();
+      flex::create_proof(params, *pk, asg, seed, transcript, &ws);
+      proof = transcript.finalize();
+    }
+    std::printf("vk %s\n", hex(pk->vk.to_bytes()).c_str());
+    for (const Fr& v : asg.instance) {
+      const Fr c = plonk::to_canonical(v);
+      std::printf("instance %016llx%016llx%016llx%016llx\n", (unsigned long long)c.l[3], (unsigned long long)c.l[2], (unsigned long long)c.l[1],
+                  (unsigned long long)c.l[0]);
+    }
+    std::printf("proof %s\n", hex(proof).c_str());
+    std::printf("proof_bytes %zu\n", proof.size());
+    h2mi_shutdown();
+    return 0;
+  } catch (const Error& e) {
+    std::fprintf(stderr, "halo2_lib: %s\n", e.what());
+    return 2;
+  }
+}

@@ -250,3 +250,39 @@ def test_poseidon_proof_verifies_at_degree_20(gpu):
     assert FX.verify(vk, proof, [asg.instance])
     keys.release()
     params.release()
+
+
+def test_cpp_host_halo2_lib_examples(gpu):
+    """the C++ host layer for the halo2-lib builders (include/h2mi_flex.hpp, examples/halo2_lib.cpp): Context, keygen
+    and create_proof in C++ over the same C ABI.  Its verifying key and proof bytes equal the oracle engine's (and so
+    the Python host's) for the halo2_lib closure and for the range closure (LOOKUP_BITS 4: no remainder, 7: one-bit top
+    limb, 6: shifted top limb); at DEGREE 13 its range proof is accepted against the closed-form verifying key."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    exe = os.path.join(root, "examples", "halo2_lib")
+
+    def run(shape, k, bits, x, seed):
+        r = subprocess.run([exe, shape, str(k), str(bits), str(x), hex(SRS_SECRET), str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+        lines = [l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ", "instance "))]
+        return ([v for n, v in lines if n == "vk"][0], [v for n, v in lines if n == "proof"][0], [int(v, 16) for n, v in lines if n == "instance"])
+
+    for shape, k, bits, x, seed in (("halo2_lib", 6, 0, 12, 2024), ("range", 7, 4, 0xDEADBEEFCAFE1234, 99), ("range", 8, 7, (1 << 64) - 1, 5),
+                                    ("range", 8, 6, 77, 6)):
+        vk, proof, instance = run(shape, k, bits, x, seed)
+        ocs = FX.flex_gate_cs(shape == "range")
+        oasg = FX.range_assignment(ocs, x, bits, 1 << k) if shape == "range" else FX.halo2_lib_assignment(ocs, x)
+        okeys = _oracle_keys(ocs, k, oasg)
+        assert vk == okeys.vk_bytes().hex(), shape
+        assert [instance] == oasg.instance
+        assert proof == FX.prove(okeys, oasg, seed)["proof"].hex(), (shape, bits)
+    k, bits, x = 13, 9, 0x0123456789ABCDEF
+    vk, proof, instance = run("range", k, bits, x, 3)
+    ocs = FX.flex_gate_cs(True)
+    oasg = FX.range_assignment(ocs, x, bits, 1 << k)
+    ovk = FX.VerifierKeys(ocs, k, SRS_SECRET, oasg.fixed, oasg.copies)
+    assert FX.verify(ovk, bytes.fromhex(proof), [instance])
+    assert not FX.verify(ovk, bytes.fromhex(proof), [[x ^ 1]])
