@@ -4,7 +4,8 @@
 // HBM; public inputs and proof bytes printed.  The proof bytes are checked by the test-suite against the oracle engine
 // and the Python host (tests/test_gpu_flex.py).
 //
-// Usage: halo2_lib <halo2_lib | range> [k [lookup_bits [x [srs_secret_hex [seed]]]]]
+// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]   (poseidon hashes x and x + 1:
+//        examples/poseidon.rs `hash_two`)
 //        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
 #include <chrono>
 #include <cstdio>
@@ -47,15 +48,18 @@ int main(int argc, char** argv) {
   const Fr s = fr_from_hex(argc > 5 ? argv[5] : "5ec2e7");
   const uint64_t seed = argc > 6 ? std::stoull(argv[6]) : 11;
   const bool lookup = shape == "range";
-  if (!lookup && shape != "halo2_lib") {
-    std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
+  if (!lookup && shape != "halo2_lib" && shape != "poseidon") {
+    std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
     return 1;
   }
   try {
     init();
     auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
     const flex::FlexGateCS cs(lookup);
-    auto closure = [&](uint64_t v) { return lookup ? flex::range_closure(cs, v, lookup_bits) : flex::halo2_lib_closure(cs, fr::from_u64(v)); };
+    auto closure = [&](uint64_t v) {
+      if (shape == "poseidon") return flex::poseidon_hash_two_closure(cs, fr::from_u64(v), fr::from_u64(v + 1));
+      return lookup ? flex::range_closure(cs, v, lookup_bits) : flex::halo2_lib_closure(cs, fr::from_u64(v));
+    };
     // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape
     auto pk = [&] { Timer t("Generating verifying and proving key"); return flex::keygen(params, cs, closure(0)); }();
     flex::Assignment asg = closure(x);

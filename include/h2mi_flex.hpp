@@ -193,6 +193,152 @@ inline Assignment range_closure(const FlexGateCS& cs, uint64_t x, uint32_t looku
   return asg;
 }
 
+// ---- reference examples/poseidon.rs:15-36 `hash_two`: T = 3, RATE = 2, R_F = 8, R_P = 57 ---------------------------------
+// Parameters from the Grain LFSR of the Poseidon reference script (pinned in the test-suite by circomlib's published
+// constants); the permutation laid out from its definition on FlexGate cells; sponge convention [RECALL snark-verifier]:
+// state (2^64, 0, 0), inputs added into state[1..], a short / trailing empty chunk adds 1 at the next free position,
+// squeeze returns state[1].  See halo2-scaffold_amd/poseidon.py.
+namespace poseidon {
+constexpr uint32_t T = 3, RATE = 2, R_F = 8, R_P = 57;
+class Grain {
+ public:
+  Grain(uint32_t t, uint32_t r_f, uint32_t r_p) {
+    const std::pair<uint64_t, int> fields[] = {{1, 2}, {0, 4}, {254, 12}, {t, 12}, {r_f, 10}, {r_p, 10}, {(1u << 30) - 1, 30}};
+    for (const auto& f : fields)
+      for (int i = f.second - 1; i >= 0; i--) bits_.push_back((f.first >> i) & 1);
+    for (int i = 0; i < 160; i++) clock();
+  }
+  Fr next_field_element(bool reject) {  // 254 bits, big-endian
+    for (;;) {
+      uint64_t l[4] = {0, 0, 0, 0};
+      for (int i = 0; i < 254; i++) {
+        for (int j = 3; j > 0; j--) l[j] = (l[j] << 1) | (l[j - 1] >> 63);
+        l[0] = (l[0] << 1) | next_bit();
+      }
+      bool lt = false;
+      for (int j = 3; j >= 0; j--) {
+        if (l[j] != fr::MODULUS[j]) { lt = l[j] < fr::MODULUS[j]; break; }
+      }
+      if (reject && !lt) continue;
+      Fr raw{{l[0], l[1], l[2], l[3]}};
+      return fr::mul(raw, fr::R2);  // Montgomery form (reduces values >= r as well)
+    }
+  }
+
+ private:
+  uint64_t clock() {
+    const uint64_t b = bits_[pos_ + 62] ^ bits_[pos_ + 51] ^ bits_[pos_ + 38] ^ bits_[pos_ + 23] ^ bits_[pos_ + 13] ^ bits_[pos_];
+    bits_.push_back((uint8_t)b);
+    pos_++;
+    return b;
+  }
+  uint64_t next_bit() {
+    for (;;) {
+      const uint64_t first = clock(), second = clock();
+      if (first) return second;
+    }
+  }
+  std::vector<uint8_t> bits_;
+  size_t pos_ = 0;
+};
+struct Spec {
+  std::vector<std::array<Fr, T>> constants;
+  std::array<std::array<Fr, T>, T> mds;
+};
+inline const Spec& spec() {
+  static const Spec s = [] {
+    Spec sp;
+    Grain g(T, R_F, R_P);
+    for (uint32_t r = 0; r < R_F + R_P; r++) {
+      std::array<Fr, T> row;
+      for (uint32_t i = 0; i < T; i++) row[i] = g.next_field_element(true);
+      sp.constants.push_back(row);
+    }
+    for (;;) {
+      std::array<Fr, T> xs, ys;
+      for (uint32_t i = 0; i < T; i++) xs[i] = g.next_field_element(false);
+      for (uint32_t i = 0; i < T; i++) ys[i] = g.next_field_element(false);
+      bool ok = true;
+      std::vector<Fr> all(xs.begin(), xs.end());
+      all.insert(all.end(), ys.begin(), ys.end());
+      for (size_t i = 0; i < all.size(); i++)
+        for (size_t j = i + 1; j < all.size(); j++) ok = ok && !(all[i] == all[j]);
+      for (uint32_t i = 0; i < T; i++)
+        for (uint32_t j = 0; j < T; j++) ok = ok && !(fr::add(xs[i], ys[j]) == fr_zero());
+      if (!ok) continue;
+      for (uint32_t i = 0; i < T; i++)
+        for (uint32_t j = 0; j < T; j++) sp.mds[i][j] = fr::invert(fr::add(xs[i], ys[j]));
+      return sp;
+    }
+  }();
+  return s;
+}
+class Chip {
+ public:
+  explicit Chip(Context& ctx) : ctx_(ctx) {
+    Fr two64 = fr::from_u64(1ULL << 32);
+    two64 = fr::mul(two64, two64);
+    state_ = {ctx.assign_region_last({Context::constant(two64)}, {}), ctx.assign_region_last({Context::constant(0)}, {}),
+              ctx.assign_region_last({Context::constant(0)}, {})};
+  }
+  void update(const std::vector<uint32_t>& cells) { buf_.insert(buf_.end(), cells.begin(), cells.end()); }
+  uint32_t squeeze() {
+    std::vector<std::vector<uint32_t>> chunks;
+    for (size_t i = 0; i < buf_.size(); i += RATE) chunks.push_back(std::vector<uint32_t>(buf_.begin() + i, buf_.begin() + std::min(buf_.size(), i + RATE)));
+    if (buf_.size() % RATE == 0) chunks.push_back({});
+    buf_.clear();
+    for (const auto& chunk : chunks) {
+      for (size_t i = 0; i < chunk.size(); i++) state_[1 + i] = ctx_.add(state_[1 + i], chunk[i]);
+      if (chunk.size() < RATE) state_[1 + chunk.size()] = ctx_.add_constant(state_[1 + chunk.size()], fr::ONE);
+      permute();
+    }
+    return state_[1];
+  }
+
+ private:
+  uint32_t inner_product_const(const std::array<uint32_t, T>& cells, const std::array<Fr, T>& coeffs) {
+    std::vector<Context::Item> items = {Context::constant(0)};
+    std::vector<uint32_t> gates;
+    Fr acc = fr_zero();
+    for (uint32_t k = 0; k < T; k++) {
+      acc = fr::add(acc, fr::mul(ctx_.value(cells[k]), coeffs[k]));
+      items.push_back(Context::existing(cells[k]));
+      items.push_back(Context::constant(coeffs[k]));
+      items.push_back(Context::witness(acc));
+      gates.push_back(3 * k);
+    }
+    return ctx_.assign_region_last(items, gates);
+  }
+  void permute() {
+    const Spec& sp = spec();
+    const uint32_t half = R_F / 2;
+    for (uint32_t rnd = 0; rnd < R_F + R_P; rnd++) {
+      std::array<uint32_t, T> s;
+      for (uint32_t i = 0; i < T; i++) s[i] = ctx_.add_constant(state_[i], sp.constants[rnd][i]);
+      const uint32_t lanes = (rnd < half || rnd >= half + R_P) ? T : 1;
+      for (uint32_t i = 0; i < lanes; i++) {
+        const uint32_t x2 = ctx_.mul(s[i], s[i]), x4 = ctx_.mul(x2, x2);
+        s[i] = ctx_.mul(x4, s[i]);
+      }
+      for (uint32_t i = 0; i < T; i++) state_[i] = inner_product_const(s, sp.mds[i]);
+    }
+  }
+  Context& ctx_;
+  std::array<uint32_t, T> state_;
+  std::vector<uint32_t> buf_;
+};
+}  // namespace poseidon
+inline Assignment poseidon_hash_two_closure(const FlexGateCS& cs, const Fr& x, const Fr& y) {
+  Assignment asg(cs);
+  Context ctx(asg);
+  const uint32_t xc = ctx.load_witness(x), yc = ctx.load_witness(y);
+  poseidon::Chip chip(ctx);
+  chip.update({xc, yc});
+  const uint32_t out = chip.squeeze();
+  ctx.finish({xc, yc, out});
+  return asg;
+}
+
 // ---- keys -----------------------------------------------------------------------------------------------------------
 struct FlexKeys {
   FlexGateCS cs;

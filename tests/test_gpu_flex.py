@@ -256,7 +256,8 @@ def test_cpp_host_halo2_lib_examples(gpu):
     """the C++ host layer for the halo2-lib builders (include/h2mi_flex.hpp, examples/halo2_lib.cpp): Context, keygen
     and create_proof in C++ over the same C ABI.  Its verifying key and proof bytes equal the oracle engine's (and so
     the Python host's) for the halo2_lib closure and for the range closure (LOOKUP_BITS 4: no remainder, 7: one-bit top
-    limb, 6: shifted top limb); at DEGREE 13 its range proof is accepted against the closed-form verifying key."""
+    limb, 6: shifted top limb) and for poseidon's hash_two; at DEGREE 13 its range proof is accepted against the closed-form
+    verifying key."""
     import os
     import subprocess
 
@@ -279,6 +280,20 @@ def test_cpp_host_halo2_lib_examples(gpu):
         assert vk == okeys.vk_bytes().hex(), shape
         assert [instance] == oasg.instance
         assert proof == FX.prove(okeys, oasg, seed)["proof"].hex(), (shape, bits)
+    # examples/poseidon.rs hash_two(x, x + 1): the C++ Grain LFSR / chip lay out the same 7.4 k cells as the Python host,
+    # the public hash is the oracle's sponge, the proof equals the oracle engine's
+    from oracle import poseidon as OPS
+
+    from halo2_scaffold_amd import flex, poseidon
+
+    k, x, seed = 13, 0xFEEDFACE, 17
+    vk, proof, instance = run("poseidon", k, 0, x, seed)
+    assert instance == [x, x + 1, OPS.sponge_hash([x, x + 1])]
+    ocs = FX.flex_gate_cs(False)
+    oasg = _oracle_assignment(ocs, poseidon.hash_two_closure(flex.FlexGateCS(lookup=False), x, x + 1))
+    okeys = _oracle_keys(ocs, k, oasg)
+    assert vk == okeys.vk_bytes().hex()
+    assert proof == FX.prove(okeys, oasg, seed)["proof"].hex()
     k, bits, x = 13, 9, 0x0123456789ABCDEF
     vk, proof, instance = run("range", k, bits, x, 3)
     ocs = FX.flex_gate_cs(True)
