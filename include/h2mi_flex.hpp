@@ -467,6 +467,7 @@ struct FlexWorkspace {  // device buffers of one create_proof, handed out in req
   std::vector<Dev> pool, shplonk_q;
   size_t cursor = 0;
   Dev points, nx, tmp, h_x, l_x, h2_x;
+  std::unique_ptr<plonk::ShplonkLanes> lanes;
   h2mi_stream_t side = nullptr;
   FlexWorkspace(const FlexWorkspace&) = delete;
   FlexWorkspace& operator=(const FlexWorkspace&) = delete;
@@ -476,6 +477,7 @@ struct FlexWorkspace {  // device buffers of one create_proof, handed out in req
     points = vec(24);  // 8 x 96 B
     nx = vec(n); tmp = vec(n); h_x = vec(n); l_x = vec(n); h2_x = vec(n);
     for (int i = 0; i < 6; i++) shplonk_q.push_back(vec(n));
+    lanes.reset(new plonk::ShplonkLanes(n));
     check(h2mi_stream_create(&side), "stream_create");
   }
   ~FlexWorkspace() {
@@ -744,7 +746,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   for (auto& sp : pk.sigma_polys) q(sp.get(), x);
   q(&h_poly, x);
   q(&random_poly, x);
-  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q};
+  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, ws.lanes->lanes()};
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
     commit(false, poly.p, 0);
     write_points(1);

@@ -20,6 +20,7 @@
 // blinding rows, seed + 2 permutation-product blinding rows, seed + 3 the random polynomial, generated on the device).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <optional>
@@ -443,22 +444,24 @@ inline Fr vanishing_at(const std::vector<Fr>& roots, const Fr& z) {
   return acc;
 }
 inline bool contains(const std::vector<Fr>& v, const Fr& x) { return std::find(v.begin(), v.end(), x) != v.end(); }
-inline void lincomb(const std::vector<const DeviceVec*>& polys, const std::vector<Fr>& scalars, size_t n, DeviceVec& out) {
+inline void lincomb(const std::vector<const DeviceVec*>& polys, const std::vector<Fr>& scalars, size_t n, DeviceVec& out, h2mi_stream_t stream = nullptr) {
   std::vector<const void*> ptrs;
   for (auto* p : polys) ptrs.push_back(p->p);
-  check(h2mi_fr_lincomb_dev(ptrs.data(), (const uint64_t*)scalars.data(), polys.size(), n, out.p, nullptr), "lincomb");
+  check(h2mi_fr_lincomb_dev(ptrs.data(), (const uint64_t*)scalars.data(), polys.size(), n, out.p, stream), "lincomb");
 }
-inline void add_head(DeviceVec& poly, const std::vector<Fr>& head) { check(h2mi_fr_add_head_dev(poly.p, (const uint64_t*)head.data(), head.size(), nullptr), "add_head"); }
-// out = src / prod (X - root), zero-padded to n coefficients; src is clobbered when there are >= 2 roots
-inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out) {
-  check(h2mi_memset_zero(out.p, n * 32), "zero");
+inline void add_head(DeviceVec& poly, const std::vector<Fr>& head, h2mi_stream_t stream = nullptr) {
+  check(h2mi_fr_add_head_dev(poly.p, (const uint64_t*)head.data(), head.size(), stream), "add_head");
+}
+// out = src / prod (X - root); `out` must have been zeroed (the quotient has n - #roots coefficients, the rest stay
+// zero); src is clobbered when there are >= 2 roots
+inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out, h2mi_stream_t stream = nullptr) {
   DeviceVec* cur = &src;
   DeviceVec* bufs[2] = {&tmp, &src};
   size_t len = n;
   for (size_t i = 0; i < roots.size(); i++) {
     DeviceVec* dst = i + 1 == roots.size() ? &out : bufs[i % 2];
     Fr binv = fr::invert(roots[i]);
-    check(h2mi_fr_kate_division_dev(cur->p, len, roots[i].l, binv.l, dst->p, nullptr), "kate_division");
+    check(h2mi_fr_kate_division_dev(cur->p, len, roots[i].l, binv.l, dst->p, stream), "kate_division");
     cur = dst;
     len--;
   }
@@ -472,6 +475,35 @@ struct RotationSet {
 struct ShplonkScratch {  // n-element device vectors the argument works in (at least as many q as rotation sets)
   DeviceVec *nx, *tmp, *h_x, *l_x, *h2_x;
   std::vector<Dev>* q;
+  // optional extra lanes (side stream + its own nx / tmp): the rotation sets' quotient chains are independent, so set i
+  // runs on lane i mod (1 + lanes.size()) and the longest chain, not their sum, is waited for
+  struct Lane {
+    h2mi_stream_t stream;
+    DeviceVec *nx, *tmp;
+  };
+  std::vector<Lane> lanes;
+};
+struct ShplonkLanes {  // two side lanes, owned by a prover workspace
+  Dev nx[2], tmp[2];
+  h2mi_stream_t stream[2] = {nullptr, nullptr};
+  ShplonkLanes(const ShplonkLanes&) = delete;
+  ShplonkLanes& operator=(const ShplonkLanes&) = delete;
+  explicit ShplonkLanes(size_t n) {
+    for (int i = 0; i < 2; i++) {
+      nx[i].reset(new DeviceVec(n));
+      tmp[i].reset(new DeviceVec(n));
+      check(h2mi_stream_create(&stream[i]), "stream_create");
+    }
+  }
+  ~ShplonkLanes() {
+    for (h2mi_stream_t s : stream)
+      if (s) h2mi_stream_destroy(s);
+  }
+  std::vector<ShplonkScratch::Lane> lanes() const {
+    static const bool off = std::getenv("H2MI_SHPLONK_LANES") && std::getenv("H2MI_SHPLONK_LANES")[0] == '0';  // A/B knob
+    if (off) return {};
+    return {{stream[0], nx[0].get(), tmp[0].get()}, {stream[1], nx[1].get(), tmp[1].get()}};
+  }
 };
 template <class CommitAndWrite>
 inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const std::vector<ProverQuery>& queries, CommitAndWrite commit_and_write,
@@ -509,21 +541,28 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
   DeviceVec &nx = *sc.nx, &tmp = *sc.tmp, &h_x = *sc.h_x, &l_x = *sc.l_x, &h2_x = *sc.h2_x;
   std::vector<Dev>& q = *sc.q;
   if (sets.size() > q.size()) throw Error(H2MI_ERANGE, "shplonk: more rotation sets than scratch vectors");
+  for (size_t i = 0; i < sets.size(); i++) check(h2mi_memset_zero(q[i]->p, n * 32), "zero");
+  for (const auto& lane : sc.lanes) check(h2mi_stream_wait(lane.stream, nullptr), "stream_wait");
   for (size_t i = 0; i < sets.size(); i++) {
     const RotationSet& rs = sets[i];
+    const size_t lane = i % (1 + sc.lanes.size());
+    h2mi_stream_t stream = lane ? sc.lanes[lane - 1].stream : nullptr;
+    DeviceVec& lnx = lane ? *sc.lanes[lane - 1].nx : nx;
+    DeviceVec& ltmp = lane ? *sc.lanes[lane - 1].tmp : tmp;
     std::vector<Fr> ypow(rs.members.size(), fr::ONE);
     for (size_t j = 1; j < ypow.size(); j++) ypow[j] = fr::mul(ypow[j - 1], y);
     std::vector<const DeviceVec*> polys;
     for (auto& m : rs.members) polys.push_back(m.first);
-    lincomb(polys, ypow, n, nx);
+    lincomb(polys, ypow, n, lnx, stream);
     std::vector<Fr> rsum(rs.points.size(), fr_zero());
     for (size_t j = 0; j < rs.members.size(); j++) {
       std::vector<Fr> r = interpolate(rs.points, rs.members[j].second);
       for (size_t t = 0; t < r.size(); t++) rsum[t] = fr::sub(rsum[t], fr::mul(ypow[j], r[t]));
     }
-    add_head(nx, rsum);
-    kate_chain(nx, n, rs.points, tmp, *q[i]);
+    add_head(lnx, rsum, stream);
+    kate_chain(lnx, n, rs.points, ltmp, *q[i], stream);
   }
+  for (const auto& lane : sc.lanes) check(h2mi_stream_wait(nullptr, lane.stream), "stream_wait");
   {
     std::vector<const DeviceVec*> polys;
     std::vector<Fr> vpow(sets.size(), fr::ONE);
@@ -561,6 +600,7 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
   scalars.push_back(fr::neg(fr::mul(zt_eval, norm)));
   lincomb(polys, scalars, n, l_x);
   add_head(l_x, {konst});
+  check(h2mi_memset_zero(h2_x.p, n * 32), "zero");
   kate_chain(l_x, n, {u}, tmp, h2_x);
   commit_and_write(h2_x);
 }
@@ -571,6 +611,7 @@ struct ProverWorkspace {
   size_t n, ext;
   std::vector<Dev> advice, advice_polys, advice_cosets, z, z_polys, z_cosets, shplonk_q;
   Dev random_poly, h, h_poly, points, evals, nx, tmp, h_x, l_x, h2_x;
+  std::unique_ptr<ShplonkLanes> lanes;
   h2mi_stream_t side = nullptr;  // transforms of the advice columns run here, beside the permutation argument's chain
   ProverWorkspace(const ProverWorkspace&) = delete;
   ProverWorkspace& operator=(const ProverWorkspace&) = delete;
@@ -586,6 +627,7 @@ struct ProverWorkspace {
     for (int i = 0; i < 4; i++) shplonk_q.push_back(vec(n));
     random_poly = vec(n); h = vec(ext); h_poly = vec(n); points = vec(12); evals = vec(32);
     nx = vec(n); tmp = vec(n); h_x = vec(n); l_x = vec(n); h2_x = vec(n);
+    lanes.reset(new ShplonkLanes(n));
     check(h2mi_stream_create(&side), "stream_create");
   }
 };
@@ -759,7 +801,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   for (uint32_t c = 0; c < na; c++) q(pk.permutation.polys[c].get(), x);
   q(&h_poly, x);
   q(&random_poly, x);
-  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q};
+  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, ws.lanes->lanes()};
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
     commit(params.g_handle(), poly.p, 0);
     write_phase_points(1);
