@@ -806,10 +806,10 @@ static uint32_t pick_window(size_t n) {
   // Larger windows mean fewer point additions (n * ceil(255/c)); the bucket phase is latency-bound and
   // nearly independent of the bucket count.  Only windows whose TOP window still holds many scalar bits
   // are used: c = 12 or 14 leave 2 bits there, i.e. four buckets that each receive n/4 points.
-  // c = 17 (15 windows, the widest the bucket-matrix kernels take; H2MI_MSM_C=17) measured 2 % faster
-  // than c = 16 at 2^20 and no faster at 2^22 — twice the buckets to reduce for 6 % fewer additions — so
-  // it is not the default.
-  int c = lg >= 20 ? 16 : lg >= 18 ? 15 : 13;
+  // c = 17 (15 windows, the widest the bucket-matrix kernels take): 6 % fewer additions for twice the buckets to
+  // reduce.  Re-measured at the end of round 2 inside whole proofs (the reductions are cheaper than when this table was
+  // first drawn up): create_proof 2^20 -1..2 % (the replay step unchanged), 2^21 -5 %, 2^22 -3 % — the default from 2^21.
+  int c = lg >= 21 ? 17 : lg >= 20 ? 16 : lg >= 18 ? 15 : 13;
   return (uint32_t)c;
 }
 
