@@ -809,7 +809,10 @@ static uint32_t pick_window(size_t n) {
   // c = 17 (15 windows, the widest the bucket-matrix kernels take): 6 % fewer additions for twice the buckets to
   // reduce.  Re-measured at the end of round 2 inside whole proofs (the reductions are cheaper than when this table was
   // first drawn up): create_proof 2^20 -1..2 % (the replay step unchanged), 2^21 -5 %, 2^22 -3 % — the default from 2^21.
-  int c = lg >= 21 ? 17 : lg >= 20 ? 16 : lg >= 18 ? 15 : 13;
+  // Smaller sizes, same sweep (`tools/msm_sweep.py`, back-to-back / latency in us): 2^17: c = 13: 307 / 517, 15: 287 / 494,
+  // 16: 286 / 476; 2^18: 15: 475 / 706, 16: 458 / 666; 2^19: 15: 832 / 1112, 16: 809 / 1058; 2^15: 13: 180 / 334, 16: 164 /
+  // 324; 2^14: 13: 149 / 296, 15: 135 / 282, 16: 153 / 309; 2^10: 13 is best.  (c = 14 leaves a 3-bit top window: 50 % slower.)
+  int c = lg >= 21 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
   return (uint32_t)c;
 }
 
