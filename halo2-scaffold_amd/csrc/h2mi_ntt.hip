@@ -799,8 +799,20 @@ __global__ void __launch_bounds__(256) k_perm_write_sets(const fe* R, uint32_t u
     t = lo;
   }
   fe o = fe_one<Fr>();
-  if (t) f29_to_mont256<F9>(ld261(&R[t - 1]), o.v);
+  if (t) {
+    if (active) o = fe_load(&R[t - 1]);  // sparse form: R was brought to the memory format once per position (k_perm_to_mont256)
+    else f29_to_mont256<F9>(ld261(&R[t - 1]), o.v);
+  }
   fe_store(&out.z[set][i], o);
+}
+// the sparse form's prefix products, Montgomery-2^261 -> the columns' Montgomery-2^256, once per active position instead
+// of once per row of every z column (the rows between two positions repeat one value)
+__global__ void __launch_bounds__(256) k_perm_to_mont256(fe* R, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe o;
+  f29_to_mont256<F9>(ld261(&R[i]), o.v);
+  fe_store(&R[i], o);
 }
 // lookup argument's grand product (plonk/lookup/prover.rs commit_product), single-expression lookups:
 // num_i = (a_i + beta)(t_i + gamma), den_i = (a'_i + beta)(s'_i + gamma), i < u
@@ -907,6 +919,47 @@ __global__ void k_fr_inv_one(const fe* in, fe* out) {
   fe r = fe_inv_gcd<Fr>(fe_load(in));
   for (int i = 0; i < 10; i++) r = fe_dbl<Fr>(r);
   fe_store(out, r);
+}
+// A handful of constrained cells (the reference's StandardPlonk: 8 positions, x^2 + 72: ~30): the whole sparse grand
+// product in ONE workgroup — each thread forms its position's numerator and denominator and inverts its own denominator
+// (binary Euclid, the lanes in parallel: as long as one inversion), one Hillis-Steele product scan over the ratios, the
+// result already in the columns' Montgomery-2^256 form for k_perm_write_sets.  Twelve launches of latency-bound scans over
+// thirty elements (0.6 ms) become one (0.2 ms).
+constexpr uint32_t PERM_SMALL_MAX = 256;
+__global__ void __launch_bounds__(PERM_SMALL_MAX) k_perm_sparse_small(PermArgs a, uint32_t chunk, uint32_t n_active, uint32_t u, const fe* wlo,
+                                                                      const fe* whi, uint32_t wh, const uint32_t* active, fe* R) {
+  __shared__ fe sh[PERM_SMALL_MAX];
+  const uint32_t tid = threadIdx.x;
+  f29 ratio = f29_const<F9>(F9::ONE);
+  if (tid < n_active) {
+    const uint32_t t = active[tid];
+    const uint32_t set = t / u, i = t - set * u;
+    const f29 w = pow2tab(wlo, whi, wh, i);
+    f29 pn = f29_const<F9>(F9::ONE), pd = pn;
+    for (uint32_t j = set * chunk; j < a.m && j < (set + 1) * chunk; j++) {
+      f29 nf, df;
+      perm_factors(a, j, i, w, nf, df);
+      pn = f29_mul<F9>(nf, pn);
+      pd = f29_mul<F9>(df, pd);
+    }
+    fe inv = fe_inv_gcd<Fr>(pack261(pd));  // see k_fr_inv_one: x 2^261 read as Montgomery-2^256, then * 2^10
+    for (int q = 0; q < 10; q++) inv = fe_dbl<Fr>(inv);
+    ratio = f29_mul<F9>(pn, f29_unpack(inv.v));
+  }
+  sh[tid] = pack261(ratio);
+  __syncthreads();
+  for (uint32_t d = 1; d < n_active; d <<= 1) {
+    fe v = one261();
+    if (tid >= d) v = sh[tid - d];
+    __syncthreads();
+    if (tid >= d) sh[tid] = pack261(f29_mul<F9>(f29_unpack(sh[tid].v), f29_unpack(v.v)));
+    __syncthreads();
+  }
+  if (tid < n_active) {
+    fe o;
+    f29_to_mont256<F9>(f29_unpack(sh[tid].v), o.v);
+    fe_store(&R[tid], o);
+  }
 }
 // ratio_i = num_i / den_i = num_i * P_(i-1) * S_(i+1) / P_(n-1)   (P, S: prefix / suffix products of den)
 __global__ void __launch_bounds__(256) k_perm_ratio(const fe* num, const fe* P, const fe* S, const fe* inv_total, size_t n, fe* ratio) {
@@ -1587,6 +1640,14 @@ static int perm_products(const void* const* d_values, const void* const* d_sigma
   PowTab pw;
   int rc = get_powtab(omega, k, s, &pw);
   if (rc) return rc;
+  if (d_active && n_active <= PERM_SMALL_MAX) {
+    rc = ensure_tmp(PERM_SMALL_MAX, s);
+    if (rc) return rc;
+    H2_LAUNCH("k_perm_sparse_small", k_perm_sparse_small, 1, PERM_SMALL_MAX, 0, s, a, chunk_len, n_active, usable_rows, (const fe*)pw.lo,
+              (const fe*)pw.hi, pw.h, d_active, g_tmp);
+    H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, wgrid, 256, 0, s, (const fe*)g_tmp, usable_rows, zo, d_active, n_active);
+    return release_tmp(s);
+  }
   const size_t total = d_active ? (size_t)n_active : (size_t)sets * usable_rows;  // elements the scans run over
   const uint32_t nblocks = ceil_div_u32(total, MS_TILE);
   rc = ensure_tmp(3 * total + 2 * (size_t)nblocks + 2, s);
@@ -1607,6 +1668,7 @@ static int perm_products(const void* const* d_values, const void* const* d_sigma
   H2_LAUNCH("k_perm_ratio", k_perm_ratio, ceil_div_u32(total, 256), 256, 0, s, (const fe*)num, (const fe*)P, (const fe*)S, (const fe*)inv_total, total, num);
   rc = mulscan(num, total, 0, totals, offsets, s);
   if (rc) return rc;
+  if (d_active) H2_LAUNCH("k_perm_to_mont256", k_perm_to_mont256, ceil_div_u32(n_active, 256), 256, 0, s, num, n_active);
   H2_LAUNCH("k_perm_write_sets", k_perm_write_sets, wgrid, 256, 0, s, (const fe*)num, usable_rows, zo, d_active, n_active);
   return release_tmp(s);
 }
