@@ -275,9 +275,10 @@ class FlexKeys:
             sc = _m(pow(FR_DELTA, j, R))
             check(lib.h2mi_fr_lincomb_dev(ptrs, sc.ctypes.data, 1, n, col.ptr, None), "identity permutation")
             self.sigma_values.append(col)
+        dpow = [pow(FR_DELTA, j, R) for j in range(m)]
         for (j, i), (tj, ti) in asm.mapping.items():
             if (j, i) != (tj, ti):
-                self.sigma_values[j].upload(_m(pow(FR_DELTA, tj, R) * pow(d.omega, ti, R) % R), offset=i * 32)
+                self.sigma_values[j].patch(_m(dpow[tj] * pow(d.omega, ti, R) % R), offset=i * 32)  # stream-ordered, no host wait per cell
         check(lib.h2mi_sync(), "sync")
         omega_pows.free()
         self.active_rows = gp.ActiveRows(asm.mapping, cs.chunk, u)  # the support of the copy constraints (sparse grand products)
