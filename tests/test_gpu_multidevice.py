@@ -62,6 +62,21 @@ pk = keygen.keygen_pk(params, vk, circuit)
 assert vk.to_bytes().hex() == case["vk_bytes"]
 proof = prover.create_proof(params, pk, circuits.StandardPlonk(int(case["witness_x"], 16)), case["seed"])
 assert proof.hex() == case["proof"]
+# and the Range builder's prover (lookup argument, side streams, sparse grand products) over sharded commitments: same
+# bytes as the oracle engine's proof
+from halo2_scaffold_amd import flex
+from oracle import flex as FX
+S2, k2, bits, x2 = 0x5EC2E7 + 0x48324D49, 8, 6, 0xFEEDC0DE77
+p2 = h2.ParamsKZG.setup(k2, S2)
+cs = flex.FlexGateCS(lookup=True)
+asg = flex.range_closure(cs, x2, bits)
+keys = flex.FlexKeys(p2, cs, asg)
+proof2 = flex.create_proof(p2, keys, asg, 21)
+ocs = FX.flex_gate_cs(True)
+oasg = FX.range_assignment(ocs, x2, bits, 1 << k2)
+okeys = FX.Keys(ocs, k2, S2, oasg.fixed, oasg.copies)
+assert keys.vk_bytes() == okeys.vk_bytes()
+assert proof2 == FX.prove(okeys, oasg, 21)["proof"]
 print("MULTIDEV_OK", NDEV)
 """
 
