@@ -382,13 +382,23 @@ def _write_points(ws: FlexWorkspace, transcript, k: int):
 def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, transcript: Blake2bWrite = None, trace: dict = None,
                  ws: FlexWorkspace = None) -> bytes:
     """create_proof for one circuit with one instance column: scaffold::prove's call (src/scaffold.rs:322-331,
-    `&[&[&public_io]]`).  `params` is the whole SRS, or one rank's slice of it together with ws.combiner."""
+    `&[&[&public_io]]`).  `params` is the whole SRS, or one rank's slice of it together with ws.combiner.  Without `ws` the
+    device buffers live for this call only (released on every exit path)."""
+    if ws is not None:
+        return _create_proof(params, pk, asg, seed, transcript, trace, ws)
+    own = FlexWorkspace(params, pk)
+    try:
+        return _create_proof(params, pk, asg, seed, transcript, trace, own)
+    finally:
+        check(lib.h2mi_sync(), "sync")
+        own.release()
+
+
+def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, transcript, trace, ws: FlexWorkspace) -> bytes:
     cs, d = pk.cs, pk.domain
     n, ext, u, bf = d.n, d.extended_len(), pk.u, cs.blinding_factors
     transcript = transcript or Blake2bWrite.init()
     sq = lambda: F.fr_from_mont_limbs(transcript.squeeze_challenge())
-    own_ws = ws is None
-    ws = ws or FlexWorkspace(params, pk)
     ws.begin()
     dev = ws.take
     out_base = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
@@ -433,8 +443,6 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
         check(lib.h2mi_fr_mul_dev(pk.fixed_values[cs.col_qlookup].ptr, advice[0].ptr, n, lk_input.ptr, None), "lookup input")
         a_perm, s_perm = dev(n), dev(n)
         if gp.lookup_permute(d.k, lk_input, pk.table, a_perm, s_perm):
-            if own_ws:
-                ws.release()
             raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
         lb = synth.uniform_fr(2 * (bf + 1), seed + 4)
         a_perm.patch(lb[: bf + 1], offset=u * 32)
@@ -558,6 +566,4 @@ def create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, tr
     if trace is not None:
         trace.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x)
     check(lib.h2mi_sync(), "sync")
-    if own_ws:
-        ws.release()
     return proof
