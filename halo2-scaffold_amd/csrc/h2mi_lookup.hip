@@ -134,6 +134,8 @@ __global__ void __launch_bounds__(256) k_lk_fill_table(const uint32_t* repeated,
 
 static uint32_t* g_lk_scratch = nullptr;
 static size_t g_lk_words = 0;
+static hipEvent_t g_lk_event = nullptr;     // last use of the scratch: a caller on another stream queues behind it
+static hipStream_t g_lk_stream = nullptr;
 
 static int scan_u32(const uint32_t* in, uint32_t* out, uint32_t m /* multiple of 4 */, uint32_t* segsum, hipStream_t s) {
   const uint32_t nseg = ceil_div_u32(m, SCAN_SEG_BINS);
@@ -183,6 +185,7 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
   uint32_t* rep_before = rep + uu + 4;
   uint32_t* segsum = rep_before + uu + 4;
   uint32_t* missing = segsum + nseg;
+  if (g_lk_event && g_lk_stream != s) H2_HIP(hipStreamWaitEvent(s, g_lk_event, 0));
   H2_HIP(hipMemsetAsync(g_lk_scratch, 0, words * 4, s));
   const fe* in = (const fe*)d_input;
   const fe* sorted = (const fe*)d_table_sorted;
@@ -200,6 +203,9 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
   // zero pads make rep_before[u] == rep_before[uu]
   H2_LAUNCH("k_lk_fill_table", k_lk_fill_table, ceil_div_u32(u, 256), 256, 0, s, (const uint32_t*)rep, (const uint32_t*)rep_before, (const uint32_t*)lstart,
             n_unique, sorted_mont, (const fe*)d_permuted_input, u, (fe*)d_permuted_table);
+  if (!g_lk_event) H2_HIP(hipEventCreateWithFlags(&g_lk_event, hipEventDisableTiming));
+  H2_HIP(hipEventRecord(g_lk_event, s));
+  g_lk_stream = s;
   if (not_in_table_out) {  // the crate fails the proof (ConstraintSystemFailure) when an input is not in the table
     uint32_t m = 0;
     H2_HIP(hipMemcpyAsync(&m, missing, 4, hipMemcpyDeviceToHost, s));
