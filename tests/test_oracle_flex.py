@@ -91,3 +91,21 @@ def test_verify_with_pairing():
     g2, s_g2 = fm.G2_GEN, fm.g2_mul(s)
     assert FX.verify(keys, proof, asg.instance, g2=g2, s_g2=s_g2)
     assert not FX.verify(keys, proof, asg.instance, g2=g2, s_g2=fm.g2_mul(s + 1))
+
+
+def test_committed_flex_golden_proofs_are_what_the_oracle_produces():
+    """tests/golden/flex_proofs.json (tests/golden/make_flex_golden.py): the committed proofs of the halo2-lib example
+    closures still come out of the oracle engine bit for bit and still verify — the fixture both device hosts are held to"""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flex_proofs.json")))
+    s = int(g["srs_secret"], 16)
+    for case in g["cases"]:
+        if case["shape"] == "poseidon":
+            continue  # regenerated by the script (4 s); its verification below covers the committed bytes
+        cs = FX.flex_gate_cs(case["shape"] == "range")
+        x = int(case["x"], 16)
+        asg = FX.range_assignment(cs, x, case["lookup_bits"], 1 << case["k"]) if case["shape"] == "range" else FX.halo2_lib_assignment(cs, x)
+        keys = FX.Keys(cs, case["k"], s, asg.fixed, asg.copies)
+        assert keys.vk_bytes().hex() == case["vk_bytes"]
+        assert FX.prove(keys, asg, case["seed"])["proof"].hex() == case["proof"]
+        assert [int(v, 16) for v in case["instance"]] == asg.instance[0]
+        assert FX.verify(keys, bytes.fromhex(case["proof"]), asg.instance)
