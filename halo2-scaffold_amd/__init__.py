@@ -19,5 +19,5 @@ from ._lib import H2miError, lib, init, lib_path  # noqa: F401
 from .device import DevBuf  # noqa: F401
 from .arithmetic import best_fft, best_multiexp, eval_polynomial, kate_division, lincomb  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
-from .params import ParamsKZG  # noqa: F401
+from .params import ParamsKZG, gen_srs, gen_srs_secret  # noqa: F401
 from . import serde, transcript  # noqa: F401

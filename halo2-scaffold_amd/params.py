@@ -18,6 +18,55 @@ from ._lib import check, lib
 from .device import DevBuf
 
 
+def chacha20_block(key_words, counter: int, stream: int = 0):
+    """one 64-byte block of ChaCha20 (20 rounds; 64-bit block counter, 64-bit stream id: the layout rand_chacha uses) as 16
+    little-endian u32 words"""
+    M = 0xFFFFFFFF
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter & M, counter >> 32, stream & M, stream >> 32]
+    x = list(st)
+    rotl = lambda v, c: ((v << c) & M) | (v >> (32 - c))
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & M for a, b in zip(x, st)]
+
+
+def gen_srs_secret() -> int:
+    """the toxic-waste scalar of the SRS the scaffold generates: `gen_srs(k)` (src/scaffold.rs:119,174,271; halo2-base
+    utils::fs) calls ParamsKZG::setup(k, ChaCha20Rng::from_seed(Default::default())), whose first draw is
+    s = Fr::random(rng) = from_u512 of eight next_u64 (the first 64 keystream bytes of the all-zero key, little-endian),
+    reduced mod r [RECALL: halo2-base and halo2curves are not vendored; the keystream itself is the published ChaCha20
+    zero-key vector].  With it `ParamsKZG.setup(k, gen_srs_secret())` is, as far as memory can settle, the very
+    params/kzg_bn254_{k}.srs the reference caches — NOT a production SRS (the reference says so itself)."""
+    words = chacha20_block([0] * 8, 0)
+    wide = sum(w << (32 * i) for i, w in enumerate(words))
+    return wide % F.FR_MODULUS
+
+
+def gen_srs(k: int, params_dir: str = None) -> "ParamsKZG":
+    """halo2-base `gen_srs` / `read_or_create_srs`: read {PARAMS_DIR or ./params}/kzg_bn254_{k}.srs if it exists, else
+    set the SRS up from the fixed-seed rng above and write the file."""
+    import os
+
+    d = params_dir or os.environ.get("PARAMS_DIR", "./params")
+    path = os.path.join(d, f"kzg_bn254_{k}.srs")
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            return ParamsKZG.read(f)
+    p = ParamsKZG.setup(k, gen_srs_secret())
+    os.makedirs(d, exist_ok=True)
+    with open(path, "wb") as f:
+        p.write(f)
+    return p
+
+
 class ParamsKZG:
     def __init__(self, k: int):
         self.k = k

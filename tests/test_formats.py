@@ -309,3 +309,23 @@ def test_device_formats_match_golden(gpu):
     params.write(buf)
     assert hashlib.sha256(buf.getvalue()).hexdigest() == g["srs_k3_s5_sha256"]
     params.release()
+
+
+@pytest.mark.gpu
+def test_gen_srs_reads_or_creates_the_params_file(gpu, tmp_path):
+    """gen_srs(k) as the scaffold calls it (src/scaffold.rs:119,174,271): creates params/kzg_bn254_{k}.srs from the
+    fixed-seed secret on first use, reads it back afterwards; both objects commit identically and the file's points
+    are s^i G for that secret"""
+    k = 6
+    first = gpu.gen_srs(k, str(tmp_path))
+    path = tmp_path / f"kzg_bn254_{k}.srs"
+    assert path.exists() and path.stat().st_size == 4 + 2 * 32 * (1 << k) + 2 * 64
+    again = gpu.gen_srs(k, str(tmp_path))
+    s = gpu.gen_srs_secret()
+    g = o.unpack_points(first.get_g())
+    assert g[0] == o.G1_GEN and g[1] == o.g1_mul(s, o.G1_GEN) and g[5] == o.g1_mul(pow(s, 5, o.R), o.G1_GEN)
+    assert o.unpack_points(again.get_g()) == g and o.unpack_points(again.get_g_lagrange()) == o.unpack_points(first.get_g_lagrange())
+    poly = o.random_field_limbs(1 << k, 7)
+    assert o.unpack_jacobian(first.commit(poly)) == o.unpack_jacobian(again.commit(poly))
+    first.release()
+    again.release()

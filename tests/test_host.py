@@ -215,3 +215,17 @@ def test_cpp_host_example_builds_and_fails_loudly_without_gpu(h2):
         pytest.skip("GPU present: the example is run by the -m gpu tests")
     r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+def test_gen_srs_secret_from_the_chacha20_zero_seed(h2):
+    """params.gen_srs_secret: halo2-base's gen_srs seeds ChaCha20Rng with zeros; the keystream block is the published
+    ChaCha20 zero-key / zero-nonce vector (djb's reference test vector, also RFC 7539 A.1 #1), and the scalar is its first 64
+    bytes read as a little-endian integer mod r (Fr::from_u512)"""
+    from halo2_scaffold_amd import params as P
+
+    ks = b"".join(w.to_bytes(4, "little") for w in P.chacha20_block([0] * 8, 0))
+    assert ks.hex() == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                        "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    s = P.gen_srs_secret()
+    assert s == int.from_bytes(ks, "little") % o.R and 0 < s < o.R
+    assert P.chacha20_block([0] * 8, 1) != P.chacha20_block([0] * 8, 0)
