@@ -519,3 +519,113 @@ void h2ref_sum(const uint64_t* jacp, size_t k, uint64_t out[12]) {
   for (size_t i = 0; i < k; i++) jac_add(&t, &t, (const jac*)(jacp + 12 * i));
   memcpy(out, &t, 96);
 }
+
+/* ---- Fr vector helpers for the large-size oracle prover (oracle/vec.py, oracle/fastflex.py) -------------------------
+ * The Python-integer oracle prover (oracle/flex.py) takes hours at 2^20 rows; these are the same element-wise
+ * definitions (halo2_proofs::arithmetic::{eval_polynomial, kate_division, parallelize} loops and the batch inversion of
+ * plonk/permutation/prover.rs) over (n,4)-limb Montgomery arrays so that it can produce golden proofs at the sizes
+ * BASELINE.json names.  Test infrastructure; validated element for element against oracle/bn254.py in tests/test_oracle_fast.py. */
+typedef struct { int op; const fe* a; const fe* b; int b_scalar; fe* out; size_t lo, hi; } vec_job;
+static void* vec_worker(void* arg) {
+  vec_job* J = (vec_job*)arg;
+  for (size_t i = J->lo; i < J->hi; i++) {
+    const fe* y = J->b_scalar ? J->b : &J->b[i];
+    fe r;
+    switch (J->op) {
+      case 0: fe_mul(&r, &J->a[i], y, &FR); break;
+      case 1: fe_add(&r, &J->a[i], y, &FR); break;
+      case 2: fe_sub(&r, &J->a[i], y, &FR); break;
+      default: fe_sub(&r, y, &J->a[i], &FR); break; /* 3: b - a */
+    }
+    J->out[i] = r;
+  }
+  return NULL;
+}
+/* out[i] = a[i] (op) b[i] or b[0]; op 0 mul, 1 add, 2 sub, 3 reversed sub.  out may alias a or b. */
+void h2ref_vec_binop(int op, const uint64_t* a, const uint64_t* b, int b_scalar, uint64_t* out, size_t n, int threads) {
+  if (threads < 1) threads = 1;
+  if (n < 4096) threads = 1;
+  pthread_t* th = (pthread_t*)malloc((size_t)threads * sizeof(pthread_t));
+  vec_job* jobs = (vec_job*)malloc((size_t)threads * sizeof(vec_job));
+  for (int t = 0; t < threads; t++) {
+    vec_job J = {op, (const fe*)a, (const fe*)b, b_scalar, (fe*)out, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads};
+    jobs[t] = J;
+    if (threads == 1) vec_worker(&jobs[0]);
+    else pthread_create(&th[t], NULL, vec_worker, &jobs[t]);
+  }
+  if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
+}
+/* sum_i a[i] b[i] */
+void h2ref_vec_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+  fe acc;
+  memset(&acc, 0, sizeof acc);
+  for (size_t i = 0; i < n; i++) {
+    fe t;
+    fe_mul(&t, (const fe*)(a + 4 * i), (const fe*)(b + 4 * i), &FR);
+    fe_add(&acc, &acc, &t, &FR);
+  }
+  memcpy(out, acc.l, 32);
+}
+/* arithmetic::eval_polynomial: Horner from the top coefficient */
+void h2ref_vec_horner(const uint64_t* a, size_t n, const uint64_t x[4], uint64_t out[4]) {
+  fe acc, X;
+  memset(&acc, 0, sizeof acc);
+  memcpy(X.l, x, 32);
+  for (size_t i = n; i-- > 0;) {
+    fe_mul(&acc, &acc, &X, &FR);
+    fe_add(&acc, &acc, (const fe*)(a + 4 * i), &FR);
+  }
+  memcpy(out, acc.l, 32);
+}
+/* arithmetic::kate_division: q[i-1] = a[i] + b q[i] from the top; out has n entries, out[n-1] = 0 */
+void h2ref_vec_kate(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* out) {
+  fe tmp, B;
+  memset(&tmp, 0, sizeof tmp);
+  memcpy(B.l, b, 32);
+  if (n) memset(out + 4 * (n - 1), 0, 32);
+  for (size_t i = n; i-- > 1;) {
+    fe t;
+    fe_mul(&t, &tmp, &B, &FR);
+    fe_add(&tmp, &t, (const fe*)(a + 4 * i), &FR);
+    memcpy(out + 4 * (i - 1), tmp.l, 32);
+  }
+}
+/* out[i] = start * base^i */
+void h2ref_vec_powers(const uint64_t base[4], const uint64_t start[4], size_t n, uint64_t* out) {
+  fe w, B;
+  memcpy(w.l, start, 32);
+  memcpy(B.l, base, 32);
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out + 4 * i, w.l, 32);
+    fe_mul(&w, &w, &B, &FR);
+  }
+}
+/* out[0] = start, out[i+1] = out[i] * a[i] for i < n - 1 … out has `n_out` entries, uses a[0 .. n_out-2] */
+void h2ref_vec_running_product(const uint64_t* a, const uint64_t start[4], size_t n_out, uint64_t* out) {
+  fe w;
+  memcpy(w.l, start, 32);
+  for (size_t i = 0; i < n_out; i++) {
+    memcpy(out + 4 * i, w.l, 32);
+    if (i + 1 < n_out) fe_mul(&w, &w, (const fe*)(a + 4 * i), &FR);
+  }
+}
+/* Montgomery batch inversion (one field inversion), zero stays zero; out must not alias a */
+void h2ref_vec_batch_inv(const uint64_t* a, uint64_t* out, size_t n) {
+  fe acc = FR.one;
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out + 4 * i, acc.l, 32);
+    if (!fe_is_zero((const fe*)(a + 4 * i))) fe_mul(&acc, &acc, (const fe*)(a + 4 * i), &FR);
+  }
+  fe inv;
+  fe_inv(&inv, &acc, &FR);
+  for (size_t i = n; i-- > 0;) {
+    const fe* x = (const fe*)(a + 4 * i);
+    if (fe_is_zero(x)) { memset(out + 4 * i, 0, 32); continue; }
+    fe t;
+    fe_mul(&t, &inv, (const fe*)(out + 4 * i), &FR);
+    fe_mul(&inv, &inv, x, &FR);
+    memcpy(out + 4 * i, t.l, 32);
+  }
+}
