@@ -71,6 +71,17 @@ int main(int argc, char** argv) {
       flex::create_proof(params, *pk, asg, seed, transcript, &ws);
       proof = transcript.finalize();
     }
+    if (const char* np = std::getenv("H2MI_PROOFS")) {  // steady state: N more proofs through the same workspace (bench.py reads the line)
+      const int count = std::atoi(np);
+      check(h2mi_sync(), "sync");
+      const auto t0 = Clock::now();
+      for (int i = 0; i < count; i++) {
+        auto transcript = transcript::Blake2bWrite::init();
+        flex::create_proof(params, *pk, asg, seed + 1 + (uint64_t)i, transcript, &ws);
+        transcript.finalize();
+      }
+      std::printf("steady_ms_per_proof %.4f over %d proofs\n", std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / count, count);
+    }
     std::printf("vk %s\n", hex(pk->vk.to_bytes()).c_str());
     for (const Fr& v : asg.instance) {
       const Fr c = plonk::to_canonical(v);

@@ -69,6 +69,17 @@ int main(int argc, char** argv) {
       plonk::create_proof(params, *pk, circuit, seed, transcript, &ws);
       proof = transcript.finalize();
     }
+    if (const char* np = std::getenv("H2MI_PROOFS")) {  // steady state: N more proofs through the same workspace (bench.py reads the line)
+      const int count = std::atoi(np);
+      check(h2mi_sync(), "sync");
+      const auto t0 = Clock::now();
+      for (int i = 0; i < count; i++) {
+        auto transcript = transcript::Blake2bWrite::init();
+        plonk::create_proof(params, *pk, circuit, seed + 1 + (uint64_t)i, transcript, &ws);
+        transcript.finalize();
+      }
+      std::printf("steady_ms_per_proof %.4f over %d proofs\n", std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / count, count);
+    }
     std::printf("vk %s\n", hex(vk.to_bytes()).c_str());
     std::printf("proof %s\n", hex(proof).c_str());
     std::printf("proof_bytes %zu\n", proof.size());

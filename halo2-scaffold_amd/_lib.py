@@ -43,6 +43,7 @@ def _load():
         "h2mi_memset_zero": ([vp, sz], C.c_int),
         "h2mi_sync": ([], C.c_int),
         "h2mi_join": ([], C.c_int),
+        "h2mi_msm_flush": ([], C.c_int),
         "h2mi_bases_register": ([vp, sz, u64p], C.c_int),
         "h2mi_bases_register_dev": ([vp, sz, u64p], C.c_int),
         "h2mi_bases_release": ([C.c_uint64], C.c_int),

@@ -325,6 +325,11 @@ int h2mi_join(void) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   return msm_join_all(ctx().stream);
 }
+int h2mi_msm_flush(void) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  return msm_flush_all();
+}
 int h2mi_sync(void) {
   H2_REQUIRE_INIT();
   {

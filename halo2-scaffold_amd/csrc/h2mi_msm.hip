@@ -866,7 +866,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   if ((uint64_t)B->stride * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = B->stride * B->W;
   // partial sums of one accumulation: one per chunk (at most whole rounds of the resident grid) + one per bucket
-  B->max_tasks0 = accum_rounds((uint32_t)nW) * ACCUM_RESIDENT_CHUNKS + B->nb + 1;
+  B->max_tasks0 = std::min(accum_rounds((uint32_t)nW) * ACCUM_RESIDENT_CHUNKS, (uint32_t)nW) + B->nb + 1;
   B->max_tasks1 = B->max_tasks0 / S1 + B->nb;
   H2_ALLOC(B->table, nW * 64);
   B->lb = B->c - 1 > 9 ? B->c - 1 - 9 : 0;
@@ -1094,7 +1094,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
             (const uint32_t*)nullptr);
   // upper bound of the chunks (zero digits leave no entry): whole rounds of the resident grid, or total / override
-  const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : accum_rounds(total) * ACCUM_RESIDENT_CHUNKS;
+  // (a chunk holds at least one entry: small base sets never come near a whole round)
+  const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : std::min(accum_rounds(total) * ACCUM_RESIDENT_CHUNKS, total);
   const uint32_t tasks0 = chunks0 + nb;                                             // upper bound of the partial sums
   if (pipelined) {
     H2_HIP(hipEventRecord(S.head_done, hs));
@@ -1362,6 +1363,8 @@ static int msm_sharded(Sharded* sh, const void* scalars, bool on_host, size_t n,
 }
 
 // make stream `s` wait for every outstanding MSM (device-side join, no host synchronisation)
+int msm_flush_all() { return flush_tails(); }
+
 int msm_join_all(hipStream_t s) {
   int rc = flush_tails();
   if (rc) return rc;

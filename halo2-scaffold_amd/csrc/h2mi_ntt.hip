@@ -921,43 +921,53 @@ __global__ void k_fr_inv_one(const fe* in, fe* out) {
   fe_store(out, r);
 }
 // A handful of constrained cells (the reference's StandardPlonk: 8 positions, x^2 + 72: ~30): the whole sparse grand
-// product in ONE workgroup — each thread forms its position's numerator and denominator and inverts its own denominator
-// (binary Euclid, the lanes in parallel: as long as one inversion), one Hillis-Steele product scan over the ratios, the
-// result already in the columns' Montgomery-2^256 form for k_perm_write_sets.  Twelve launches of latency-bound scans over
-// thirty elements (0.6 ms) become one (0.2 ms).
+// product in ONE workgroup.  R_i = prod_{j<=i} num_j / den_j = PN_i * S_(i+1) / S_0 with PN the prefix products of the
+// numerators and S the suffix products of the denominators: the two scans run together (Hillis-Steele), and the ONE
+// inversion (binary Euclid, see k_fr_inv_one) is of S_0 — every lane of the first wavefront runs it on the same value, so
+// its data-dependent branches are wavefront-uniform.  (Round 2 inverted each lane's own denominator: 64 different branch
+// histories in one wavefront, 0.22 ms for 8 cells.)  The result is already in the columns' Montgomery-2^256 form for
+// k_perm_write_sets.
 constexpr uint32_t PERM_SMALL_MAX = 256;
 __global__ void __launch_bounds__(PERM_SMALL_MAX) k_perm_sparse_small(PermArgs a, uint32_t chunk, uint32_t n_active, uint32_t u, const fe* wlo,
                                                                       const fe* whi, uint32_t wh, const uint32_t* active, fe* R) {
-  __shared__ fe sh[PERM_SMALL_MAX];
+  __shared__ fe shn[PERM_SMALL_MAX], shd[PERM_SMALL_MAX + 1], sh_inv;
   const uint32_t tid = threadIdx.x;
-  f29 ratio = f29_const<F9>(F9::ONE);
+  f29 pn = f29_const<F9>(F9::ONE), pd = pn;
   if (tid < n_active) {
     const uint32_t t = active[tid];
     const uint32_t set = t / u, i = t - set * u;
     const f29 w = pow2tab(wlo, whi, wh, i);
-    f29 pn = f29_const<F9>(F9::ONE), pd = pn;
     for (uint32_t j = set * chunk; j < a.m && j < (set + 1) * chunk; j++) {
       f29 nf, df;
       perm_factors(a, j, i, w, nf, df);
       pn = f29_mul<F9>(nf, pn);
       pd = f29_mul<F9>(df, pd);
     }
-    fe inv = fe_inv_gcd<Fr>(pack261(pd));  // see k_fr_inv_one: x 2^261 read as Montgomery-2^256, then * 2^10
-    for (int q = 0; q < 10; q++) inv = fe_dbl<Fr>(inv);
-    ratio = f29_mul<F9>(pn, f29_unpack(inv.v));
   }
-  sh[tid] = pack261(ratio);
+  shn[tid] = pack261(pn);
+  shd[tid] = pack261(pd);
+  if (tid == 0) shd[PERM_SMALL_MAX] = one261();
   __syncthreads();
-  for (uint32_t d = 1; d < n_active; d <<= 1) {
-    fe v = one261();
-    if (tid >= d) v = sh[tid - d];
+  for (uint32_t d = 1; d < n_active; d <<= 1) {  // shn: inclusive prefix products; shd: inclusive suffix products
+    fe vn = one261(), vd = one261();
+    if (tid >= d) vn = shn[tid - d];
+    if (tid + d < PERM_SMALL_MAX) vd = shd[tid + d];
     __syncthreads();
-    if (tid >= d) sh[tid] = pack261(f29_mul<F9>(f29_unpack(sh[tid].v), f29_unpack(v.v)));
+    if (tid >= d) shn[tid] = pack261(f29_mul<F9>(f29_unpack(shn[tid].v), f29_unpack(vn.v)));
+    if (tid + d < PERM_SMALL_MAX) shd[tid] = pack261(f29_mul<F9>(f29_unpack(shd[tid].v), f29_unpack(vd.v)));
     __syncthreads();
   }
+  if (tid < 64) {  // (S_0 2^261) read as Montgomery-2^256 is (32 S_0) 2^256; its inverse times 2^10 is S_0^-1 2^261
+    fe inv = fe_inv_gcd<Fr>(shd[0]);
+    for (int q = 0; q < 10; q++) inv = fe_dbl<Fr>(inv);
+    if (tid == 0) sh_inv = inv;
+  }
+  __syncthreads();
   if (tid < n_active) {
+    f29 r = f29_mul<F9>(f29_unpack(shn[tid].v), f29_unpack(sh_inv.v));
+    r = f29_mul<F9>(r, f29_unpack(shd[tid + 1].v));
     fe o;
-    f29_to_mont256<F9>(f29_unpack(sh[tid].v), o.v);
+    f29_to_mont256<F9>(r, o.v);
     fe_store(&R[tid], o);
   }
 }

@@ -427,6 +427,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         advice.append(col)
     for j, col in enumerate(advice):
         commit(col, True, j)
+    check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join
     # coefficient / extended forms of the advice and instance columns: no challenge enters them, so they run on the side
     # stream beside the transcript round trips, the lookup's counting sort and the grand products (see prover.py)
     side = ws.side
@@ -449,6 +450,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         s_perm.patch(lb[bf + 1 :], offset=u * 32)
         commit(a_perm, True, 0)
         commit(s_perm, True, 1)
+        check(lib.h2mi_msm_flush(), "flush")
         side.after_library()
         lk_f = [forms(a_perm, side.handle), forms(s_perm, side.handle)]
         _write_points(ws, transcript, 2)
@@ -481,6 +483,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         commit(lz, True, slot)
         slot += 1
     slot += 1  # the random polynomial's commitment, queued before the grand products (RANDOM_SLOT)
+    check(lib.h2mi_msm_flush(), "flush")
     # coefficient / extended forms, queued behind the commitments
     z_f = [forms(z) for z in zs]
     if cs.lookup:

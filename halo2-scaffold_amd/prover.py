@@ -142,6 +142,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
     for i, c in enumerate(ws.advice):
         _commit(params, ws, c, 0, True, i)
+    check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join below
     # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
     # y): on a side stream they run beside the commitments' bucket reductions, the transcript round trip and the
     # permutation argument's chain of small scans — a stretch in which the device is otherwise nearly idle, because the
@@ -168,6 +169,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
         z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
     for i, z in enumerate(ws.z):
         _commit(params, ws, z, 0, True, i)
+    check(lib.h2mi_msm_flush(), "flush")
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
     # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products
     for col, p, e in zip(ws.z, ws.z_polys, ws.z_cosets):

@@ -99,11 +99,12 @@ def _add_head(poly: DevBuf, coeffs, stream=None):
     check(lib.h2mi_fr_add_head_dev(poly.ptr, hd.ctypes.data, len(coeffs), stream), "add_head")
 
 
-def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf, stream=None):
-    """out = src / prod (X - root); src is clobbered when there are >= 2 roots.  `out` must have been zeroed (the
-    quotient has n - len(roots) coefficients; the rest of the n stay zero)"""
+def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf, stream=None, tmp2: DevBuf = None):
+    """out = src / prod (X - root).  `out` must have been zeroed (the quotient has n - len(roots) coefficients; the rest
+    of the n stay zero).  Intermediate quotients alternate between tmp and tmp2; without a tmp2, src is clobbered when
+    there are >= 2 roots"""
     cur, length = src, n
-    bufs = [tmp, src]
+    bufs = [tmp, tmp2 if tmp2 is not None else src]
     for i, root in enumerate(roots):
         last = i == len(roots) - 1
         dst = out if last else bufs[i % 2]
@@ -121,11 +122,12 @@ class ProverSHPLONK:
         self._nx = [DevBuf(n * 32) for _ in range(self.LANES)]
         self._tmp = [DevBuf(n * 32) for _ in range(self.LANES)]
         self._q = [DevBuf(n * 32) for _ in range(6)]
+        self._s = [DevBuf(n * 32) for _ in range(6)]  # per rotation set: sum_j y^j P_ij(X) - R_i(X), kept for the linearisation
         self._side = [None] + [SideStream() for _ in range(self.LANES - 1)]
         self.h_x, self.l_x, self.h2_x = DevBuf(n * 32), DevBuf(n * 32), DevBuf(n * 32)
 
     def release(self):
-        for b in self._nx + self._tmp + [self.h_x, self.l_x, self.h2_x] + self._q:
+        for b in self._nx + self._tmp + [self.h_x, self.l_x, self.h2_x] + self._q + self._s:
             b.free()
         for st in self._side[1:]:
             st.free()
@@ -145,39 +147,43 @@ class ProverSHPLONK:
             check(lib.h2mi_memset_zero(self._q[i].ptr, n * 32), "zero")
         for st in self._side[1:]:
             st.after_library()
+        remainders = []
         for i, rs in enumerate(sets):
             lane = i % self.LANES
             stream = self._side[lane].handle if lane else None
             nx, tmp = self._nx[lane], self._tmp[lane]
             ypow = [pow(y, j, R) for j in range(len(rs.members))]
-            _lincomb([p for p, _ in rs.members], ypow, n, nx, stream)
+            _lincomb([p for p, _ in rs.members], ypow, n, self._s[i], stream)
             rsum = [0] * len(rs.points)
             for (_, evals), yp in zip(rs.members, ypow):
                 for t, c in enumerate(_interpolate(rs.points, evals)):
                     rsum[t] = (rsum[t] - yp * c) % R
-            _add_head(nx, rsum, stream)
-            _kate_chain(nx, n, rs.points, tmp, self._q[i], stream)
+            _add_head(self._s[i], rsum, stream)
+            remainders.append([(-c) % R for c in rsum])  # R_i(X) = sum_j y^j R_ij(X), low to high
+            _kate_chain(self._s[i], n, rs.points, tmp, self._q[i], stream, tmp2=nx)
         for st in self._side[1:]:
             st.join_library()
         _lincomb(self._q[: len(sets)], [pow(v, i, R) for i in range(len(sets))], n, self.h_x)
         commit_and_write(self.h_x)
         u = F.fr_from_mont_limbs(transcript.squeeze_challenge())
-        # linearisation: one linear combination over every opened polynomial and h(X), one constant, one division
+        # linearisation.  sum_j y^j (P_ij(X) - R_ij(u)) = S_i(X) + R_i(X) - R_i(u) with S_i = sum_j y^j P_ij - R_i the vector the
+        # quotient step left in self._s[i]: one linear combination over the rotation sets' sums and h(X) — four or six
+        # vectors instead of every opened polynomial again (22 at 2^20 rows: 0.32 -> 0.07 ms) — and a low-degree head
         zt_eval = _vanishing_at(super_points, u)
         z_diffs = [_vanishing_at([p for p in super_points if p not in rs.points], u) for rs in sets]
         norm = pow(z_diffs[0], -1, R)  # "normalize coefficients by the coefficient of the first polynomial"
-        polys, scalars, const = [], [], 0
+        polys, scalars, head = [], [], [0] * max(len(rs.points) for rs in sets)
         for i, rs in enumerate(sets):
             w = pow(v, i, R) * z_diffs[i] % R * norm % R
-            for j, (poly, evals) in enumerate(rs.members):
-                sc = w * pow(y, j, R) % R
-                polys.append(poly)
-                scalars.append(sc)
-                const = (const - sc * _horner(_interpolate(rs.points, evals), u)) % R
+            polys.append(self._s[i])
+            scalars.append(w)
+            for t, c in enumerate(remainders[i]):
+                head[t] = (head[t] + w * c) % R
+            head[0] = (head[0] - w * _horner(remainders[i], u)) % R
         polys.append(self.h_x)
         scalars.append((-zt_eval * norm) % R)
         _lincomb(polys, scalars, n, self.l_x)
-        _add_head(self.l_x, [const])
+        _add_head(self.l_x, head)
         check(lib.h2mi_memset_zero(self.h2_x.ptr, n * 32), "zero")
         _kate_chain(self.l_x, n, [u], self._tmp[0], self.h2_x)
         commit_and_write(self.h2_x)

@@ -80,6 +80,11 @@ int h2mi_sync(void); /* wait for all work queued on the library's streams */
  * h2mi_memcpy_d2h (or when eight reductions are pending).  A prover calls h2mi_join where the transcript
  * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream. */
 int h2mi_join(void);
+/* start the deferred bucket reductions of the MSMs queued so far NOW, on the library's reduction stream, without ordering
+ * the library's stream behind them (h2mi_join still does that, later): a prover that has queued the commitments of a phase
+ * and goes on to queue work that does not need them (the columns' transforms) calls this first, so the reductions run
+ * beside that work instead of starting when the host reaches h2mi_join. */
+int h2mi_msm_flush(void);
 /* ---- side streams.  Every *_dev entry point takes a stream (NULL = the library's own, on which calls execute in issue
  * order).  A second stream lets work that does not depend on the next transcript challenge — e.g. the coefficient and
  * extended forms of the advice columns, needed only by evaluate_h — run beside the library stream's chain instead of

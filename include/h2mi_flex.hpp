@@ -464,7 +464,7 @@ inline std::unique_ptr<FlexKeys> keygen(const poly::kzg::ParamsKZG& params, cons
 
 // ---- create_proof ---------------------------------------------------------------------------------------------------
 struct FlexWorkspace {  // device buffers of one create_proof, handed out in request order and kept for the next proof
-  std::vector<Dev> pool, shplonk_q;
+  std::vector<Dev> pool, shplonk_q, shplonk_s;
   size_t cursor = 0;
   Dev points, nx, tmp, h_x, l_x, h2_x;
   std::unique_ptr<plonk::ShplonkLanes> lanes;
@@ -477,6 +477,7 @@ struct FlexWorkspace {  // device buffers of one create_proof, handed out in req
     points = vec(24);  // 8 x 96 B
     nx = vec(n); tmp = vec(n); h_x = vec(n); l_x = vec(n); h2_x = vec(n);
     for (int i = 0; i < 6; i++) shplonk_q.push_back(vec(n));
+    for (int i = 0; i < 6; i++) shplonk_s.push_back(vec(n));
     lanes.reset(new plonk::ShplonkLanes(n));
     check(h2mi_stream_create(&side), "stream_create");
   }
@@ -538,6 +539,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   std::vector<Fr> blind = uniform_fr(seed + 1, bf + 1);
   check(h2mi_memcpy_h2d_async((char*)advice.p + (size_t)u * 32, blind.data(), (bf + 1) * 32), "blinding rows");
   commit(true, advice.p, 0);
+  check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // coefficient / extended forms that wait for no challenge: on the side stream, beside the transcript round trips
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
   Forms advice_f = forms(advice, ws.side), instance_f = forms(instance, ws.side);
@@ -560,6 +562,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
     check(h2mi_memcpy_h2d_async((char*)s_perm->p + (size_t)u * 32, lb.data() + (bf + 1), (bf + 1) * 32), "blinding rows");
     commit(true, a_perm->p, 0);
     commit(true, s_perm->p, 1);
+    check(h2mi_msm_flush(), "flush");
     check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
     ap_f = forms(*a_perm, ws.side);
     sp_f = forms(*s_perm, ws.side);
@@ -606,6 +609,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
     commit(true, lz->p, slot++);
   }
   slot++;  // the random polynomial's slot
+  check(h2mi_msm_flush(), "flush");
   std::vector<Forms> z_f;
   for (uint32_t s = 0; s < n_sets; s++) z_f.push_back(forms(*zs[s], nullptr));
   if (cs.lookup) lz_f = forms(*lz, nullptr);
@@ -746,7 +750,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   for (auto& sp : pk.sigma_polys) q(sp.get(), x);
   q(&h_poly, x);
   q(&random_poly, x);
-  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, ws.lanes->lanes()};
+  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, &ws.shplonk_s, ws.lanes->lanes()};
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
     commit(false, poly.p, 0);
     write_points(1);

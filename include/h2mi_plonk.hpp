@@ -453,10 +453,11 @@ inline void add_head(DeviceVec& poly, const std::vector<Fr>& head, h2mi_stream_t
   check(h2mi_fr_add_head_dev(poly.p, (const uint64_t*)head.data(), head.size(), stream), "add_head");
 }
 // out = src / prod (X - root); `out` must have been zeroed (the quotient has n - #roots coefficients, the rest stay
-// zero); src is clobbered when there are >= 2 roots
-inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out, h2mi_stream_t stream = nullptr) {
+// zero); intermediate quotients alternate between tmp and tmp2 — without a tmp2, src is clobbered when there are >= 2 roots
+inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out, h2mi_stream_t stream = nullptr,
+                       DeviceVec* tmp2 = nullptr) {
   DeviceVec* cur = &src;
-  DeviceVec* bufs[2] = {&tmp, &src};
+  DeviceVec* bufs[2] = {&tmp, tmp2 ? tmp2 : &src};
   size_t len = n;
   for (size_t i = 0; i < roots.size(); i++) {
     DeviceVec* dst = i + 1 == roots.size() ? &out : bufs[i % 2];
@@ -475,6 +476,7 @@ struct RotationSet {
 struct ShplonkScratch {  // n-element device vectors the argument works in (at least as many q as rotation sets)
   DeviceVec *nx, *tmp, *h_x, *l_x, *h2_x;
   std::vector<Dev>* q;
+  std::vector<Dev>* s;  // per rotation set: sum_j y^j P_ij(X) - R_i(X), kept from the quotient step for the linearisation
   // optional extra lanes (side stream + its own nx / tmp): the rotation sets' quotient chains are independent, so set i
   // runs on lane i mod (1 + lanes.size()) and the longest chain, not their sum, is waited for
   struct Lane {
@@ -540,7 +542,9 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
   const Fr v = tr.squeeze_challenge();
   DeviceVec &nx = *sc.nx, &tmp = *sc.tmp, &h_x = *sc.h_x, &l_x = *sc.l_x, &h2_x = *sc.h2_x;
   std::vector<Dev>& q = *sc.q;
-  if (sets.size() > q.size()) throw Error(H2MI_ERANGE, "shplonk: more rotation sets than scratch vectors");
+  std::vector<Dev>& ssum = *sc.s;
+  if (sets.size() > q.size() || sets.size() > ssum.size()) throw Error(H2MI_ERANGE, "shplonk: more rotation sets than scratch vectors");
+  std::vector<std::vector<Fr>> remainders;  // R_i(X) = sum_j y^j R_ij(X), low to high
   for (size_t i = 0; i < sets.size(); i++) check(h2mi_memset_zero(q[i]->p, n * 32), "zero");
   for (const auto& lane : sc.lanes) check(h2mi_stream_wait(lane.stream, nullptr), "stream_wait");
   for (size_t i = 0; i < sets.size(); i++) {
@@ -553,14 +557,17 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
     for (size_t j = 1; j < ypow.size(); j++) ypow[j] = fr::mul(ypow[j - 1], y);
     std::vector<const DeviceVec*> polys;
     for (auto& m : rs.members) polys.push_back(m.first);
-    lincomb(polys, ypow, n, lnx, stream);
+    lincomb(polys, ypow, n, *ssum[i], stream);
     std::vector<Fr> rsum(rs.points.size(), fr_zero());
     for (size_t j = 0; j < rs.members.size(); j++) {
       std::vector<Fr> r = interpolate(rs.points, rs.members[j].second);
       for (size_t t = 0; t < r.size(); t++) rsum[t] = fr::sub(rsum[t], fr::mul(ypow[j], r[t]));
     }
-    add_head(lnx, rsum, stream);
-    kate_chain(lnx, n, rs.points, ltmp, *q[i], stream);
+    add_head(*ssum[i], rsum, stream);
+    std::vector<Fr> rem;
+    for (const Fr& c : rsum) rem.push_back(fr::neg(c));
+    remainders.push_back(rem);
+    kate_chain(*ssum[i], n, rs.points, ltmp, *q[i], stream, &lnx);
   }
   for (const auto& lane : sc.lanes) check(h2mi_stream_wait(nullptr, lane.stream), "stream_wait");
   {
@@ -581,25 +588,26 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
     z_diffs.push_back(vanishing_at(diffs, u));
   }
   const Fr norm = fr::invert(z_diffs[0]);
+  // linearisation: sum_j y^j (P_ij(X) - R_ij(u)) = S_i(X) + R_i(X) - R_i(u) with S_i the vector the quotient step left in
+  // ssum[i] — one linear combination over the rotation sets' sums and h(X) instead of every opened polynomial again
   std::vector<const DeviceVec*> polys;
   std::vector<Fr> scalars;
-  Fr konst = fr_zero(), vp = fr::ONE;
+  size_t head_len = 0;
+  for (const RotationSet& rs : sets) head_len = std::max(head_len, rs.points.size());
+  std::vector<Fr> head(head_len, fr_zero());
+  Fr vp = fr::ONE;
   for (size_t i = 0; i < sets.size(); i++) {
     const Fr w = fr::mul(fr::mul(vp, z_diffs[i]), norm);
-    Fr yp = fr::ONE;
-    for (auto& m : sets[i].members) {
-      const Fr sc = fr::mul(w, yp);
-      polys.push_back(m.first);
-      scalars.push_back(sc);
-      konst = fr::sub(konst, fr::mul(sc, horner(interpolate(sets[i].points, m.second), u)));
-      yp = fr::mul(yp, y);
-    }
+    polys.push_back(ssum[i].get());
+    scalars.push_back(w);
+    for (size_t t = 0; t < remainders[i].size(); t++) head[t] = fr::add(head[t], fr::mul(w, remainders[i][t]));
+    head[0] = fr::sub(head[0], fr::mul(w, horner(remainders[i], u)));
     vp = fr::mul(vp, v);
   }
   polys.push_back(&h_x);
   scalars.push_back(fr::neg(fr::mul(zt_eval, norm)));
   lincomb(polys, scalars, n, l_x);
-  add_head(l_x, {konst});
+  add_head(l_x, head);
   check(h2mi_memset_zero(h2_x.p, n * 32), "zero");
   kate_chain(l_x, n, {u}, tmp, h2_x);
   commit_and_write(h2_x);
@@ -609,7 +617,7 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
 // examples/linear_regression.rs:178-185); allocating and freeing ~1 GB of vectors per proof costs more than the proof
 struct ProverWorkspace {
   size_t n, ext;
-  std::vector<Dev> advice, advice_polys, advice_cosets, z, z_polys, z_cosets, shplonk_q;
+  std::vector<Dev> advice, advice_polys, advice_cosets, z, z_polys, z_cosets, shplonk_q, shplonk_s;
   Dev random_poly, h, h_poly, points, evals, nx, tmp, h_x, l_x, h2_x;
   std::unique_ptr<ShplonkLanes> lanes;
   h2mi_stream_t side = nullptr;  // transforms of the advice columns run here, beside the permutation argument's chain
@@ -625,6 +633,7 @@ struct ProverWorkspace {
       z.push_back(vec(n)); z_polys.push_back(vec(n)); z_cosets.push_back(vec(ext));
     }
     for (int i = 0; i < 4; i++) shplonk_q.push_back(vec(n));
+    for (int i = 0; i < 4; i++) shplonk_s.push_back(vec(n));
     random_poly = vec(n); h = vec(ext); h_poly = vec(n); points = vec(12); evals = vec(32);
     nx = vec(n); tmp = vec(n); h_x = vec(n); l_x = vec(n); h2_x = vec(n);
     lanes.reset(new ShplonkLanes(n));
@@ -669,6 +678,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     check(h2mi_memcpy_h2d_async((char*)col.p + (size_t)u * 32, &blind[(size_t)j * (bf + 1)], (bf + 1) * 32), "blinding rows");
   }
   for (uint32_t j = 0; j < na; j++) commit(params.g_lagrange_handle(), advice[j]->p, j);
+  check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // the advice columns' coefficient / extended forms wait for no challenge: on the side stream they run beside the
   // transcript round trip and the permutation argument's latency-bound scans
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
@@ -700,6 +710,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   for (uint32_t m = 0; m < na; m++)
     check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");
   for (uint32_t m = 0; m < na; m++) commit(params.g_lagrange_handle(), z[m]->p, m);
+  check(h2mi_msm_flush(), "flush");
   // coefficient / extended forms of z, queued behind the commitments
   for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *z[j], *z_polys[j], *z_cosets[j]);
   check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");  // evaluate_h and the openings read the advice forms
@@ -801,7 +812,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   for (uint32_t c = 0; c < na; c++) q(pk.permutation.polys[c].get(), x);
   q(&h_poly, x);
   q(&random_poly, x);
-  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, ws.lanes->lanes()};
+  ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, &ws.shplonk_s, ws.lanes->lanes()};
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
     commit(params.g_handle(), poly.p, 0);
     write_phase_points(1);

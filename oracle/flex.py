@@ -99,65 +99,67 @@ class Assignment:
         self.copies = []  # ((kind, column, row), (kind, column, row)): constrain_equal(left, right)
 
 
-# ---- the two halo2-lib closures of the reference, laid out as halo2-base lays them out [RECALL] ------------------------
-class _Ctx:
-    """halo2-base Context on one advice column: cells appended in order; Existing(cell) copies; Constant(v) cells are tied
-    to the constants column afterwards (one fixed cell per distinct value, in order of first appearance)."""
+# ---- the halo2-lib closures of the reference as explicit cell tables [RECALL halo2-base 0.3 gates/flex_gate.rs, range.rs] ---------
+# Written from halo2-base's own description of what each instruction assigns — NOT from the product's host (flex.Context appends
+# cells through an imperative Context; here every closure is a literal table of rows with closed-form row indices, so the tests'
+# `asg.advice == oasg.advice` compares two independently written layouts):
+#   GateChip::mul(a, b)       assign_region_last([Constant(0), a, b, Witness(a b)], [0])
+#   GateChip::add(a, b)       assign_region_last([a, b, Constant(1), Witness(a + b)], [0])
+#   GateChip::mul_add(a,b,c)  assign_region_last([c, a, b, Witness(a b + c)], [0])
+#   GateChip::inner_product(a, b) with b[0] = Constant(1): cells a_0, then (a_i, b_i, running sum) for i >= 1, gates on rows 0, 3, 6, ...
+#                             otherwise Constant(0), then (a_i, b_i, running sum) for i >= 0
+#   RangeChip::range_check(a, bits): k = ceil(bits / lookup_bits) limbs through inner_product(limbs, [1, 2^lb, 2^(2 lb), ...]);
+#                             constrain_equal(a, acc); "the progression of indices is 0, 1, 4, ..., 4 + 3 i" for cells_to_lookup;
+#                             rem = bits % lookup_bits: 1 -> assert_bit(last limb) = | 0 | x | x | x |, > 1 -> mul(last limb,
+#                             Constant(2^(lookup_bits - rem))) whose output is looked up too
+#   Context: an Existing(cell) input re-assigns the value and records (new cell, cell) in advice_equality_constraints, a
+#   Constant(c) input records (c, new cell) in constant_equality_constraints; assign_all applies the advice equalities in
+#   order, assign_constants gives every distinct constant ONE fixed cell (first-appearance order) and ties its uses to it;
+#   the scaffold's wrapper then constrains the public cells to the instance column (src/scaffold.rs:411, 480).
+W_, E_, K_ = "witness", "existing", "constant"
 
-    def __init__(self, asg):
-        self.asg = asg
-        self.cells = []           # values of advice column 0
-        self.const_cells = []     # (row, value)
-        self.lookup_cells = []    # rows whose value must be looked up
 
-    def load_witness(self, v):
-        self.cells.append(v % R)
-        return len(self.cells) - 1
+class _Table:
+    """a closure as data: rows of (kind, value, source row for Existing), gate rows, extra equalities, looked-up rows"""
 
-    def assign_region_last(self, items, gate_offsets):
-        base = len(self.cells)
-        for kind, v in items:
-            row = len(self.cells)
-            if kind == "existing":
-                self.cells.append(self.cells[v])
-                self.asg.copies.append(((ADVICE, 0, row), (ADVICE, 0, v)))
-            elif kind == "constant":
-                self.cells.append(v % R)
-                self.const_cells.append((row, v % R))
+    def __init__(self):
+        self.rows, self.gates, self.lookups = [], [], []
+        self.events = []  # advice_equality_constraints in chronological order: (new row, source row)
+
+    def put(self, cells, gate_offsets=()):
+        """cells: [(kind, value or source row)]; -> row of the first cell"""
+        base = len(self.rows)
+        for kind, v in cells:
+            if kind == E_:
+                self.events.append((len(self.rows), v))
+                self.rows.append((E_, self.rows[v][1]))
             else:
-                self.cells.append(v % R)
-        for off in gate_offsets:
-            self.asg.fixed[self.asg.cs.col_q][base + off] = 1
-        return len(self.cells) - 1
+                self.rows.append((kind, v % R))
+        self.gates += [base + g for g in gate_offsets]
+        return base
 
-    def mul(self, a, b):
-        return self.assign_region_last([("constant", 0), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b])], [0])
+    def value(self, row):
+        return self.rows[row][1]
 
-    def add_const(self, a, c):
-        return self.assign_region_last([("existing", a), ("constant", c), ("constant", 1), ("witness", self.cells[a] + c)], [0])
-
-    def add(self, a, b):
-        return self.assign_region_last([("existing", a), ("existing", b), ("constant", 1), ("witness", self.cells[a] + self.cells[b])], [0])
-
-    def mul_add_const(self, a, b, c):
-        return self.assign_region_last([("constant", c), ("existing", a), ("existing", b), ("witness", self.cells[a] * self.cells[b] + c)], [0])
-
-    def finish(self, public_rows):
-        asg = self.asg
-        cs = asg.cs
-        for row, v in enumerate(self.cells):
-            asg.advice[0][row] = v
-        consts = {}
-        for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, then constrain_equal
-            if v not in consts:
-                consts[v] = len(consts)
-                asg.fixed[cs.col_const][consts[v]] = v
-            asg.copies.append(((ADVICE, 0, row), (FIXED, cs.col_const, consts[v])))
-        for row in self.lookup_cells:  # single advice column: q_lookup is enabled on the cell's own row, nothing is copied
-            asg.fixed[cs.col_qlookup][row] = 1
-        for i, row in enumerate(public_rows):  # constrain_instance(cell, instance, i)
-            asg.instance[0].append(self.cells[row])
-            asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
+    def assignment(self, cs, public_rows):
+        asg = Assignment(cs)
+        asg.advice[0] = {r: v for r, (_, v) in enumerate(self.rows)}
+        for g in self.gates:
+            asg.fixed[cs.col_q][g] = 1
+        asg.copies = [((ADVICE, 0, new), (ADVICE, 0, src)) for new, src in self.events]
+        first_use = {}
+        for r, (kind, v) in enumerate(self.rows):
+            if kind == K_:
+                first_use.setdefault(v, len(first_use))
+        for v, slot in first_use.items():
+            asg.fixed[cs.col_const][slot] = v
+        asg.copies += [((ADVICE, 0, r), (FIXED, cs.col_const, first_use[v])) for r, (kind, v) in enumerate(self.rows) if kind == K_]
+        for r in self.lookups:  # single advice column: q_lookup on the cell's own row
+            asg.fixed[cs.col_qlookup][r] = 1
+        for i, r in enumerate(public_rows):
+            asg.instance[0].append(self.value(r))
+            asg.copies.append(((ADVICE, 0, r), (INSTANCE, 0, i)))
+        return asg
 
 
 def standard_plonk_assignment(cs, x):
@@ -175,54 +177,55 @@ def standard_plonk_assignment(cs, x):
 
 
 def halo2_lib_assignment(cs, x):
-    """examples/halo2_lib.rs:14-60: x^2 + 72 three ways; public: x and out"""
-    asg = Assignment(cs)
-    ctx = _Ctx(asg)
-    xc = ctx.load_witness(x)
-    x_sq = ctx.mul(xc, xc)
-    out = ctx.add_const(x_sq, 72)
-    val = (x * x + 72) % R
-    ctx.assign_region_last([("constant", 72), ("existing", xc), ("existing", xc), ("witness", val)], [0])
-    ctx.mul_add_const(xc, xc, 72)
-    ctx.finish([xc, out])
-    return asg
+    """examples/halo2_lib.rs:14-60: x^2 + 72 three ways; public: x and out.  Seventeen rows:
+         0        x                       load_witness
+         1 ..  4  0, x, x, x^2            gate.mul(x, x)                          gate on row 1
+         5 ..  8  x^2, 72, 1, x^2 + 72    gate.add(x_sq, Constant(72))            gate on row 5
+         9 .. 12  72, x, x, x^2 + 72      assign_region_last([...], [0])          gate on row 9
+        13 .. 16  72, x, x, x^2 + 72      gate.mul_add(x, x, Constant(72))        gate on row 13"""
+    x %= R
+    t = _Table()
+    t.put([(W_, x)])
+    t.put([(K_, 0), (E_, 0), (E_, 0), (W_, x * x)], [0])
+    t.put([(E_, 4), (K_, 72), (K_, 1), (W_, x * x + 72)], [0])
+    t.put([(K_, 72), (E_, 0), (E_, 0), (W_, x * x + 72)], [0])
+    t.put([(K_, 72), (E_, 0), (E_, 0), (W_, x * x + 72)], [0])
+    assert len(t.rows) == 17 and t.gates == [1, 5, 9, 13]
+    return t.assignment(cs, [0, 8])
 
 
 def range_assignment(cs, x, lookup_bits, n):
     """examples/range.rs:10-34: x public, range_check(x, 64) with LOOKUP_BITS limbs, then x + x.  The table column holds
-    0 .. 2^LOOKUP_BITS - 1 (RangeConfig::load_lookup_table), zero elsewhere."""
-    assert 0 <= x < 1 << 64
-    asg = Assignment(cs)
-    ctx = _Ctx(asg)
-    xc = ctx.load_witness(x)
-    num_limbs = -(-64 // lookup_bits)
-    limbs = [(x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1) for i in range(num_limbs)]
-    # inner_product_left_last(limbs, bases) with bases[0] = 1: [l0, l1, 2^b, acc1, l2, 2^2b, acc2, ...], gate on every third row
-    rows = [ctx.load_witness(limbs[0])]
-    acc_row, acc = rows[0], limbs[0]
-    for i in range(1, num_limbs):
-        base = len(ctx.cells) - 1  # the accumulator cell doubles as the gate's first cell
-        acc = acc + limbs[i] * (1 << (lookup_bits * i))
-        ctx.cells.append(limbs[i])
-        rows.append(len(ctx.cells) - 1)
-        ctx.cells.append((1 << (lookup_bits * i)) % R)
-        ctx.const_cells.append((len(ctx.cells) - 1, (1 << (lookup_bits * i)) % R))
-        ctx.cells.append(acc % R)
-        asg.fixed[cs.col_q][base] = 1
-        acc_row = len(ctx.cells) - 1
-    asg.copies.append(((ADVICE, 0, xc), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
-    ctx.lookup_cells += rows
+    0 .. 2^LOOKUP_BITS - 1 (RangeConfig::load_lookup_table), zero elsewhere.  Rows: 0 = x; the inner product occupies rows
+    1 .. 3k - 1 (k limbs): limb 0 at row 1, limb i >= 1 at row 3 i - 1, its base 2^(i lb) at row 3 i, the running sum at row
+    3 i + 1, gates on rows 1, 4, 7, ...; then the remainder cells, then [x, x, 1, 2x]."""
+    assert 0 <= x < 1 << 64 and n >= 1 << lookup_bits
+    k = -(-64 // lookup_bits)
+    limb = lambda i: (x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1)
+    partial = lambda i: x & ((1 << (lookup_bits * (i + 1))) - 1)  # sum of limbs 0 .. i with their bases
+    t = _Table()
+    t.put([(W_, x)])
+    cells = [(W_, limb(0))]
+    for i in range(1, k):
+        cells += [(W_, limb(i)), (K_, 1 << (lookup_bits * i)), (W_, partial(i))]
+    base = t.put(cells, [3 * j for j in range(k - 1)])
+    assert base == 1
+    limb_row = lambda i: 1 if i == 0 else 3 * i - 1
+    acc_row = 3 * (k - 1) + 1 if k > 1 else 1
+    assert len(t.rows) == acc_row + 1 and t.value(acc_row) == x
+    t.events.append((0, acc_row))  # ctx.constrain_equal(&a, &acc)
+    t.lookups = [limb_row(i) for i in range(k)]
     rem = 64 % lookup_bits
-    if rem == 1:  # range.rs `match rem_bits.cmp(&1)`: a one-bit top limb is checked by assert_bit: | 0 | x | x | x |
-        ctx.assign_region_last([("constant", 0), ("existing", rows[-1]), ("existing", rows[-1]), ("existing", rows[-1])], [0])
-    elif rem:  # the top limb must fit the remaining bits: limb * 2^(lookup_bits - rem) is looked up too
-        top = ctx.assign_region_last([("constant", 0), ("existing", rows[-1]), ("constant", 1 << (lookup_bits - rem)),
-                                      ("witness", limbs[-1] << (lookup_bits - rem))], [0])
-        ctx.lookup_cells.append(top)
-    ctx.add(xc, xc)
-    ctx.finish([xc])
-    for i in range(1 << lookup_bits):
-        asg.fixed[cs.col_table][i] = i
+    top = limb_row(k - 1)
+    if rem == 1:
+        t.put([(K_, 0), (E_, top), (E_, top), (E_, top)], [0])
+    elif rem > 1:
+        shift = 1 << (lookup_bits - rem)
+        r0 = t.put([(K_, 0), (E_, top), (K_, shift), (W_, limb(k - 1) * shift)], [0])
+        t.lookups.append(r0 + 3)
+    t.put([(E_, 0), (E_, 0), (K_, 1), (W_, 2 * x)], [0])
+    asg = t.assignment(cs, [0])
+    asg.fixed[cs.col_table] = {i: i for i in range(1 << lookup_bits)}
     return asg
 
 

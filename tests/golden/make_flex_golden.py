@@ -24,38 +24,49 @@ R = FX.R
 
 
 def poseidon_assignment(cs, x, y):
-    """examples/poseidon.rs:15-36 on the oracle's _Ctx: the same cell layout as halo2-scaffold_amd/poseidon.py, written
-    against oracle/poseidon.py's parameters"""
+    """examples/poseidon.rs:15-36 on the oracle's cell tables (oracle/flex.py _Table): the sponge of T = 3, RATE = 2 absorbing
+    [x, y] laid out from the oracle's own permutation, gate by gate [RECALL snark-verifier's halo2-base Poseidon chip]:
+    add-round-constants by gate.add(cell, Constant(c)), x^5 as three gate.mul, the MDS rows as inner products whose first
+    coefficient is not one ([0, (cell, Constant(m), sum) ...])"""
     constants, mds = OP.params()
-    asg = FX.Assignment(cs)
-    ctx = FX._Ctx(asg)
-    xc, yc = ctx.load_witness(x), ctx.load_witness(y)
-    state = [ctx.assign_region_last([("constant", v)], []) for v in (1 << 64, 0, 0)]
+    W, E, K = FX.W_, FX.E_, FX.K_
+    t = FX._Table()
+    last = lambda base, count: base + count - 1
+    xc, yc = t.put([(W, x)]), t.put([(W, y)])
+    state = [t.put([(K, v)]) for v in (1 << 64, 0, 0)]
+
+    def add_const(cell, c):
+        return last(t.put([(E, cell), (K, c), (K, 1), (W, t.value(cell) + c)], [0]), 4)
+
+    def add(a, b):
+        return last(t.put([(E, a), (E, b), (K, 1), (W, t.value(a) + t.value(b))], [0]), 4)
+
+    def mul(a, b):
+        return last(t.put([(K, 0), (E, a), (E, b), (W, t.value(a) * t.value(b))], [0]), 4)
 
     def inner(cells, coeffs):
-        items, gates, acc = [("constant", 0)], [], 0
-        for k, (cell, c) in enumerate(zip(cells, coeffs)):
-            acc = (acc + ctx.cells[cell] * c) % R
-            items += [("existing", cell), ("constant", c), ("witness", acc)]
-            gates.append(3 * k)
-        return ctx.assign_region_last(items, gates)
+        items, acc = [(K, 0)], 0
+        for cell, c in zip(cells, coeffs):
+            acc = (acc + t.value(cell) * c) % R
+            items += [(E, cell), (K, c), (W, acc)]
+        return last(t.put(items, [3 * j for j in range(len(cells))]), len(items))
 
     def permute(st):
         for rnd in range(8 + 57):
-            s = [ctx.add_const(cell, c) for cell, c in zip(st, constants[rnd])]
+            s = [add_const(cell, c) for cell, c in zip(st, constants[rnd])]
             for i in (range(3) if rnd < 4 or rnd >= 4 + 57 else range(1)):
-                x2 = ctx.mul(s[i], s[i])
-                x4 = ctx.mul(x2, x2)
-                s[i] = ctx.mul(x4, s[i])
+                x2 = mul(s[i], s[i])
+                x4 = mul(x2, x2)
+                s[i] = mul(x4, s[i])
             st = [inner(s, row) for row in mds]
         return st
 
-    state[1] = ctx.add(state[1], xc)
-    state[2] = ctx.add(state[2], yc)
+    state[1] = add(state[1], xc)
+    state[2] = add(state[2], yc)
     state = permute(state)
-    state[1] = ctx.add_const(state[1], 1)  # the empty chunk after an exact multiple of RATE: padding only
+    state[1] = add_const(state[1], 1)  # the empty chunk after an exact multiple of RATE: padding only
     state = permute(state)
-    ctx.finish([xc, yc, state[1]])
+    asg = t.assignment(cs, [xc, yc, state[1]])
     assert asg.instance[0][2] == OP.sponge_hash([x, y])
     return asg
 

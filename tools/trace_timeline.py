@@ -3,7 +3,7 @@
 tools/proof_loop.py): start (us from the group's first dispatch), duration, gap to the latest earlier end on the same queue,
 queue id, kernel.  Ends with the totals that matter for a latency-bound proof: span, sum of durations per queue, idle time
 of the union of all queues.
-Usage: trace_timeline.py TRACE.csv LAUNCHES [--summary]"""
+Usage: trace_timeline.py TRACE.csv LAUNCHES [--summary] [--last]   (--last: the final LAUNCHES dispatches, e.g. the C++ examples' steady loop)"""
 import csv
 import re
 import sys
@@ -11,7 +11,7 @@ import sys
 path, launches = sys.argv[1], int(sys.argv[2])
 rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-group = rows[-2 * launches : -launches] if len(rows) >= 2 * launches else rows[-launches:]
+group = rows[-launches:] if "--last" in sys.argv or len(rows) < 2 * launches else rows[-2 * launches : -launches]
 t0 = int(group[0]["Start_Timestamp"])
 last_end = {}
 intervals = []
