@@ -79,6 +79,7 @@ def main():
         else:
             dist.init_process_group(backend)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    ranks_info = rank_device_report(torch, dist, rank, local_rank, world)
 
     import _load_pkg
 
@@ -191,7 +192,7 @@ def main():
     # HBM traffic of the kernel comes from rocprofv3 PMC counters, which cannot be collected from inside this
     # process: the field carries the figure of the latest committed counter run of this same workload and says so
     traffic, traffic_source = None, None
-    for tname in ("r02_traffic.json", "r01_traffic.json"):
+    for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and world == 1 and args.k == 20 and args.shape == "standard_plonk":
             try:
@@ -254,11 +255,16 @@ def main():
             "msm_buckets": nb.value,
             "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
             "combines_per_step": (R.combiner.combines // max(args.warmup + args.steps + 1, 1)) if R.combiner is not None else 0,
-            "combine": (("RCCL all-gather + device fold at every transcript join, device-resident" if backend == "nccl" else
-                         "gloo all-gather (host) + device fold at every transcript join") if R.combiner is not None else "none (single GPU)"),
+            "combine": ((("RCCL all-gather + device fold at every transcript join, device-resident" if R.combiner.mode == "rccl" else
+                          "RCCL all-gather through host-synchronised copies (H2MI_COMBINE=host) + device fold at every transcript join")
+                         if backend == "nccl" else "gloo all-gather (host) + device fold at every transcript join") if R.combiner is not None
+                        else "none (single GPU)"),
             "what_is_timed": ("MSM + NTT + evaluate_h kernels on HBM-resident vectors; not transcript / witness generation" if R.with_evaluate_h else
                               "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation"),
         },
+        "rccl_world_seen": (dist.get_world_size() if dist is not None else 1),
+        "collective_backend": (backend if dist is not None else None),
+        "ranks": ranks_info,
         "commitments_sha256": digest,
         "ntt_placement": ("single GPU" if world == 1 else "leaf transforms spread round-robin, consumed transforms on every rank"
                           if R.spread else "every rank replays every transform"),
@@ -270,10 +276,22 @@ def main():
         "issue_roofline": issue,
     }
 
+    if world == 1 and args.k == 20 and shape.name == "standard_plonk":
+        try:
+            out["roofline_ntt"] = time_ntt_roofline(h2)
+        except Exception as e:  # never lose the headline line to an auxiliary measurement
+            out["roofline_ntt"] = {"error": repr(e)}
     if create_proof_stats is not None:
         out["create_proof"] = create_proof_stats
         out["pipeline_ms_per_step"] = create_proof_stats["ms_per_proof"]
         if world == 1 and args.k == 20:
+            try:
+                small = time_small_proofs(h2, ROOT)
+                out["create_proof_k16"], out["create_proof_k8"] = small["k16"], small["k8"]
+                out["create_proof"]["cpp_host_ms"] = small["k20"].get("cpp_host_ms")
+                out["create_proof_hosts_what"] = small["what"]
+            except Exception as e:
+                out["create_proof_k16"] = {"error": repr(e)}
             # BASELINE configs[2], [4], [3] data-true on this GPU: create_proof through the halo2-lib builders
             try:
                 out["halo2_lib_create_proof"] = time_halo2_lib_examples(h2, R)
@@ -284,6 +302,132 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def rank_device_report(torch, dist, rank, local_rank, world):
+    """every rank's device ordinal and PCI bus id, gathered to all ranks; two ranks on one device without the H2MI_DEVICE
+    rehearsal knob is a launch mistake (each rank would time half a GPU): fail loudly on every rank."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        name = pr.name
+    except Exception as e:  # no GPU visible: the library's init reports that properly a moment later
+        bus, name = "unknown", repr(e)
+    mine = {"rank": rank, "device": local_rank, "pci_bus_id": bus, "name": name, "visible_devices": torch.cuda.device_count()}
+    if dist is None:
+        return [mine]
+    info = [None] * dist.get_world_size()
+    dist.all_gather_object(info, mine)
+    seen = {}
+    for r in info:
+        seen.setdefault((r["device"], r["pci_bus_id"]), []).append(r["rank"])
+    shared = {k: v for k, v in seen.items() if len(v) > 1}
+    if shared and "H2MI_DEVICE" not in os.environ:
+        raise SystemExit(f"ranks share a GPU {shared}: launch one rank per device (LOCAL_RANK), or set H2MI_DEVICE=<i> for a one-GPU rehearsal")
+    return info
+
+
+def time_ntt_roofline(h2):
+    """the NTT kernels alone: per-transform launch time of k_ntt_pass_* from HIP events on the library's
+    launch stream, against both bounds — HBM on the algorithmic 64 n bytes per transform and 32-bit multiply
+    issue on the transform's field multiplications (162 v_mad_u64_u32 each; tools/ubench.hip: 32.6 T mad/s)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from halo2_scaffold_amd import field as F
+    from halo2_scaffold_amd.device import DevBuf
+
+    lib = h2.lib
+
+    def mults_per_element(log_n, coset):  # csrc/h2mi_ntt.hip choose_split + local_ntt: radix-4 rounds, the first one nearly free
+        if log_n <= 10:
+            ms = [log_n]
+        elif log_n <= 20:
+            ms = [(log_n + 1) // 2, log_n - (log_n + 1) // 2]
+        else:
+            m0 = (log_n + 2) // 3
+            m1 = (log_n - m0 + 1) // 2
+            ms = [m0, m1, log_n - m0 - m1]
+        per = sum((m // 2 - 1) + 0.25 + (0.5 if m & 1 else 0) for m in ms)
+        return per + (len(ms) - 1) + (1 if coset else 0), ms
+
+    out = {}
+    for label, log_n, coset in (("ntt_2^20", 20, False), ("coset_ntt_2^21", 21, True), ("ntt_2^24", 24, False)):
+        n = 1 << log_n
+        buf = DevBuf(n * 32)
+        h2._lib.check(lib.h2mi_fr_random_dev(buf.ptr, n, 0x4E5454, 0, None), "random")
+        omega = F.fr_to_mont_limbs(F.omega_for(log_n))
+        pre = F.fr_to_mont_limbs(F.FR_ZETA) if coset else None
+        run = lambda: h2._lib.check(lib.h2mi_ntt_bn254_fr_dev(buf.ptr, log_n, omega.ctypes.data, pre.ctypes.data if coset else None, None, None), "ntt")
+        for _ in range(3):
+            run()
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        reps = 10 if log_n <= 21 else 4
+        lib.h2mi_profile_reset()
+        lib.h2mi_profile_filter(b"k_ntt_pass")
+        lib.h2mi_profile_enable(1)
+        for _ in range(reps):
+            run()
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        lib.h2mi_profile_enable(0)
+        tot, cnt = C.c_double(), C.c_uint64()
+        lib.h2mi_profile_query(b"k_ntt_pass", C.byref(tot), C.byref(cnt))
+        lib.h2mi_profile_reset()
+        buf.free()
+        us = tot.value / reps * 1e3
+        mpe, ms = mults_per_element(log_n, coset)
+        gbs = 64 * n / (us * 1e-6) / 1e9
+        mads = mpe * 162 * n / (us * 1e-6) / 1e12
+        out[label] = {"us_per_transform": round(us, 1), "launches_per_transform": cnt.value // reps, "passes": ms,
+                      "algorithmic_bytes": 64 * n, "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                      "mad_issue": {"field_mults_per_element": mpe, "achieved": round(mads, 2), "peak": 32.6, "unit": "T mad/s", "frac": round(mads / 32.6, 4)}}
+    out["bound"] = "valu (v_mad_u64_u32 issue): see DESIGN.md 4.2; the HBM fraction is the contractual figure on 64 n algorithmic bytes"
+    return out
+
+
+def time_small_proofs(h2, root):
+    """create_proof() at the other BASELINE sizes (configs[1]: DEGREE 16; configs[0]: DEGREE 8 — CPU-only in BASELINE, here as
+    the launch-latency floor), steady state, host-inclusive wall clock: the Python host in this process and the C++ host
+    (examples/standard_plonk, the compiled mirror of the reference's Rust example) as a child process."""
+    import subprocess
+
+    from halo2_scaffold_amd import circuits, keygen, prover
+    from halo2_scaffold_amd.params import ParamsKZG
+
+    lib = h2.lib
+    out = {}
+    exe = os.path.join(root, "examples", "standard_plonk")
+    for k in (16, 8, 20):
+        entry = {}
+        if k != 20:  # the k = 20 Python-host figure is the create_proof block itself
+            params = ParamsKZG.setup(k, 0x5EC2E7 + 0x48324D49)
+            c = circuits.StandardPlonk(None)
+            pk = keygen.keygen_pk(params, keygen.keygen_vk(params, c), c)
+            ws = prover.ProverWorkspace(params, pk)
+            for i in range(3):
+                prover.create_proof(params, pk, circuits.StandardPlonk(5 + i), 10 + i, ws=ws)
+            h2._lib.check(lib.h2mi_sync(), "sync")
+            times = []
+            for i in range(20):
+                t0 = time.perf_counter()
+                prover.create_proof(params, pk, circuits.StandardPlonk(50 + i), 100 + i, ws=ws)
+                times.append(time.perf_counter() - t0)
+            ws.release()
+            pk.release()
+            params.release()
+            entry["python_host_ms"] = round(1e3 * sum(times) / len(times), 3)
+            entry["python_host_min_ms"] = round(1e3 * min(times), 3)
+        try:
+            r = subprocess.run([exe, str(k)], capture_output=True, text=True, timeout=300, env=dict(os.environ, H2MI_PROOFS="20" if k < 20 else "10"))
+            line = next(l for l in r.stdout.splitlines() if l.startswith("steady_ms_per_proof"))
+            entry["cpp_host_ms"] = round(float(line.split()[1]), 3)
+        except Exception as e:  # the C++ example is optional evidence: never lose the headline line to it
+            entry["cpp_host_error"] = repr(e)[:200]
+        out[f"k{k}"] = entry
+    out["what"] = ("steady-state create_proof() wall clock per proof, host-inclusive; cpp_host = examples/standard_plonk.cpp over include/h2mi_plonk.hpp "
+                   "(same C ABI, same proof bytes)")
+    return out
 
 
 def time_halo2_lib_examples(h2, R):
@@ -356,6 +500,7 @@ def time_create_proof(h2, R, args, dist, backend, torch_device, coll_dev):
     h2._lib.check(lib.h2mi_sync(), "sync")
     keygen_s = time.perf_counter() - t0
     ws = prover.ProverWorkspace(params, pk, combiner=combiner)
+    proofs_run = 0
 
     def barrier():
         h2._lib.check(lib.h2mi_sync(), "sync")
@@ -399,14 +544,17 @@ def time_create_proof(h2, R, args, dist, backend, torch_device, coll_dev):
     phase_ms = tr.get("phase_ms")
     ws.release()
     pk.release()
-    if combiner is not None:
+    combines_per_proof = 0
+    if combiner is not None:  # counted, not assumed: every create_proof above went through this combiner
+        proofs_run = max(args.warmup, 1) + args.steps + 2
+        combines_per_proof = combiner.combines // proofs_run
         combiner.release()
     times.sort()
     return {
         "ms_per_proof": round(sum(times) / len(times) * 1e3, 3),
         "min_ms": round(times[0] * 1e3, 3),
         "proofs": len(times),
-        "combines_per_proof": 6 if combiner is not None else 0,
+        "combines_per_proof": combines_per_proof,
         "proof_bytes": len(proof),
         "last_proof_sha256": hashlib.sha256(proof).hexdigest(),
         "keygen_vk_pk_seconds": round(keygen_s, 3),
@@ -416,7 +564,9 @@ def time_create_proof(h2, R, args, dist, backend, torch_device, coll_dev):
         "phase_ms": phase_ms,
         "what": ("create_proof() of the reference's StandardPlonk circuit at 2^%d rows: real witness and copy constraints, keygen'd proving key, "
                  "Blake2b transcript on the host, 11 MSM + 13 NTT + permutation products + evaluate_h + 21 evaluations + SHPLONK on the device; "
-                 "wall-clock, host-inclusive; rng = seeded SplitMix64 (the reference uses OsRng); verified by tests/test_gpu_prover.py, not here" % args.k),
+                 "wall-clock, host-inclusive; rng = seeded SplitMix64 (the reference uses OsRng); byte-identical to the in-repo CPU oracle (golden proof at this "
+                 "size: tests/test_gpu_big_golden.py), NOT interoperable with the reference's verify_proof: vk.transcript_repr is a stand-in for the "
+                 "crate's hash of the pinned key's Debug text, so every challenge differs from the Rust prover's" % args.k),
     }
 
 

@@ -2,6 +2,8 @@
 #include <algorithm>
 
 #include "g1.cuh"
+#include <cstdio>
+
 #include "h2mi_internal.h"
 
 namespace h2 {
@@ -214,12 +216,22 @@ int h2mi_init_devices(int n_devices) {
   for (int i = 1; i < n_devices; i++) {
     if (devs[(size_t)i].device == devs[0].device) continue;
     int can = 0;
-    if (hipDeviceCanAccessPeer(&can, devs[0].device, devs[(size_t)i].device) == hipSuccess && can) {
+    hipError_t pe = hipDeviceCanAccessPeer(&can, devs[0].device, devs[(size_t)i].device);
+    if (pe == hipSuccess && can) {
       hipSetDevice(devs[0].device);
-      hipDeviceEnablePeerAccess(devs[(size_t)i].device, 0);
-      hipSetDevice(devs[(size_t)i].device);
-      hipDeviceEnablePeerAccess(devs[0].device, 0);
+      pe = hipDeviceEnablePeerAccess(devs[(size_t)i].device, 0);
+      if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) {
+        hipSetDevice(devs[(size_t)i].device);
+        pe = hipDeviceEnablePeerAccess(devs[0].device, 0);
+      }
     }
+    // without peer access hipMemcpyPeerAsync stages through the host: correct but slow, so say so instead of hiding it
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+      std::fprintf(stderr, "h2mi: no peer access between devices %d and %d (%s): slices and partial results will be staged through the host\n",
+                   devs[0].device, devs[(size_t)i].device, hipGetErrorString(pe));
+    else if (!can)
+      std::fprintf(stderr, "h2mi: devices %d and %d cannot access each other's memory: copies will be staged through the host\n", devs[0].device,
+                   devs[(size_t)i].device);
   }
   (void)hipGetLastError();
   ctx().devs = devs;
@@ -242,6 +254,14 @@ void h2mi_shutdown(void) {
   use_device(0);
   msm_join_all(ctx().stream);
   hipStreamSynchronize(ctx().stream);
+  for (DevCtx& d : ctx().devs) {
+    hipSetDevice(d.device);
+    hipDeviceSynchronize();
+  }
+  msm_teardown();  // registrations on every device
+  use_device(0);
+  ntt_teardown();     // plans, power tables, scratch vectors (primary device)
+  lookup_teardown();  // counting-sort scratch and its event
   if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; g_fixed_built.destroy(); }
   for (hipEvent_t& ev : g_wait_ring)
     if (ev) { hipEventDestroy(ev); ev = nullptr; }

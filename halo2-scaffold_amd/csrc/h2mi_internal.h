@@ -116,6 +116,10 @@ int launch_fold_groups(const uint8_t* pts, size_t world, size_t k, uint8_t* out,
 // h2mi_msm.hip: make `s` wait for all outstanding MSM tails
 int msm_join_all(hipStream_t s);
 int msm_flush_all();
+// per-module teardown hooks of h2mi_shutdown (device memory, events and cached tables of the devices being released)
+void msm_teardown();
+void ntt_teardown();
+void lookup_teardown();
 
 inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 

@@ -40,8 +40,7 @@ __device__ __forceinline__ int cmp256(const fe& a, const fe& b) {  // canonical 
 // uniform), then within the workgroup through a 64-slot LDS table keyed by rank (a slot taken by another rank falls
 // back to the global atomic), and only the table is flushed to HBM: 2^22 zero rows -> 4096 global atomics.
 constexpr uint32_t LK_SLOTS = 64, LK_EMPTY = 0xFFFFFFFFu;
-__global__ void __launch_bounds__(1024) k_lk_rank(const fe* input, uint32_t u, const fe* sorted, uint32_t n_unique, uint32_t* rank, uint32_t* cnt,
-                                                  uint32_t* missing) {
+__global__ void __launch_bounds__(1024) k_lk_rank(const fe* input, uint32_t u, const fe* sorted, uint32_t n_unique, uint32_t* cnt, uint32_t* missing) {
   __shared__ uint32_t hkey[LK_SLOTS], hcnt[LK_SLOTS];
   if (threadIdx.x < LK_SLOTS) {
     hkey[threadIdx.x] = LK_EMPTY;
@@ -61,10 +60,8 @@ __global__ void __launch_bounds__(1024) k_lk_rank(const fe* input, uint32_t u, c
       else hi = mid;
     }
     if (lo < n_unique && cmp256(fe_load(&sorted[lo]), v) == 0) {
-      rank[i] = lo;
       active = true;
     } else {
-      rank[i] = LK_EMPTY;
       atomicAdd(missing, 1u);
     }
   }
@@ -144,6 +141,16 @@ static int scan_u32(const uint32_t* in, uint32_t* out, uint32_t m /* multiple of
   return H2MI_OK;
 }
 
+// h2mi_shutdown: the scratch and its event belong to the device that is being torn down
+void lookup_teardown() {
+  if (g_lk_scratch) hipFree(g_lk_scratch);
+  if (g_lk_event) hipEventDestroy(g_lk_event);
+  g_lk_scratch = nullptr;
+  g_lk_words = 0;
+  g_lk_event = nullptr;
+  g_lk_stream = nullptr;
+}
+
 }  // namespace h2
 
 using namespace h2;
@@ -154,16 +161,23 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
                                   uint32_t n_unique, uint32_t k, uint32_t usable_rows, void* d_permuted_input, void* d_permuted_table,
                                   uint64_t* not_in_table_out, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
-  if (!d_input || !d_table_sorted || !d_table_sorted_mont || !d_table_mult || !d_permuted_input || !d_permuted_table || n_unique == 0)
+  // not_in_table_out is mandatory: with inputs outside the table the permuted columns are not a permutation at all (the
+  // crate fails the proof with ConstraintSystemFailure), so a caller must not be able to overlook the count
+  if (!d_input || !d_table_sorted || !d_table_sorted_mont || !d_table_mult || !d_permuted_input || !d_permuted_table || !not_in_table_out ||
+      n_unique == 0)
     return H2MI_EINVAL;
   if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k) || n_unique > usable_rows) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  {
+    int rc0 = use_device(0);  // single-process n-device mode: the argument's vectors live on the primary device
+    if (rc0) return rc0;
+  }
   hipStream_t s = pick_stream(stream);
   const uint32_t u = usable_rows;
   const uint32_t mu = (n_unique + 3u) & ~3u, uu = (u + 3u) & ~3u;  // scan lengths (multiples of 4; the pads are zero)
   const uint32_t nseg = ceil_div_u32(std::max(mu, uu), SCAN_SEG_BINS) + 1;
-  // scratch (words): cnt[mu+4] start[mu+4] left[mu+4] lstart[mu+4] rank[uu] rep[uu+4] rep_before[uu+4] segsum[nseg] missing[4]
-  const size_t words = 4 * ((size_t)mu + 4) + (size_t)uu + 2 * ((size_t)uu + 4) + nseg + 4;
+  // scratch (words): cnt[mu+4] start[mu+4] left[mu+4] lstart[mu+4] rep[uu+4] rep_before[uu+4] segsum[nseg] missing[4]
+  const size_t words = 4 * ((size_t)mu + 4) + 2 * ((size_t)uu + 4) + nseg + 4;
   if (g_lk_words < words) {
     if (g_lk_scratch) {
       H2_HIP(hipDeviceSynchronize());
@@ -180,8 +194,7 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
   uint32_t* start = cnt + mu + 4;
   uint32_t* left = start + mu + 4;
   uint32_t* lstart = left + mu + 4;
-  uint32_t* rank = lstart + mu + 4;
-  uint32_t* rep = rank + uu;
+  uint32_t* rep = lstart + mu + 4;
   uint32_t* rep_before = rep + uu + 4;
   uint32_t* segsum = rep_before + uu + 4;
   uint32_t* missing = segsum + nseg;
@@ -190,7 +203,7 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
   const fe* in = (const fe*)d_input;
   const fe* sorted = (const fe*)d_table_sorted;
   const fe* sorted_mont = (const fe*)d_table_sorted_mont;
-  H2_LAUNCH("k_lk_rank", k_lk_rank, ceil_div_u32(u, 1024), 1024, 0, s, in, u, sorted, n_unique, rank, cnt, missing);
+  H2_LAUNCH("k_lk_rank", k_lk_rank, ceil_div_u32(u, 1024), 1024, 0, s, in, u, sorted, n_unique, cnt, missing);
   int rc = scan_u32(cnt, start, mu, segsum, s);
   if (rc) return rc;
   H2_LAUNCH("k_lk_leftover", k_lk_leftover, ceil_div_u32(n_unique, 256), 256, 0, s, (const uint32_t*)cnt, (const uint32_t*)d_table_mult, n_unique, left, missing);
@@ -206,12 +219,10 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
   if (!g_lk_event) H2_HIP(hipEventCreateWithFlags(&g_lk_event, hipEventDisableTiming));
   H2_HIP(hipEventRecord(g_lk_event, s));
   g_lk_stream = s;
-  if (not_in_table_out) {  // the crate fails the proof (ConstraintSystemFailure) when an input is not in the table
-    uint32_t m = 0;
-    H2_HIP(hipMemcpyAsync(&m, missing, 4, hipMemcpyDeviceToHost, s));
-    H2_HIP(hipStreamSynchronize(s));
-    *not_in_table_out = m;
-  }
+  uint32_t m = 0;  // the crate fails the proof (ConstraintSystemFailure) when an input is not in the table
+  H2_HIP(hipMemcpyAsync(&m, missing, 4, hipMemcpyDeviceToHost, s));
+  H2_HIP(hipStreamSynchronize(s));
+  *not_in_table_out = m;
   return H2MI_OK;
 }
 

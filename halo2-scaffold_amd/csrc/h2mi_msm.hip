@@ -35,9 +35,11 @@ namespace h2 {
 
 constexpr uint32_t S0_MAX = 128;  // most entries per accumulation chunk (see accum_chunk_len)
 constexpr uint32_t S1 = 8;       // partials per fold task
-constexpr uint32_t FG = 8;       // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
+constexpr uint32_t FG_NARROW = 8;  // workers (lanes or quads) that cooperate on one bucket in k_msm_finish
+constexpr uint32_t FG_WIDE = 2;    // wide windows (2^17 .. 2^19 buckets holding a partial or two each): two lanes per bucket
 constexpr size_t SHIFT_MIN_N = 4096;  // base sets below this never use the dominant-value shift
 constexpr uint32_t HOT_MIN = 64; // a bucket with more folded partials than this gets a whole workgroup (k_msm_finish_hot)
+constexpr uint32_t HOT_MIN_WIDE = 8;  // wide windows: two lanes per bucket, no fold level (the finish reads the accumulation's partials)
 
 // Entries per accumulation chunk (= additions per thread).  The accumulation is resident at two workgroups of
 // 256 threads per CU (the occupancy cap in msm_dev): ACCUM_RESIDENT_CHUNKS chunks run at once, all of the same
@@ -80,6 +82,8 @@ struct Slot {
   uint32_t* toff[2] = {nullptr, nullptr};  // exclusive scans of np (nb+1 entries, last = total)
   uint8_t* part[2] = {nullptr, nullptr};   // XYZZ partial buffers: accumulation output, fold output
   uint8_t* dense = nullptr;                // one XYZZ sum per bucket
+  uint8_t *dense2 = nullptr, *vsum = nullptr;  // wide windows: per segment of 2^seg_log buckets, plain and local weighted sums
+  uint32_t* tseg[2] = {nullptr, nullptr};      // wide windows: segment sums of the two task-count scans
   uint8_t* rc = nullptr;                            // row sums [Nh] then column sums [Nl]
   uint8_t* g = nullptr;                             // weighted partials (<= 32)
   uint64_t* stats = nullptr;                        // [0] = insertions
@@ -101,6 +105,7 @@ struct Bases {
   size_t stride = 0;            // table row length: n + 1 (slot n = the sum of all n bases, see k_msm_pick_shift)
   bool has_sum = false;
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
+  uint32_t seg_log = 0;         // wide windows (c >= 18): nb = 2^(MAT_LOG + seg_log); the bucket matrix stays 2^logNh x 2^logNl = 2^16
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
   uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
@@ -199,6 +204,23 @@ __global__ void __launch_bounds__(256) k_msm_fill_one(fe* out, size_t n) {
 // k_msm_final for what that means for the result.
 constexpr uint32_t P1_TS = 768;       // scalars per partition tile = threads per workgroup
 constexpr uint32_t NBINS_MAX = 512;
+// Wide windows (c = 18 .. 20: 2^17 .. 2^19 buckets; round 3, measured in profiles/r03_msm_sweep.txt).  The first partition
+// level keeps its 512 bins, so a bin holds up to 1024 buckets: 16-bit in-bin keys and a 1024-entry second-level histogram
+// (k_msm_bin_sort_wide).  The bucket-matrix kernels (rowcol / weighted / final) keep their 2^16-bucket matrix: k_msm_seg first
+// folds every run of L = 2^(c-17) consecutive buckets into its plain sum P_s and its local weighted sum V_s, and
+//     sum_b (b + 1) B_b = L sum_s (s + 1) P_s - sum_s V_s,   V_s = sum_j (L - 1 - j) B_(sL+j).
+constexpr uint32_t WIDE_MIN_C = 18, WIDE_MAX_C = 20, MAT_LOG = 16;
+// Wide windows bin a bucket by its LOW nine bits (in-bin key = the rest): the top window of a 254-bit scalar holds only
+// 254 mod c bits (14 at c = 20, 7 at c = 19, 2 at c = 18), so its digits fall into the lowest buckets — with the narrow
+// windows' high-bit binning, into 16 (or one) of the 512 bins, whose workgroups then sort a thirteenth of the MSM alone
+// (measured: k_msm_bin_sort 185 us at c = 20, 1.3 - 1.6 ms at c = 18 / 19, against ~55 us balanced).  The sorted array is
+// therefore in PERMUTED bucket order b' = (b & 511) << lb | b >> 9; accumulation, fold and finish never look at a bucket's
+// number, and k_msm_seg undoes the permutation when it gathers its segments.
+constexpr uint32_t WIDE_BIN_BITS = 9;
+template <bool WIDE>
+__device__ __forceinline__ uint32_t bin_of(uint32_t bucket, uint32_t lb) { return WIDE ? (bucket & ((1u << WIDE_BIN_BITS) - 1)) : (bucket >> lb); }
+template <bool WIDE>
+__device__ __forceinline__ uint32_t key_of(uint32_t bucket, uint32_t mask) { return WIDE ? (bucket >> WIDE_BIN_BITS) : (bucket & mask); }
 constexpr uint32_t P2_THREADS = 512, P2_PER = 16, P2_CH = P2_THREADS * P2_PER;
 
 // Windows: a canonical scalar has 254 bits and the signed recoding can carry one into the top window, so
@@ -273,7 +295,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size
   size_t i = (size_t)blockIdx.x * P1_TS + tid;
   if (i < n + (shift ? 1 : 0)) {
     fe s = msm_scalar(scalars, i, n, shift);
-    for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> lb], 1u); });
+    for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bin_of<(CT >= WIDE_MIN_C)>(bucket, lb)], 1u); });
   }
   __syncthreads();
   if (tid < nbins) cnt_out[(size_t)tid * ntiles + blockIdx.x] = cnt[tid];
@@ -285,7 +307,8 @@ extern __shared__ uint4 h2_msm_smem[];
 template <uint32_t CT>
 __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W,
                                                            uint32_t lb, uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
-                                                           uint8_t* keys_out) {
+                                                           void* keys_out_) {
+  constexpr bool WIDE = CT >= WIDE_MIN_C;  // in-bin keys of up to 10 bits: staged and written as 16-bit values
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
   uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);             // P1_TS * W payloads
   uint16_t* stage_key = reinterpret_cast<uint16_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids
@@ -308,7 +331,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   if (live) {
     s = msm_scalar(scalars, i, n, shift);
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
-      uint32_t r = atomicAdd(&cnt[bucket >> lb], 1u);
+      uint32_t r = atomicAdd(&cnt[bin_of<WIDE>(bucket, lb)], 1u);
       if (CT) {
         ent[w] = bucket | (neg << 31);
         rk[w] = r;
@@ -338,9 +361,9 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
     for (uint32_t w = 0; w < WK; w++)
       if (ent[w] != 0xFFFFFFFFu) {
         const uint32_t bucket = ent[w] & 0x7FFFFFFFu;
-        const uint32_t pos = lstart[bucket >> lb] + rk[w];
+        const uint32_t pos = lstart[bin_of<WIDE>(bucket, lb)] + rk[w];
         stage_val[pos] = (ent[w] & 0x80000000u) | (uint32_t)((size_t)w * n_reg + i);
-        stage_key[pos] = (uint16_t)bucket;
+        stage_key[pos] = (uint16_t)(WIDE ? key_of<true>(bucket, mask) : bucket);
       }
   } else if (live) {
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
@@ -356,11 +379,27 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   if (tid < NBINS_MAX) cnt[tid] = gb - lstart[tid];
   __syncthreads();
   const uint32_t total = lstart[NBINS_MAX];
-  for (uint32_t p = tid; p < total; p += P1_TS) {
-    const uint32_t key = stage_key[p];
-    const uint32_t dst = p + cnt[key >> lb];
-    vals_out[dst] = stage_val[p];
-    keys_out[dst] = (uint8_t)(key & mask);
+  if (WIDE) {  // the staged key no longer names the bin: it is the one whose run [lstart[b], lstart[b+1]) holds slot p
+    uint16_t* keys_out = reinterpret_cast<uint16_t*>(keys_out_);
+    for (uint32_t p = tid; p < total; p += P1_TS) {
+      uint32_t lo = 0, hi = NBINS_MAX;  // invariant: lstart[lo] <= p < lstart[hi]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (lstart[mid] <= p) lo = mid;
+        else hi = mid;
+      }
+      const uint32_t dst = p + cnt[lo];
+      vals_out[dst] = stage_val[p];
+      keys_out[dst] = stage_key[p];
+    }
+  } else {
+    uint8_t* keys_out = reinterpret_cast<uint8_t*>(keys_out_);
+    for (uint32_t p = tid; p < total; p += P1_TS) {
+      const uint32_t key = stage_key[p];
+      const uint32_t dst = p + cnt[key >> lb];
+      vals_out[dst] = stage_val[p];
+      keys_out[dst] = (uint8_t)(key & mask);
+    }
   }
 }
 
@@ -465,6 +504,108 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
   }
 }
 
+// k_msm_bin_sort for wide windows: up to NQW = 1024 buckets per bin, 16-bit keys, one shared histogram (1024 counters
+// see little contention), two counters per thread in the scans, chunks of 6144 payloads staged in LDS (52 KB in all).
+constexpr uint32_t NQW = 1024, P2W_PER = 12, P2W_CH = P2_THREADS * P2W_PER;
+__device__ __forceinline__ void block_excl_scan_1024(const uint32_t* in, uint32_t* out, uint32_t* wtot /* P2_THREADS / 64 */) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t a = in[2 * tid], b = in[2 * tid + 1];
+  const uint32_t inc = wave_incl_scan(a + b);
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  uint32_t add = 0;
+  for (uint32_t w = 0; w < wave; w++) add += wtot[w];
+  const uint32_t ex = add + inc - (a + b);
+  __syncthreads();  // wtot is reused by the next scan
+  out[2 * tid] = ex;
+  out[2 * tid + 1] = ex + a;
+}
+__global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort_wide(const uint16_t* keys_in, const uint32_t* vals_in, const uint32_t* base,
+                                                                  uint32_t ntiles, uint32_t nbins, uint32_t lb, uint32_t s0_fixed, uint32_t nb,
+                                                                  uint32_t* vals_out, uint32_t* off, uint32_t* np0, uint32_t* np1, uint32_t* s0_out) {
+  __shared__ uint32_t hist[NQW], run[NQW], ccnt[NQW], cstart[NQW], wtot[P2_THREADS / 64];
+  __shared__ uint32_t stage[P2W_CH];
+  __shared__ uint16_t stage_q[P2W_CH];
+  const uint32_t tid = threadIdx.x, bin = blockIdx.x;
+  const uint32_t start = base[(size_t)bin * ntiles], end = base[(size_t)(bin + 1) * ntiles];
+  const uint32_t nq = 1u << lb;
+  const uint32_t entries = base[(size_t)nbins * ntiles];
+  const uint32_t s0 = s0_fixed ? s0_fixed : accum_chunk_len(entries);
+  for (uint32_t j = tid; j < NQW; j += P2_THREADS) {
+    hist[j] = 0;
+    ccnt[j] = 0;
+  }
+  __syncthreads();
+  // 8 keys per load; the buffer is padded so that the aligned window may overhang [start, end)
+  for (uint32_t j = (start & ~7u) + tid * 8; j < end; j += P2_THREADS * 8) {
+    const uint4 kk = *reinterpret_cast<const uint4*>(keys_in + j);
+    const uint32_t w4[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) {
+      const uint32_t idx = j + t;
+      if (idx >= start && idx < end) atomicAdd(&hist[(w4[t >> 1] >> (16 * (t & 1))) & (NQW - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  block_excl_scan_1024(hist, cstart, wtot);
+  __syncthreads();
+  for (uint32_t q = tid; q < NQW; q += P2_THREADS) {
+    const uint32_t ex = cstart[q], tot = hist[q];
+    run[q] = start + ex;
+    if (q < nq) {
+      const uint32_t b = (bin << lb) + q;
+      const uint32_t o = start + ex;
+      off[b] = o;
+      const uint32_t f0 = tot ? 1u + (o + tot - 1) / s0 - o / s0 : 0u;
+      np0[b] = f0;
+      np1[b] = (f0 + S1 - 1) / S1;
+    }
+  }
+  if (bin == 0 && tid == 0) {
+    off[nb] = entries;
+    np0[nb] = 0;
+    np1[nb] = 0;
+    *s0_out = s0;
+  }
+  __syncthreads();
+  for (uint32_t cs = start; cs < end; cs += P2W_CH) {
+    const uint32_t m = min(P2W_CH, end - cs);
+    uint32_t q[P2W_PER], v[P2W_PER], r[P2W_PER];
+#pragma unroll
+    for (uint32_t k = 0; k < P2W_PER; k++) {
+      const uint32_t p = k * P2_THREADS + tid;
+      if (p < m) {
+        q[k] = keys_in[cs + p] & (NQW - 1);
+        v[k] = vals_in[cs + p];
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < P2W_PER; k++)
+      if (k * P2_THREADS + tid < m) r[k] = atomicAdd(&ccnt[q[k]], 1u);
+    __syncthreads();
+    block_excl_scan_1024(ccnt, cstart, wtot);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < P2W_PER; k++)
+      if (k * P2_THREADS + tid < m) {
+        const uint32_t pos = cstart[q[k]] + r[k];
+        stage[pos] = v[k];
+        stage_q[pos] = (uint16_t)q[k];
+      }
+    __syncthreads();
+    for (uint32_t p = tid; p < m; p += P2_THREADS) {
+      const uint32_t qq = stage_q[p];
+      vals_out[run[qq] + (p - cstart[qq])] = stage[p];
+    }
+    __syncthreads();
+    for (uint32_t qi = tid; qi < NQW; qi += P2_THREADS) {
+      run[qi] += ccnt[qi];
+      ccnt[qi] = 0;
+    }
+    __syncthreads();
+  }
+}
+
 // Partial bucket sums travel between the MSM kernels as raw xyzz29 values (4 x 9 normalized limbs =
 // 144 B, Montgomery-2^261, loosely reduced): no conversion until the final result.
 constexpr uint32_t PART_BYTES = 144;
@@ -561,6 +702,12 @@ struct TailDesc {
   uint8_t *part1, *dense, *rc, *g, *out;
   uint64_t* stats;
   uint32_t nb, logNh, logNl, canonical;
+  // wide windows: dense holds nb = 2^(MAT_LOG + seg_log) buckets; k_msm_seg leaves the segment sums in mat (what rowcol
+  // reads; = dense when seg_log = 0) and the segments' local weighted sums in vsum
+  const uint8_t* mat;
+  uint8_t *dense2, *vsum;
+  uint32_t seg_log;
+  uint32_t hot_min;  // a bucket with more partials than this is finished by a whole workgroup (k_msm_finish_hot)
 };
 struct TailBatch {
   TailDesc d[TAIL_BATCH];
@@ -577,6 +724,7 @@ constexpr uint32_t TAIL_THREADS = 512;  // rowcol / weighted: 128 quads reduce u
 template <bool QUAD>
 __global__ void __launch_bounds__(256) k_msm_fold(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
+  if (d.seg_log) return;  // wide windows skip the fold level (tail_desc)
   const uint32_t nb = d.nb;
   const uint32_t *toff_out = d.toff1, *toff_in = d.toff0, *np_in = d.np0;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
@@ -610,7 +758,7 @@ __device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta
   }
   return r;
 }
-template <bool QUAD>
+template <bool QUAD, uint32_t FG>
 __global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   const uint32_t nb = d.nb;
@@ -622,7 +770,7 @@ __global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
   bool hot = false;
   if (b < nb) {
     uint32_t cnt = d.np1[b], s = d.toff1[b];
-    hot = cnt > HOT_MIN;  // left to k_msm_finish_hot (8 workers would each chain cnt / 8 additions)
+    hot = cnt > d.hot_min;  // left to k_msm_finish_hot (FG workers would each chain cnt / FG additions)
     if (hot) cnt = 0;
     for (uint32_t k = l; k < cnt; k += FG) {
       xyzz29 p = part_load(d.part1 + (size_t)(s + k) * PART_BYTES);
@@ -662,7 +810,7 @@ __global__ void __launch_bounds__(256) k_msm_finish_hot(const TailBatch tb) {
   const uint32_t b = blockIdx.x * 256 + tid;
   if (tid == 0) nhot = 0;
   __syncthreads();
-  if (b < d.nb && d.np1[b] > HOT_MIN) hot_list[atomicAdd(&nhot, 1u)] = b;
+  if (b < d.nb && d.np1[b] > d.hot_min) hot_list[atomicAdd(&nhot, 1u)] = b;
   __syncthreads();
   const uint32_t n_hot = nhot;
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
@@ -679,19 +827,44 @@ __global__ void __launch_bounds__(256) k_msm_finish_hot(const TailBatch tb) {
   }
 }
 
-// bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums
+// wide windows: segment s = buckets [sL, (s+1)L), L = 2^seg_log <= 8: P_s = their sum, V_s = sum_j (L - 1 - j) B_(sL+j) by a
+// running sum (V += T; T += B_j) — 2 (L - 1) dependent additions, one QUAD per segment (a lane per segment took 113 us at
+// c = 20: the chain's latency, not its throughput, is what a join waits for).  Bucket b sits at the permuted position
+// (b & 511) << lb | b >> 9 of the dense array (see WIDE_BIN_BITS).
+__global__ void __launch_bounds__(256) k_msm_seg(const TailBatch tb) {
+  const TailDesc& d = tb.d[blockIdx.y];
+  if (!d.seg_log) return;
+  const uint32_t L = 1u << d.seg_log, s = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (s >= (d.nb >> d.seg_log)) return;  // whole quads: the bound is a multiple of 64
+  const uint32_t lb = MAT_LOG + d.seg_log - WIDE_BIN_BITS;  // log2(buckets per bin)
+  xyzz29 T = xyzz29_identity(), V = xyzz29_identity();
+  for (uint32_t j = 0; j < L; j++) {
+    const uint32_t b = s * L + j, bp = ((b & ((1u << WIDE_BIN_BITS) - 1)) << lb) | (b >> WIDE_BIN_BITS);
+    V = xyzz29_add_quad(V, T);
+    T = xyzz29_add_quad(T, part_load(d.dense + (size_t)bp * PART_BYTES));
+  }
+  if ((threadIdx.x & 3u) == 0) {
+    part_store(d.dense2 + (size_t)s * PART_BYTES, T);
+    part_store(d.vsum + (size_t)s * PART_BYTES, V);
+  }
+}
+
+// bucket matrix B[hi][lo] (b = hi*Nl + lo): blocks 0..Nh-1 produce row sums, blocks Nh..Nh+Nl-1 column sums;
+// wide windows: blocks Nh+Nl .. 2Nh+Nl-1 the row sums of the segments' local weighted sums (vsum)
 __global__ void __launch_bounds__(TAIL_THREADS) k_msm_rowcol(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t logNl = d.logNl, Nh = 1u << d.logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
-  if (blk >= Nh + Nl) return;
+  if (blk >= Nh + Nl + (d.seg_log ? Nh : 0u)) return;
   if (tid < 256) {
     xyzz29 v = xyzz29_identity();
     if (blk < Nh) {
-      if (tid < Nl) v = part_load(d.dense + (size_t)((blk << logNl) + tid) * PART_BYTES);
+      if (tid < Nl) v = part_load(d.mat + (size_t)((blk << logNl) + tid) * PART_BYTES);
+    } else if (blk < Nh + Nl) {
+      if (tid < Nh) v = part_load(d.mat + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
     } else {
-      if (tid < Nh) v = part_load(d.dense + (size_t)((tid << logNl) + (blk - Nh)) * PART_BYTES);
+      if (tid < Nl) v = part_load(d.vsum + (size_t)(((blk - Nh - Nl) << logNl) + tid) * PART_BYTES);
     }
     lds[tid] = v;
   }
@@ -707,14 +880,17 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_msm_weighted(const TailBatch t
   xyzz29* lds = reinterpret_cast<xyzz29*>(h2_msm_smem);
   const uint32_t logNh = d.logNh, logNl = d.logNl, Nh = 1u << logNh, Nl = 1u << logNl;
   const uint32_t tid = threadIdx.x, blk = blockIdx.x;
-  if (blk >= logNh + logNl + 1) return;
+  const uint32_t terms = logNh + logNl + 1;
+  if (blk >= terms + (d.seg_log ? 1u : 0u)) return;
   if (tid < 256) {
     xyzz29 v = xyzz29_identity();
     if (blk < logNh) {
       if (tid < Nh && ((tid >> blk) & 1u)) v = part_load(d.rc + (size_t)tid * PART_BYTES);
-    } else {
+    } else if (blk < terms) {
       uint32_t beta = blk - logNh;
       if (tid < Nl && (((tid + 1) >> beta) & 1u)) v = part_load(d.rc + (size_t)(Nh + tid) * PART_BYTES);
+    } else {  // wide windows: the plain sum of the local weighted sums' row sums
+      if (tid < Nh) v = part_load(d.rc + (size_t)(Nh + Nl + tid) * PART_BYTES);
     }
     lds[tid] = v;
   }
@@ -745,6 +921,17 @@ __global__ void __launch_bounds__(128) k_msm_final(const TailBatch tb) {
   if ((tid & 3u) == 0) lds[quad] = v;
   __syncthreads();
   block_tree_sum(lds, 32);
+  if (d.seg_log) {  // wide windows: L * (matrix result) - sum of the segments' local weighted sums
+    if (quad == 0) {
+      xyzz29 r = lds[0];
+      for (uint32_t k = 0; k < d.seg_log; k++) r = xyzz29_dbl_quad(r);
+      xyzz29 y = part_load(d.g + (size_t)terms * PART_BYTES);
+      y.y = f29_normalize(f29_sub(f29_zero(), y.y, Fq29::K4));  // -Y as 4p - Y (Y < 4p)
+      r = xyzz29_add_quad(r, y);
+      if (tid == 0) lds[0] = r;
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     xyzz29 r = lds[0];
     jac j;
@@ -799,7 +986,7 @@ static uint32_t pick_window(size_t n) {
   const char* ev = getenv("H2MI_MSM_C");
   if (ev) {
     int c = atoi(ev);
-    if (c >= 11 && c <= 17) return (uint32_t)c;  // below 11 the scatter tile (1024 x W pairs) outgrows LDS
+    if (c >= 11 && c <= (int)WIDE_MAX_C) return (uint32_t)c;  // below 11 the scatter tile (1024 x W pairs) outgrows LDS
   }
   uint32_t lg = 0;
   while (((size_t)1 << lg) < n) lg++;
@@ -809,10 +996,15 @@ static uint32_t pick_window(size_t n) {
   // c = 17 (15 windows, the widest the bucket-matrix kernels take): 6 % fewer additions for twice the buckets to
   // reduce.  Re-measured at the end of round 2 inside whole proofs (the reductions are cheaper than when this table was
   // first drawn up): create_proof 2^20 -1..2 % (the replay step unchanged), 2^21 -5 %, 2^22 -3 % — the default from 2^21.
+  // Round 3: wide windows (18 .. 20 bits: 2^17 .. 2^19 buckets) measured — profiles/r03_msm_sweep.txt.  c = 18 leaves a 2-bit top
+  // window (four buckets take a fifteenth of the MSM: 2x slower); c = 19 / 20 cut the accumulation by 10 - 15 % at every size,
+  // but their bucket reduction is throughput-bound (2^19 buckets x ~3 additions: fold, finish, segment sums) and costs more
+  // than the accumulation saves at 2^20 (replay step 20.0 -> 21.4 ms, create_proof 14.1 -> 14.8 ms) and breaks even at 2^21; from
+  // 2^22 (104 entries per bucket) c = 20 wins: accumulation 5.04 -> 4.39 ms, range proof at DEGREE 22 73.7 -> 72.3 ms.
   // Smaller sizes, same sweep (`tools/msm_sweep.py`, back-to-back / latency in us): 2^17: c = 13: 307 / 517, 15: 287 / 494,
   // 16: 286 / 476; 2^18: 15: 475 / 706, 16: 458 / 666; 2^19: 15: 832 / 1112, 16: 809 / 1058; 2^15: 13: 180 / 334, 16: 164 /
   // 324; 2^14: 13: 149 / 296, 15: 135 / 282, 16: 153 / 309; 2^10: 13 is best.  (c = 14 leaves a 3-bit top window: 50 % slower.)
-  int c = lg >= 21 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
+  int c = lg >= 22 ? 20 : lg >= 21 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
   return (uint32_t)c;
 }
 
@@ -830,7 +1022,7 @@ static void free_bases(Bases* B) {
     hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.binseg);
     hipFree(S.off); hipFree(S.s0_dev);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
-    hipFree(S.dense);
+    hipFree(S.dense); hipFree(S.dense2); hipFree(S.vsum); hipFree(S.tseg[0]); hipFree(S.tseg[1]);
     hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats); hipFree(S.shift);
     if (S.input_ready) hipEventDestroy(S.input_ready);
     if (S.head_done) hipEventDestroy(S.head_done);
@@ -861,8 +1053,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   B->c = pick_window(n);
   B->W = (255 + B->c - 1) / B->c;
   B->nb = 1u << (B->c - 1);
-  B->logNl = (B->c - 1 + 1) / 2;
-  B->logNh = (B->c - 1) - B->logNl;
+  B->seg_log = B->c - 1 > MAT_LOG ? B->c - 1 - MAT_LOG : 0;
+  B->logNl = (B->c - 1 - B->seg_log + 1) / 2;
+  B->logNh = (B->c - 1 - B->seg_log) - B->logNl;
   if ((uint64_t)B->stride * B->W >= (1ull << 31)) { delete B; return H2MI_ERANGE; }
   const size_t nW = B->stride * B->W;
   // partial sums of one accumulation: one per chunk (at most whole rounds of the resident grid) + one per bucket
@@ -876,10 +1069,10 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   if (bin_cells >= ((size_t)1 << 31)) { free_bases(B); return H2MI_ERANGE; }
   // the own scans (k_scan_seg) take 16-byte vectors: the [bin][tile] matrix has 512 rows and the task arrays
   // 2^(c-1) >= 1024 entries for every window width pick_window() can return
-  if ((B->nbins & 3u) || B->nb < 4 || B->nb > SCAN_SEG_TASKS) { free_bases(B); return H2MI_ERANGE; }
+  if ((B->nbins & 3u) || B->nb < 4 || (B->nb > SCAN_SEG_TASKS && !B->seg_log) || B->nbins > NBINS_MAX || (1u << B->lb) > NQW) { free_bases(B); return H2MI_ERANGE; }
   for (Slot& S : B->slot) {
     for (int i = 0; i < 2; i++) H2_ALLOC(S.vals[i], nW * 4);
-    H2_ALLOC(S.bkeys, nW + 16);
+    H2_ALLOC(S.bkeys, nW * (B->seg_log ? 2 : 1) + 16);
     H2_ALLOC(S.bincnt, bin_cells * 4);
     H2_ALLOC(S.binbase, bin_cells * 4);
     H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
@@ -890,9 +1083,14 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
       H2_ALLOC(S.toff[i], (size_t)(B->nb + 1) * 4);
     }
     H2_ALLOC(S.dense, (size_t)B->nb * PART_BYTES);
+    if (B->seg_log) {
+      H2_ALLOC(S.dense2, ((size_t)1 << MAT_LOG) * PART_BYTES);
+      H2_ALLOC(S.vsum, ((size_t)1 << MAT_LOG) * PART_BYTES);
+      for (int i = 0; i < 2; i++) H2_ALLOC(S.tseg[i], (size_t)(B->nb / SCAN_SEG_BINS + 2) * 4);
+    }
     H2_ALLOC(S.part[0], (size_t)B->max_tasks0 * PART_BYTES);
     H2_ALLOC(S.part[1], (size_t)B->max_tasks1 * PART_BYTES);
-    H2_ALLOC(S.rc, (size_t)((1u << B->logNh) + (1u << B->logNl)) * PART_BYTES);
+    H2_ALLOC(S.rc, (size_t)((2u << B->logNh) + (1u << B->logNl)) * PART_BYTES);  // row, column (and wide: vsum row) sums
     H2_ALLOC(S.g, (size_t)64 * PART_BYTES);
     H2_ALLOC(S.stats, 64);
     H2_ALLOC(S.shift, 32);
@@ -987,7 +1185,7 @@ static int fold_sharded(hipStream_t s0);
 static std::vector<Deferred> g_deferred;
 static int flush_tails();
 static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
-                        hipStream_t t);
+                        uint32_t max_seg, hipStream_t t);
 static TailDesc tail_desc(const Bases* B, const Slot& S);
 
 // One MSM.  On the library's own stream the call is split over internal streams and only queues the
@@ -1045,6 +1243,9 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<18>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   {
@@ -1061,6 +1262,9 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 15: H2_BIN_COUNT(15); break;
       case 16: H2_BIN_COUNT(16); break;
       case 17: H2_BIN_COUNT(17); break;
+      case 18: H2_BIN_COUNT(18); break;
+      case 19: H2_BIN_COUNT(19); break;
+      case 20: H2_BIN_COUNT(20); break;
       default: H2_BIN_COUNT(0); break;
     }
     const uint32_t cells = B->nbins * ntiles;  // a multiple of 4 (checked at registration)
@@ -1073,6 +1277,9 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
       case 15: H2_BIN_SCATTER(15); break;
       case 16: H2_BIN_SCATTER(16); break;
       case 17: H2_BIN_SCATTER(17); break;
+      case 18: H2_BIN_SCATTER(18); break;
+      case 19: H2_BIN_SCATTER(19); break;
+      case 20: H2_BIN_SCATTER(20); break;
       default: H2_BIN_SCATTER(0); break;
     }
 #undef H2_BIN_COUNT
@@ -1089,10 +1296,21 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.tail_pending = false;
   S.accum_pending = false;
   S.head_pending = false;
-  H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
-            (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0_fixed, nb, S.vals[1], S.off, S.np[0], S.np[1], S.s0_dev);
-  H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
-            (const uint32_t*)nullptr);
+  if (B->seg_log) {
+    H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort_wide, B->nbins, P2_THREADS, 0, hs, (const uint16_t*)S.bkeys, (const uint32_t*)S.vals[0],
+              (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0_fixed, nb, S.vals[1], S.off, S.np[0], S.np[1], S.s0_dev);
+    const uint32_t tsegs = ceil_div_u32(nb, SCAN_SEG_BINS);  // nb > 65536 task counters: segmented, one array per launch
+    for (int i = 0; i < 2; i++) {
+      H2_LAUNCH("k_scan_segsum", k_scan_segsum<SCAN_SEG_BINS>, tsegs, 1024, 0, hs, (const uint32_t*)S.np[i], nb, S.tseg[i]);
+      H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_BINS>, dim3(tsegs, 1), 1024, 0, hs, (const uint32_t*)S.np[i], S.toff[i], (const uint32_t*)nullptr,
+                (uint32_t*)nullptr, nb, (const uint32_t*)S.tseg[i]);
+    }
+  } else {
+    H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort, B->nbins, P2_THREADS, 0, hs, (const uint8_t*)S.bkeys, (const uint32_t*)S.vals[0],
+              (const uint32_t*)S.binbase, ntiles, B->nbins, B->lb, s0_fixed, nb, S.vals[1], S.off, S.np[0], S.np[1], S.s0_dev);
+    H2_LAUNCH("k_scan_seg_tasks", k_scan_seg<SCAN_SEG_TASKS>, dim3(1, 2), 1024, 0, hs, (const uint32_t*)S.np[0], S.toff[0], (const uint32_t*)S.np[1], S.toff[1], nb,
+              (const uint32_t*)nullptr);
+  }
   // upper bound of the chunks (zero digits leave no entry): whole rounds of the resident grid, or total / override
   // (a chunk holds at least one entry: small base sets never come near a whole round)
   const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : std::min(accum_rounds(total) * ACCUM_RESIDENT_CHUNKS, total);
@@ -1126,7 +1344,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   }
   TailBatch tb;
   for (uint32_t j = 0; j < TAIL_BATCH; j++) tb.d[j] = tail_desc(B, S);
-  int rc = launch_tails(tb, 1, S.tasks1, nb, B->logNh, B->logNl, s);
+  int rc = launch_tails(tb, 1, S.tasks1, nb, B->logNh, B->logNl, B->seg_log, s);
   if (rc) return rc;
   H2_HIP(hipEventRecord(S.tail_done, s));
   S.tail_pending = true;
@@ -1139,22 +1357,29 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
 // the uniform case at k = 20, <= ~50 for the hot 0/1 buckets of witness-like columns (7 serial additions
 // per lane), n / (s0 * S1) if every scalar is the same (slow but correct).  Then the weighted bucket sum.
 static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
-                        hipStream_t t) {
+                        uint32_t max_seg, hipStream_t t) {
   // fold / finish: quads (4 lanes per point operation) while the grid stays latency-bound, single lanes beyond
   const bool force_lane = getenv("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
-  if (!force_lane && (uint64_t)max_tasks1 * count <= 65536) {
+  bool all_wide = max_seg != 0;
+  for (uint32_t j = 0; j < count; j++) all_wide = all_wide && tb.d[j].seg_log != 0;
+  if (all_wide) {
+    // no fold level at all
+  } else if (!force_lane && (uint64_t)max_tasks1 * count <= 65536) {
     H2_LAUNCH("k_msm_fold", k_msm_fold<true>, dim3(ceil_div_u32((uint64_t)max_tasks1 * 4, 256), count), 256, 0, t, tb);
   } else {
     H2_LAUNCH("k_msm_fold", k_msm_fold<false>, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
   }
-  if (!force_lane && (uint64_t)max_nb * FG * count <= 65536) {
-    H2_LAUNCH("k_msm_finish", k_msm_finish<true>, dim3(ceil_div_u32((uint64_t)max_nb * FG * 4, 256), count), 256, 0, t, tb);
+  if (max_seg) {
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_WIDE>), dim3(ceil_div_u32((uint64_t)max_nb * FG_WIDE, 256), count), 256, 0, t, tb);
+  } else if (!force_lane && (uint64_t)max_nb * FG_NARROW * count <= 65536) {
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<true, FG_NARROW>), dim3(ceil_div_u32((uint64_t)max_nb * FG_NARROW * 4, 256), count), 256, 0, t, tb);
   } else {
-    H2_LAUNCH("k_msm_finish", k_msm_finish<false>, dim3(ceil_div_u32((uint64_t)max_nb * FG, 256), count), 256, 0, t, tb);
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_NARROW>), dim3(ceil_div_u32((uint64_t)max_nb * FG_NARROW, 256), count), 256, 0, t, tb);
   }
   H2_LAUNCH("k_msm_hot_finish", k_msm_finish_hot, dim3(ceil_div_u32(max_nb, 256), count), 256, 64 * PART_BYTES, t, tb);
-  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3((1u << max_logNh) + (1u << max_logNl), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
-  H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1, count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
+  if (max_seg) H2_LAUNCH("k_msm_seg", k_msm_seg, dim3((4u << MAT_LOG) / 256, count), 256, 0, t, tb);
+  H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3(((max_seg ? 2u : 1u) << max_logNh) + (1u << max_logNl), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
+  H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1 + (max_seg ? 1 : 0), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
   H2_LAUNCH("k_msm_final", k_msm_final, count, 128, 32 * PART_BYTES, t, tb);
   return H2MI_OK;
 }
@@ -1166,6 +1391,13 @@ static TailDesc tail_desc(const Bases* B, const Slot& S) {
   d.part1 = S.part[1]; d.dense = S.dense; d.rc = S.rc; d.g = S.g; d.out = (uint8_t*)S.d_out;
   d.stats = S.stats;
   d.nb = B->nb; d.logNh = B->logNh; d.logNl = B->logNl; d.canonical = g_canonical ? 1u : 0u;
+  d.seg_log = B->seg_log; d.dense2 = S.dense2; d.vsum = S.vsum; d.mat = B->seg_log ? S.dense2 : S.dense;
+  d.hot_min = B->seg_log ? HOT_MIN_WIDE : HOT_MIN;
+  if (B->seg_log) {
+    // 2^17 .. 2^19 buckets hold a partial or two each: the fold level would copy them (0.08 - 0.18 ms per MSM, measured);
+    // the finish kernels read the accumulation's partials directly
+    d.part1 = S.part[0]; d.toff1 = S.toff[0]; d.np1 = S.np[0];
+  }
   return d;
 }
 
@@ -1185,7 +1417,7 @@ static int flush_tails() {
     size_t i = 0;
     while (i < mine.size()) {
       TailBatch tb;
-      uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0;
+      uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0, max_seg = 0;
       const size_t first = i;
       for (; i < mine.size() && count < TAIL_BATCH; i++, count++) {
         Bases* B = mine[i].B;
@@ -1196,9 +1428,10 @@ static int flush_tails() {
         max_nb = std::max(max_nb, B->nb);
         max_logNh = std::max(max_logNh, B->logNh);
         max_logNl = std::max(max_logNl, B->logNl);
+        max_seg = std::max(max_seg, B->seg_log);
       }
       for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
-      int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, t);
+      int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, max_seg, t);
       if (rc) return rc;
       for (size_t j = first; j < i; j++) {
         Slot& S = *mine[j].S;
@@ -1329,7 +1562,11 @@ static int msm_sharded(Sharded* sh, const void* scalars, bool on_host, size_t n,
     const size_t cnt = n > sd.lo ? std::min(n, sd.hi) - sd.lo : 0;
     uint8_t* out = sd.part + (size_t)ring * 96;
     if (cnt == 0) {
+      // nothing of this MSM falls into the shard: its partial result is the identity.  msm_join_all only waits for the
+      // reductions of slots that ran an MSM, so the primary stream is ordered behind this write explicitly
       H2_HIP(hipMemcpyAsync(out, G1_IDENTITY_J, 96, hipMemcpyHostToDevice, si));
+      H2_HIP(hipEventRecord(sd.ready, si));
+      H2_HIP(hipStreamWaitEvent(s0, sd.ready, 0));
       continue;
     }
     const uint8_t* src = (const uint8_t*)scalars + sd.lo * 32;
@@ -1360,6 +1597,19 @@ static int msm_sharded(Sharded* sh, const void* scalars, bool on_host, size_t n,
   if (rc2) return rc2;
   g_pending_folds.push_back({sh, ring, d_out});
   return H2MI_OK;
+}
+
+// h2mi_shutdown: every registration (plain, sharded, ad hoc) belongs to the devices that are being torn down
+void msm_teardown() {
+  g_deferred.clear();
+  g_pending_folds.clear();
+  for (auto& kv : g_sharded) free_sharded(kv.second);
+  g_sharded.clear();
+  for (auto& kv : g_bases) {
+    if (use_device(kv.second->dev) == H2MI_OK) free_bases(kv.second);
+  }
+  g_bases.clear();
+  g_adhoc.clear();
 }
 
 // make stream `s` wait for every outstanding MSM (device-side join, no host synchronisation)
@@ -1656,7 +1906,9 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   if (reduce_adds) {
     // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))
     uint64_t Nh = 1ull << B->logNh, Nl = 1ull << B->logNl;
-    *reduce_adds = 2ull * B->nb + (B->logNh * Nh + (B->logNl + 1) * Nl) / 2 + (B->logNh + B->logNl + 1) * (uint64_t)(B->c);
+    const uint64_t mat = (uint64_t)B->nb >> B->seg_log;  // wide windows: 2 (L - 1) additions per segment of L buckets first
+    *reduce_adds = (B->seg_log ? 2ull * (B->nb - mat) + mat : 0ull) + 2ull * mat + (B->logNh * Nh + (B->logNl + 1) * Nl) / 2 +
+                   (B->logNh + B->logNl + 1) * (uint64_t)(B->c);
   }
   return H2MI_OK;
 }

@@ -229,10 +229,16 @@ __device__ __forceinline__ f29 powtab(const fe* lo, const fe* hi, uint32_t h, ui
 
 extern __shared__ uint32_t h2_smem[];
 
+// Compile-time geometry (round 3; tools/ntt_isa_budget.py): DS = elements per tile (limb-plane stride of the LDS image), M =
+// log2 of the DFT size.  With both known the nine plane offsets l * DS * 4 of every LDS get / put and the eight of every staged-
+// twiddle get become immediate offsets of the ds instructions instead of nine / eight v_add each — 16 of the 32 VALU
+// instructions of a get + put pair, ~6 % of a pass — and the round's strides and shifts become constants.  DS = M = 0: the
+// run-time form (small or non-default tiles).
 // non-final pass: column DFTs inside segments, in-place layout
+template <uint32_t DS, uint32_t M>
 __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
-  const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  const uint32_t dstride = C << m;
+  const uint32_t m = M ? M : p.m, logC = (DS && M) ? (uint32_t)(__builtin_ctz(DS ? DS : 1u) - M) : p.logC, C = 1u << logC;
+  const uint32_t dstride = DS ? DS : (C << m);
   uint32_t* lds = h2_smem;
   uint32_t* tw = lds + 9 * dstride;  // 8 word planes of packed twiddles: keeps a 2^10 tile at 52 KiB = 3 blocks/CU
   const uint32_t T = blockDim.x, tid = threadIdx.x;
@@ -259,14 +265,20 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
     f29 x = lds_get(lds, dstride, (c << m) | k);
     uint32_t ex = ((jl0 + c) * k) << sh;  // < n
     x = f29_mul<F9>(x, powtab(p.tlo, p.thi, p.h, p.tfull, ex));
-    pack_store(&p.out[base + ((size_t)k << logS) + jl0 + c], x);
+    // the product is normalized and below 1.2 p (< 2^255): stored as it is, without the canonical reduction — the next pass
+    // reads it as a loosely reduced input (its lazy rounds then stay below 34 p of the 169 p capacity; the LAST pass alone
+    // returns canonical values)
+    fe o_;
+    f29_pack(x, o_.v);
+    fe_store(&p.out[base + ((size_t)k << logS) + jl0 + c], o_);
   }
 }
 
 // final pass: row DFTs, digit-reversed scatter
+template <uint32_t DS, uint32_t M>
 __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
-  const uint32_t m = p.m, logC = p.logC, C = 1u << logC;
-  const uint32_t dstride = C << m;
+  const uint32_t m = M ? M : p.m, logC = (DS && M) ? (uint32_t)(__builtin_ctz(DS ? DS : 1u) - M) : p.logC, C = 1u << logC;
+  const uint32_t dstride = DS ? DS : (C << m);
   uint32_t* lds = h2_smem;
   uint32_t* tw = lds + 9 * dstride;
   const uint32_t T = blockDim.x, tid = threadIdx.x;
@@ -855,8 +867,8 @@ struct RangeCosets {
 // terms (level-0 expressions: -2); 2 the l_last term (level 1: -3); 3 .. the chain terms (l_0); then one term per
 // permutation set (expression level = columns in the set: -2 - columns); then the lookup's five: l_0 (-2), l_last (-3),
 // the product rule (level 2: -4), l_0 (-2), the ordering rule (level 1: -3).
-__global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h, const fe* xlo,
-                                                           const fe* xhi, uint32_t xh, fe* out) {
+__device__ __forceinline__ void evaluate_h_range_body(const RangeCosets& c, uint32_t ext_k, uint32_t k, uint32_t last_rot, const HConsts& h,
+                                                      const fe* xlo, const fe* xhi, uint32_t xh, fe* out) {
   const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= size) return;
@@ -910,6 +922,18 @@ __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_
   acc = f29_add(acc, hmul(sl, load_unpack(&c.l_last[idx])));
   acc = f29_add(acc, hmul(f29_normalize(sa), load_unpack(&c.l_active[idx])));
   hstore(&out[idx], acc, h.tinv[idx & (rot - 1)]);
+}
+// two register budgets of the same body (round 3): unconstrained it takes 169 VGPRs (two wavefronts per
+// SIMD); held to 128 (four wavefronts) it spills 40 dwords to scratch.  Measured inside the range proof at DEGREE 22 on one
+// box, alternating: 74.8 / 75.1 ms unconstrained, 75.1 / 75.3 ms at 128 VGPRs — the kernel streams 2^24 rows at ~40 % of HBM and
+// the spills cost what the occupancy buys.  The unconstrained form stays the default; H2MI_EVALH_OCC=4 selects the other.
+__global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h, const fe* xlo,
+                                                           const fe* xhi, uint32_t xh, fe* out) {
+  evaluate_h_range_body(c, ext_k, k, last_rot, h, xlo, xhi, xh, out);
+}
+__global__ void __launch_bounds__(256, 4) k_evaluate_h_range_occ4(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h,
+                                                                  const fe* xlo, const fe* xhi, uint32_t xh, fe* out) {
+  evaluate_h_range_body(c, ext_k, k, last_rot, h, xlo, xhi, xh, out);
 }
 
 // the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
@@ -1199,6 +1223,27 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
   return H2MI_OK;
 }
 
+// h2mi_shutdown: plans, power tables and scratch vectors live on the device that is being torn down; a later h2mi_init
+// (possibly of another device) starts from empty caches
+void ntt_teardown() {
+  for (auto& kv : g_plans) free_plan(kv.second);
+  g_plans.clear();
+  for (auto& kv : g_powtabs) {
+    hipFree(kv.second.lo);
+    hipFree(kv.second.hi);
+    kv.second.built.destroy();
+  }
+  g_powtabs.clear();
+  g_powtab_bytes = 0;
+  for (Scratch& c : g_scratch) {
+    if (c.p) hipFree(c.p);
+    if (c.event) hipEventDestroy(c.event);
+    c = Scratch();
+  }
+  g_cur = nullptr;
+  g_tmp = nullptr;
+}
+
 static int ensure_tmp(size_t elems, hipStream_t s) {
   Scratch* e = nullptr;
   for (Scratch& c : g_scratch)
@@ -1273,10 +1318,28 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
   if (nthreads != 64 && nthreads != 128 && nthreads != 256 && nthreads != 512) nthreads = 256;
   static bool attr_set = false;
   if (!attr_set) {  // tiles above 64 KiB of LDS need the opt-in
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_col), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_row), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define H2_NTT_ATTR(DS, M)                                                                                                                         \
+  H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_col<DS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
+  H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_row<DS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    H2_NTT_ATTR(0, 0);
+    H2_NTT_ATTR(1024, 7);
+    H2_NTT_ATTR(1024, 8);
+    H2_NTT_ATTR(1024, 9);
+    H2_NTT_ATTR(1024, 10);
+#undef H2_NTT_ATTR
     attr_set = true;
   }
+  static const bool fixed_geometry = !getenv("H2MI_NTT_RUNTIME_GEOMETRY");  // A/B knob: the run-time kernels everywhere
+// the compile-time form exists for 1024-element tiles and DFT sizes 2^7 .. 2^10 (every pass of every transform >= 2^14)
+#define H2_NTT_LAUNCH(NAME, KERNEL)                                                                                       \
+  do {                                                                                                                    \
+    const bool fixed_ = fixed_geometry && pp.m + pp.logC == 10;                                                           \
+    if (fixed_ && pp.m == 10) H2_LAUNCH(NAME, (KERNEL<1024, 10>), nblocks, nthreads, shmem, s, pp);                        \
+    else if (fixed_ && pp.m == 9) H2_LAUNCH(NAME, (KERNEL<1024, 9>), nblocks, nthreads, shmem, s, pp);                     \
+    else if (fixed_ && pp.m == 8) H2_LAUNCH(NAME, (KERNEL<1024, 8>), nblocks, nthreads, shmem, s, pp);                     \
+    else if (fixed_ && pp.m == 7) H2_LAUNCH(NAME, (KERNEL<1024, 7>), nblocks, nthreads, shmem, s, pp);                     \
+    else H2_LAUNCH(NAME, (KERNEL<0, 0>), nblocks, nthreads, shmem, s, pp);                                                 \
+  } while (0)
   // buffer schedule: P=1: a->a ; P=2: a->tmp, tmp->a ; P=3: a->tmp, tmp->tmp, tmp->a
   uint32_t log_seg = log_n;
   for (int p = 0; p < pl.P; p++) {
@@ -1308,7 +1371,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
       size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + ((size_t)1 << (pp.m - 1)) * 32;
-      H2_LAUNCH("k_ntt_pass_col", k_ntt_pass_col, nblocks, nthreads, shmem, s, pp);
+      H2_NTT_LAUNCH("k_ntt_pass_col", k_ntt_pass_col);
     } else {
       pp.has_post = post ? 1 : 0;
       if (post) pp.post = host_fe(post);
@@ -1326,7 +1389,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
       size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + (pp.m ? ((size_t)1 << (pp.m - 1)) : 1) * 32;
-      H2_LAUNCH("k_ntt_pass_row", k_ntt_pass_row, nblocks, nthreads, shmem, s, pp);
+      H2_NTT_LAUNCH("k_ntt_pass_row", k_ntt_pass_row);
     }
     log_seg -= pp.m;
   }
@@ -1790,8 +1853,14 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
     }
   }
   const uint32_t size = 1u << extended_k;
-  H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
-            (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
+  static const bool occ4 = getenv("H2MI_EVALH_OCC") && atoi(getenv("H2MI_EVALH_OCC")) == 4;
+  if (!occ4) {
+    H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
+              (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
+  } else {
+    H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range_occ4, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
+              (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
+  }
   return H2MI_OK;
 }
 

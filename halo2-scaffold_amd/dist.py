@@ -85,11 +85,22 @@ class PhaseCombiner:
         from ._lib import check, lib
         from .device import DevBuf
 
+        import os
+
         self.lib, self.check, self.dist, self.torch = lib, check, dist, torch
         self.group = group
         self.world = dist.get_world_size(group)
         self.slots = slots
-        self.on_device = backend == "nccl"
+        # H2MI_COMBINE=host|rccl (A/B for the first run on a real multi-GPU node; SURVEY.md 8e: "a host-side gather ... must
+        # be benchmarked against RCCL"): rccl = the all-gather is stream-ordered on the library's stream and nothing leaves
+        # HBM (default with backend nccl); host = the phase's 96-byte points are copied to the host (which synchronises),
+        # gathered there and uploaded again — the collective still runs over the process group's backend
+        mode = os.environ.get("H2MI_COMBINE", "rccl" if backend == "nccl" else "host")
+        if mode not in ("host", "rccl") or (mode == "rccl" and backend != "nccl"):
+            raise ValueError(f"H2MI_COMBINE={mode!r} with backend {backend!r}: use host or rccl (rccl needs the nccl backend)")
+        self.mode = mode
+        self.coll_device = torch_device if backend == "nccl" else None  # where collective tensors must live
+        self.on_device = mode == "rccl"
         self.combines = 0
         self.host_arrays = host_arrays
         if host_arrays is not None:
@@ -131,9 +142,12 @@ class PhaseCombiner:
             part[:] = self.host_arrays[0][first : first + count].view(np.int64)
         else:
             check(lib.h2mi_memcpy_d2h(part.ctypes.data, self.partial_ptr + 96 * first, 96 * count), "d2h")
-        gathered = [torch.empty(count * 12, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(gathered, torch.from_numpy(part.reshape(-1)), group=self.group)
-        allp = np.ascontiguousarray(torch.stack(gathered).numpy())
+        mine = torch.from_numpy(part.reshape(-1))
+        if self.coll_device is not None:  # RCCL collectives take device tensors: host-synchronised round trip through them
+            mine = mine.to(self.coll_device)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine, group=self.group)
+        allp = np.ascontiguousarray(torch.stack(gathered).cpu().numpy())
         if self.host_arrays is not None:
             _, combined, fold = self.host_arrays
             combined[first : first + count] = fold(allp.view(np.uint64).reshape(self.world, count, 12))

@@ -140,12 +140,12 @@ class LookupTable:
             b.free()
 
 
-def lookup_permute(k: int, d_input: DevBuf, table: LookupTable, d_permuted_input: DevBuf, d_permuted_table: DevBuf, check: bool = True) -> int:
+def lookup_permute(k: int, d_input: DevBuf, table: LookupTable, d_permuted_input: DevBuf, d_permuted_table: DevBuf) -> int:
     """lookup/prover.rs permute_expression_pair on the device; rows beyond usable_rows are left to the caller (blinding).
     Returns the number of inputs that are not table values (the crate raises ConstraintSystemFailure when non-zero)."""
     missing = C.c_uint64()
     _check(lib.h2mi_plonk_lookup_permute_dev(d_input.ptr, table.sorted_canonical.ptr, table.sorted_mont.ptr, table.mult.ptr, table.n_unique, k,
-                                             table.usable_rows, d_permuted_input.ptr, d_permuted_table.ptr, C.byref(missing) if check else None, None),
+                                             table.usable_rows, d_permuted_input.ptr, d_permuted_table.ptr, C.byref(missing), None),
            "lookup_permute")
     return missing.value
 

@@ -259,8 +259,9 @@ int h2mi_plonk_permutation_products_sparse_dev(const void* const* d_values, cons
  * a run starts, the unconsumed table values — ascending — on the repeated rows, last repeated row first); rows beyond
  * usable_rows (the blinding rows) are left untouched.  The fixed table is described by its distinct usable values in
  * ascending order (canonical little-endian integers AND the same values in Montgomery form) and their multiplicities,
- * prepared once at keygen: a proof needs no sort, only a counting sort against them.  not_in_table_out (may be NULL;
- * non-NULL synchronises) receives the number of inputs that are not table values — the crate fails the proof then. */
+ * prepared once at keygen: a proof needs no sort, only a counting sort against them.  not_in_table_out (mandatory; the
+ * call synchronises on it) receives the number of inputs that are not table values — the crate fails the proof then, and
+ * the permuted columns are meaningless: H2MI_EINVAL without it. */
 int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorted_canonical, const void* d_table_sorted_mont,
                                   const void* d_table_mult /* u32 x n_unique */, uint32_t n_unique, uint32_t k, uint32_t usable_rows,
                                   void* d_permuted_input, void* d_permuted_table, uint64_t* not_in_table_out, h2mi_stream_t stream);

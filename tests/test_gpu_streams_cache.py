@@ -300,3 +300,53 @@ def test_fr_mul_elementwise_matches_oracle(gpu):
         for buf in (da, db, dc):
             buf.free()
     assert h2.lib.h2mi_fr_mul_dev(None, None, 4, None, None) != 0
+
+
+_REINIT_WORKER = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch  # first: one HIP runtime
+import _load_pkg
+h2 = _load_pkg.load()
+from oracle import bn254 as o, cref
+from halo2_scaffold_amd import flex
+lib = h2.lib
+def one_round(tag):
+    h2.init(0)
+    k = 10
+    params = h2.ParamsKZG.setup(k, 0xBEEF + tag)
+    coeffs = o.random_field_limbs(1 << k, 7 + tag)
+    dom = h2.EvaluationDomain(3, k)
+    evals = dom.coeff_to_lagrange(coeffs)
+    a = coeffs.copy(); cref.ntt(a, h2.field.fr_to_mont_limbs(h2.field.omega_for(k)), k, 1)
+    assert (evals == a).all(), "ntt after re-init"
+    c1, c2 = o.unpack_jacobian(params.commit(coeffs)), o.unpack_jacobian(params.commit_lagrange(evals))
+    assert c1 == c2 == o.unpack_jacobian(cref.msm(coeffs, params.get_g(), 4)), "msm after re-init"
+    cs = flex.FlexGateCS(lookup=True)              # lookup scratch, side streams, sparse grand products
+    asg = flex.range_closure(cs, 0x1234567 + tag, 6)
+    keys = flex.FlexKeys(params, cs, asg)
+    proof = flex.create_proof(params, keys, asg, 3)
+    keys.release()
+    lib.h2mi_shutdown()                            # with params' two registrations still alive: the teardown releases them                            # handles, plans, tables, scratch: all released with the device
+    assert lib.h2mi_malloc(16, None) != 0          # nothing works until the next init
+    return proof
+p1, p2, p3 = one_round(0), one_round(0), one_round(1)
+assert p1 == p2 and p1 != p3
+print("REINIT_OK")
+"""
+
+
+def test_shutdown_releases_module_state_and_reinit_works(gpu, tmp_path):
+    """the NTT plan / table / scratch caches, the MSM registrations and the lookup scratch were process-global
+    statics that survived h2mi_shutdown; a later h2mi_init then reused stale device pointers and events.  h2mi_shutdown now
+    runs per-module teardown hooks: three init -> prove -> shutdown rounds in one process give the same proofs."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "reinit.py"
+    script.write_text(_REINIT_WORKER.format(root=root))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0 and "REINIT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -66,9 +66,20 @@ try:
     dist.destroy_process_group()
 except Exception as e:  # noqa: BLE001
     coll_ms = f"not measured: {e}"
+# the xGMI hop itself cannot be measured on one GPU.  ESTIMATE (an assumption, stated so that the first hardware run can
+# replace it): an RCCL ring all-gather of <= 4 x 96 B per rank is latency-bound — its single-rank launch + fold cost is in
+# coll_ms above; each of the N - 1 ring steps adds one xGMI store + flag round trip, taken as HOP_US = 2.5 us (LL protocol,
+# a few hundred bytes; override with H2MI_HOP_US), so one combine costs (N - 1) * HOP_US more and a step has `len(phases)` of them
+HOP_US = float(os.environ.get("H2MI_HOP_US", "2.5"))
+n_combines = 5 if shape.name == "standard_plonk" else 1
 for r in rows:
     if isinstance(coll_ms, float) and r["world"] > 1:
         r["with_combines_ms"] = round(r["slowest_rank_ms"] + coll_ms, 3)
         r["speedup_vs_1_with_combines"] = round(base / r["with_combines_ms"], 2)
-print(json.dumps({"k": k, "combines_per_step_ms_single_rank_rccl": coll_ms if not isinstance(coll_ms, float) else round(coll_ms, 3), "shape": shape.name if hasattr(shape, "name") else str(shape), "what": "rank-local step time measured on one MI355X; the five per-phase combines timed with a 1-rank RCCL group and added",
+        hop_ms = n_combines * (r["world"] - 1) * HOP_US * 1e-3
+        r["xgmi_hop_estimate_ms"] = round(hop_ms, 4)
+        r["with_combines_and_hop_estimate_ms"] = round(r["with_combines_ms"] + hop_ms, 3)
+        r["speedup_vs_1_with_hop_estimate"] = round(base / (r["with_combines_ms"] + hop_ms), 2)
+print(json.dumps({"k": k, "combines_per_step_ms_single_rank_rccl": coll_ms if not isinstance(coll_ms, float) else round(coll_ms, 3), "shape": shape.name if hasattr(shape, "name") else str(shape), "what": "rank-local step time measured on one MI355X; the five per-phase combines timed with a 1-rank RCCL group and added; "
+                  "xgmi_hop_estimate_ms = combines x (N - 1) ring steps x %.1f us per step: an ASSUMPTION (no multi-GPU node was available), not a measurement" % HOP_US,
                   "rows": rows}, indent=1))
