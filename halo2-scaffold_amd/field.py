@@ -13,16 +13,17 @@ FR_MULTIPLICATIVE_GENERATOR = 7
 FR_ROOT_OF_UNITY = pow(FR_MULTIPLICATIVE_GENERATOR, (FR_MODULUS - 1) >> FR_S, FR_MODULUS)
 FR_ZETA = pow(FR_MULTIPLICATIVE_GENERATOR, (FR_MODULUS - 1) // 3, FR_MODULUS)
 _R = 1 << 256
+_R_INV = pow(_R, -1, FR_MODULUS)
 
 
 def fr_to_mont_limbs(a: int) -> np.ndarray:
     v = (a % FR_MODULUS) * _R % FR_MODULUS
-    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    return np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint64).copy()  # a writable array of its own (callers keep it alive across the ABI call)
 
 
 def fr_from_mont_limbs(l) -> int:
-    v = sum(int(l[i]) << (64 * i) for i in range(4))
-    return v * pow(_R, -1, FR_MODULUS) % FR_MODULUS
+    v = int.from_bytes(np.ascontiguousarray(l, dtype=np.uint64).tobytes()[:32], "little")
+    return v * _R_INV % FR_MODULUS
 
 
 def fr_inv(a: int) -> int:
