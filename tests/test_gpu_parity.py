@@ -938,3 +938,25 @@ def test_eip196_vectors_hip_path(gpu):
         k = int(v["k"], 16) % o.R
         got = gpu.best_multiexp(o.pack([k], o.R), o.pack_points([pt(v["p"])]))
         assert o.unpack_jacobian(got) == pt(v["product"]), v["name"]
+
+
+@pytest.mark.parametrize("c", [19, 20])
+def test_msm_wide_windows_forced_at_small_sizes(gpu, c):
+    """the wide-window path (c = 19 / 20: 16-bit in-bin keys, low-bit binning, k_msm_bin_sort_wide, segmented task scans,
+    k_msm_seg's segment pre-reduction, the subtraction in k_msm_final) is the default only from 2^22 points (where the
+    DEGREE 22 golden proof and the 2^24 linearity test exercise it).  Forced by H2MI_MSM_C in a child process, the same MSM
+    edge-case, hot-bucket and randomised-size tests run through it at sizes that take seconds, plus the golden 2^16-row
+    proof (dominant-value shift, sparse columns): every result must still equal the oracle's."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, H2MI_MSM_C=str(c), OMP_NUM_THREADS="1")
+    sel = ("test_msm_matches_oracle or test_msm_edge_cases or test_empty_msm_is_identity or test_msm_hot_buckets_large or "
+           "test_msm_randomised_sizes_and_distributions or test_msm_vs_c_oracle_large or test_pipelined_msm_stress")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_big_golden.py", "-x", "-q", "-m", "gpu", "-k", "standard_plonk_k16 and python_host",
+                        "-p", "no:cacheprovider"], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
