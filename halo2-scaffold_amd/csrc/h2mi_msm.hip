@@ -97,7 +97,11 @@ struct Slot {
   uint32_t tasks1 = 0;          // its fold grid bound
 };
 // slots per handle = MSMs that can be in flight between two joins before a flush is forced
-constexpr int NSLOT = 4;
+// Eight for base sets up to 2^22 (round 3): with four, every fifth back-to-back MSM waited for the reduction batch of the four
+// before it — the pipeline drained every four MSMs (2^17: 290 us per MSM with four slots; the accumulation alone is 167 us).
+// A prover phase queues at most four commitments, so this matters to commitment streams (keygen, many-column circuits), not to
+// the proofs measured here.  Beyond 2^22 a slot is > 1 GB: four.
+constexpr int NSLOT = 8;
 
 struct Bases {
   int dev = 0;                  // index into ctx().devs of the device that owns every allocation below
@@ -110,6 +114,7 @@ struct Bases {
   uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
   Slot slot[NSLOT];
+  int nslot = NSLOT;            // slots in use (allocated) for this handle
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0;
 };
@@ -1070,7 +1075,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   // the own scans (k_scan_seg) take 16-byte vectors: the [bin][tile] matrix has 512 rows and the task arrays
   // 2^(c-1) >= 1024 entries for every window width pick_window() can return
   if ((B->nbins & 3u) || B->nb < 4 || (B->nb > SCAN_SEG_TASKS && !B->seg_log) || B->nbins > NBINS_MAX || (1u << B->lb) > NQW) { free_bases(B); return H2MI_ERANGE; }
-  for (Slot& S : B->slot) {
+  B->nslot = n > ((size_t)1 << 22) ? 4 : NSLOT;
+  for (int si_ = 0; si_ < B->nslot; si_++) {
+    Slot& S = B->slot[si_];
     for (int i = 0; i < 2; i++) H2_ALLOC(S.vals[i], nW * 4);
     H2_ALLOC(S.bkeys, nW * (B->seg_log ? 2 : 1) + 16);
     H2_ALLOC(S.bincnt, bin_cells * 4);
@@ -1201,7 +1208,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
-  B->next_slot = (B->next_slot + 1) % NSLOT;
+  B->next_slot = (B->next_slot + 1) % B->nslot;
   if (S.tail_deferred) {  // every slot of this handle is waiting for its reduction
     int rc = flush_tails();
     if (rc) return rc;
@@ -1339,7 +1346,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     S.tail_deferred = true;
     g_deferred.push_back({B, &S});
     static const bool eager = getenv("H2MI_MSM_EAGER_TAIL") != nullptr;  // A/B: one reduction per MSM, at once
-    if (eager || g_deferred.size() >= TAIL_BATCH) return flush_tails();
+    // half the slots: the reductions of one half run beside the accumulation of the other
+    if (eager || g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
     return H2MI_OK;
   }
   TailBatch tb;
