@@ -284,10 +284,20 @@ __global__ void __launch_bounds__(64) k_msm_pick_shift(const fe* scalars, size_t
 }
 // scalar i of an MSM over n (+ 1) points as canonical integer: s_i - shift for the caller's scalars, shift itself for
 // the sum point
+// A zero scalar (an unassigned row; every row of a constant column after the shift) skips the Montgomery conversion: real
+// columns are mostly zero — the advice, permuted-lookup and (shifted) grand-product columns of the DEGREE 22 range proof spent
+// 0.4 + 0.9 ms each in the two digit kernels converting four million zeros (round 3, profiles/r03 timeline) — and a
+// wavefront whose 64 scalars are all zero now does no field arithmetic at all.
 __device__ __forceinline__ fe msm_scalar(const fe* scalars, size_t i, size_t n, const fe* shift) {
-  if (!shift) return fe_from_mont<FrP>(fe_load(&scalars[i]));
-  const fe v = fe_load(shift);
-  return fe_from_mont<FrP>(i < n ? fe_sub<FrP>(fe_load(&scalars[i]), v) : v);
+  fe x;
+  if (!shift) {
+    x = fe_load(&scalars[i]);
+  } else {
+    const fe v = fe_load(shift);
+    x = i < n ? fe_sub<FrP>(fe_load(&scalars[i]), v) : v;
+  }
+  if (fe_is_zero(x)) return x;
+  return fe_from_mont<FrP>(x);
 }
 
 template <uint32_t CT>
@@ -300,7 +310,8 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size
   size_t i = (size_t)blockIdx.x * P1_TS + tid;
   if (i < n + (shift ? 1 : 0)) {
     fe s = msm_scalar(scalars, i, n, shift);
-    for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bin_of<(CT >= WIDE_MIN_C)>(bucket, lb)], 1u); });
+    if (!fe_is_zero(s))
+      for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bin_of<(CT >= WIDE_MIN_C)>(bucket, lb)], 1u); });
   }
   __syncthreads();
   if (tid < nbins) cnt_out[(size_t)tid * ntiles + blockIdx.x] = cnt[tid];
@@ -333,8 +344,12 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
   uint32_t ent[WK], rk[WK];
 #pragma unroll
   for (uint32_t w = 0; w < WK; w++) ent[w] = 0xFFFFFFFFu;
+  bool live_nz = false;
   if (live) {
     s = msm_scalar(scalars, i, n, shift);
+    live_nz = !fe_is_zero(s);
+  }
+  if (live_nz) {
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
       uint32_t r = atomicAdd(&cnt[bin_of<WIDE>(bucket, lb)], 1u);
       if (CT) {
@@ -370,7 +385,7 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
         stage_val[pos] = (ent[w] & 0x80000000u) | (uint32_t)((size_t)w * n_reg + i);
         stage_key[pos] = (uint16_t)(WIDE ? key_of<true>(bucket, mask) : bucket);
       }
-  } else if (live) {
+  } else if (live_nz) {
     for_each_digit<CT>(s, c, W, [&](uint32_t w, uint32_t bucket, uint32_t neg) {
       uint32_t pos = atomicAdd(&cnt[bucket >> lb], 1u);
       stage_val[pos] = (neg << 31) | (uint32_t)((size_t)w * n_reg + i);
