@@ -83,6 +83,7 @@ def _load():
         "h2mi_plonk_permutation_products_sparse_dev": ([vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32, vp, vp],
                                                        C.c_int),
         "h2mi_fr_kate_division_dev": ([vp, sz, vp, vp, vp, vp], C.c_int),
+        "h2mi_fr_kate_division_multi_dev": ([vp, sz, vp, vp, vp, sz, vp, vp], C.c_int),
         "h2mi_fr_lincomb_dev": ([vp, vp, sz, sz, vp, vp], C.c_int),
         "h2mi_plonk_evaluate_h_standard_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_permutation_product_dev": ([vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),

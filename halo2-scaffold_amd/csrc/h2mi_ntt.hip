@@ -449,6 +449,77 @@ __global__ void __launch_bounds__(256) k_kate_finish(const fe* local, const fe* 
 }
 
 // out[i] = sum_k scalar_k * poly_k[i]
+// Division by a product of up to four distinct linear factors in ONE round (round 3): for Z(X) = prod (X - r_i) dividing N(X),
+// N / Z = sum_i c_i * (N / (X - r_i)), c_i = 1 / prod_{j != i} (r_i - r_j) (partial fractions; every N / (X - r_i) is exact).
+// SHPLONK divided a rotation set's numerator by its points one after the other — a chain of up to four dependent three-launch
+// divisions (2.0 ms at 2^22 rows, the longest stretch of the opening phase) — where the m divisions are independent: the same
+// three launches with blockIdx.y = root, the finish kernel summing the weighted quotients.
+constexpr uint32_t KATE_MULTI_MAX = 4;
+struct KateRoots {
+  const fe* lo[KATE_MULTI_MAX];   // b_r^i tables
+  const fe* hi[KATE_MULTI_MAX];
+  const fe* ilo[KATE_MULTI_MAX];  // b_r^-i tables
+  const fe* ihi[KATE_MULTI_MAX];
+  uint32_t h[KATE_MULTI_MAX], ih[KATE_MULTI_MAX];
+  fe c[KATE_MULTI_MAX];           // the partial-fraction weights, Montgomery-2^256
+  uint32_t m;
+};
+__global__ void __launch_bounds__(256) k_kate_local_multi(const fe* a, size_t n, KateRoots R, uint32_t nblocks, fe* local, fe* totals) {
+  __shared__ fe tile[KATE_TILE + 8];
+  __shared__ fe tsum[256];
+  const uint32_t tid = threadIdx.x, r = blockIdx.y;
+  const size_t base = (size_t)blockIdx.x * KATE_TILE;
+  local += (size_t)r * n;
+  totals += (size_t)r * nblocks;
+  for (uint32_t q = 0; q < 4; q++) {
+    size_t i = base + tid + 256 * q;
+    fe o = fe_zero();
+    if (i < n) {
+      f29 x = f29_mul<F9>(load_unpack(&a[i]), pow2tab(R.lo[r], R.hi[r], R.h[r], (uint32_t)i));
+      f29_pack(f29_reduce_canonical<F9>(x), o.v);
+    }
+    tile[tid + 256 * q] = o;
+  }
+  __syncthreads();
+  fe e3 = tile[4 * tid + 3], e2 = fe_add<Fr>(tile[4 * tid + 2], e3), e1 = fe_add<Fr>(tile[4 * tid + 1], e2), e0 = fe_add<Fr>(tile[4 * tid], e1);
+  tsum[tid] = e0;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    fe v = fe_zero();
+    if (tid + d < 256) v = tsum[tid + d];
+    __syncthreads();
+    tsum[tid] = fe_add<Fr>(tsum[tid], v);
+    __syncthreads();
+  }
+  fe right = tid + 1 < 256 ? tsum[tid + 1] : fe_zero();
+  __syncthreads();
+  tile[4 * tid] = fe_add<Fr>(e0, right);
+  tile[4 * tid + 1] = fe_add<Fr>(e1, right);
+  tile[4 * tid + 2] = fe_add<Fr>(e2, right);
+  tile[4 * tid + 3] = fe_add<Fr>(e3, right);
+  __syncthreads();
+  for (uint32_t q = 0; q < 4; q++) {
+    size_t i = base + tid + 256 * q;
+    if (i < n) fe_store(&local[i], tile[tid + 256 * q]);
+  }
+  if (tid == 0) fe_store(&totals[blockIdx.x], tile[0]);
+}
+// q_i = sum_r c_r (local_r[i+1] + offsets_r[block(i+1)]) b_r^-(i+1)
+__global__ void __launch_bounds__(256) k_kate_finish_multi(const fe* local, const fe* offsets, size_t n, KateRoots R, uint32_t nblocks, fe* q) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  f29 acc = f29_zero();
+  for (uint32_t r = 0; r < R.m; r++) {
+    fe s = fe_add<Fr>(fe_load(&local[(size_t)r * n + i + 1]), fe_load(&offsets[(size_t)r * nblocks + (i + 1) / KATE_TILE]));
+    f29 x = f29_mul<F9>(f29_unpack(s.v), pow2tab(R.ilo[r], R.ihi[r], R.ih[r], (uint32_t)(i + 1)));  // Mont256 value, below 1.2 p
+    // weight: (x 2^256)(c 2^256) / 2^261 carries 2^-5 less than wanted; c arrives pre-multiplied by 2^5 (host)
+    acc = f29_add(acc, f29_mul<F9>(x, f29_unpack(R.c[r].v)));
+  }
+  fe o;
+  f29_pack(f29_reduce_loose<F9>(f29_normalize(acc)), o.v);  // up to four products below 1.2 p each
+  fe_store(&q[i], o);
+}
+
 constexpr uint32_t LINCOMB_MAX = 24;
 struct LincombArgs {
   const fe* poly[LINCOMB_MAX];
@@ -1586,6 +1657,43 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
   H2_LAUNCH("k_kate_finish", k_kate_finish, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, (const fe*)pi.lo,
             (const fe*)pi.hi, pi.h, (fe*)d_out);
+  return release_tmp(s);
+}
+
+int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t* roots, const uint64_t* roots_inv, const uint64_t* weights,
+                                    size_t m, void* d_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_poly || !roots || !roots_inv || !weights || !d_out || n < 2 || m == 0 || m > KATE_MULTI_MAX) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 30) return H2MI_ERANGE;
+  KateRoots R;
+  memset(&R, 0, sizeof(R));
+  R.m = (uint32_t)m;
+  for (size_t r = 0; r < m; r++) {
+    PowTab pb, pi;
+    int rc = get_powtab(roots + 4 * r, log_n, s, &pb);
+    if (!rc) rc = get_powtab(roots_inv + 4 * r, log_n, s, &pi);
+    if (rc) return rc;
+    R.lo[r] = pb.lo; R.hi[r] = pb.hi; R.h[r] = pb.h;
+    R.ilo[r] = pi.lo; R.ihi[r] = pi.hi; R.ih[r] = pi.h;
+    // the weight enters a mixed-domain product (see k_kate_finish_multi): c 2^256 -> c 2^261, i.e. five doublings
+    fe c = host_fe(weights + 4 * r);
+    R.c[r] = h_level(c, -1);
+  }
+  const uint32_t nblocks = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
+  int rc = ensure_tmp(m * (n + 2 * (size_t)nblocks) + 16, s);
+  if (rc) return rc;
+  fe* local = g_tmp;
+  fe* totals = g_tmp + m * n;
+  fe* offsets = totals + m * nblocks;
+  H2_LAUNCH("k_kate_local", k_kate_local_multi, dim3(nblocks, (uint32_t)m), 256, 0, s, (const fe*)d_poly, n, R, nblocks, local, totals);
+  for (size_t r = 0; r < m; r++)  // tiny: one workgroup per root
+    H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)(totals + r * nblocks), nblocks, offsets + r * nblocks);
+  H2_LAUNCH("k_kate_finish", k_kate_finish_multi, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, R, nblocks, (fe*)d_out);
   return release_tmp(s);
 }
 

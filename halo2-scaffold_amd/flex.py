@@ -471,6 +471,12 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     zblind = synth.uniform_fr(n_sets * bf, seed + 2)
     for s, z in enumerate(zs):
         z.patch(zblind[s * bf : (s + 1) * bf], offset=(u + 1) * 32)
+    # coefficient / extended forms of the grand products: on the side stream, ordered behind the columns themselves and
+    # AHEAD of their commitments' partition kernels (round 3: queued behind the commitments on the library stream, the six
+    # 2^24-point transforms of the DEGREE 22 range proof started only when the partitions — starved by the random
+    # polynomial's accumulation — had drained, 7 ms into the phase)
+    side.after_library()
+    z_f = [forms(z, side.handle) for z in zs]
     slot = 0
     for z in zs:
         commit(z, True, slot)
@@ -480,14 +486,12 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         gp.lookup_product(d.k, lk_input, pk.fixed_values[cs.col_table], lk[0], lk[1], beta, gamma, u, lz)
         lz.patch(synth.uniform_fr(bf, seed + 5), offset=(u + 1) * 32)
         lk[2] = lz
+        side.after_library()
+        lk_f.append(forms(lk[2], side.handle))
         commit(lz, True, slot)
         slot += 1
     slot += 1  # the random polynomial's commitment, queued before the grand products (RANDOM_SLOT)
     check(lib.h2mi_msm_flush(), "flush")
-    # coefficient / extended forms, queued behind the commitments
-    z_f = [forms(z) for z in zs]
-    if cs.lookup:
-        lk_f.append(forms(lk[2]))
     side.join_library()  # evaluate_h and the openings read the side stream's forms
     _write_points(ws, transcript, slot)
     y = sq()

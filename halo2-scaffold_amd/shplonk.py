@@ -101,14 +101,31 @@ def _add_head(poly: DevBuf, coeffs, stream=None):
 
 def _kate_chain(src: DevBuf, n: int, roots, tmp: DevBuf, out: DevBuf, stream=None, tmp2: DevBuf = None):
     """out = src / prod (X - root).  `out` must have been zeroed (the quotient has n - len(roots) coefficients; the rest
-    of the n stay zero).  Intermediate quotients alternate between tmp and tmp2; without a tmp2, src is clobbered when
-    there are >= 2 roots"""
+    of the n stay zero).  Two to four roots: ONE round of independent divisions weighted by the partial-fraction
+    coefficients 1 / prod_{k != i} (r_i - r_k) (h2mi_fr_kate_division_multi_dev) instead of a chain of dependent ones."""
+    if len(roots) == 1:
+        b, b_inv = _m(roots[0]), _m(pow(roots[0], -1, R))  # named: the arrays must outlive the call that reads their memory
+        check(lib.h2mi_fr_kate_division_dev(src.ptr, n, b.ctypes.data, b_inv.ctypes.data, out.ptr, stream), "kate_division")
+        return
+    if len(roots) <= 4:
+        weights = []
+        for i, r in enumerate(roots):
+            d = 1
+            for k, rk in enumerate(roots):
+                if k != i:
+                    d = d * (r - rk) % R
+            weights.append(pow(d, -1, R))
+        rl = np.ascontiguousarray(np.stack([_m(r) for r in roots]))
+        ri = np.ascontiguousarray(np.stack([_m(pow(r, -1, R)) for r in roots]))
+        wl = np.ascontiguousarray(np.stack([_m(w) for w in weights]))
+        check(lib.h2mi_fr_kate_division_multi_dev(src.ptr, n, rl.ctypes.data, ri.ctypes.data, wl.ctypes.data, len(roots), out.ptr, stream), "kate_division_multi")
+        return
     cur, length = src, n
     bufs = [tmp, tmp2 if tmp2 is not None else src]
     for i, root in enumerate(roots):
         last = i == len(roots) - 1
         dst = out if last else bufs[i % 2]
-        b, b_inv = _m(root), _m(pow(root, -1, R))  # named: the arrays must outlive the call that reads their memory
+        b, b_inv = _m(root), _m(pow(root, -1, R))
         check(lib.h2mi_fr_kate_division_dev(cur.ptr, length, b.ctypes.data, b_inv.ctypes.data, dst.ptr, stream), "kate_division")
         cur, length = dst, length - 1
 

@@ -181,6 +181,14 @@ int h2mi_fr_eval_polys_dev(const void* const* d_polys, size_t count, size_t n, c
  * (the remainder a(b) is dropped, as in the crate).  The caller passes b^-1 (one CPU inversion). */
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out,
                               h2mi_stream_t stream);
+/* division by prod_{i < m} (X - roots[i]), m <= 4 distinct roots, of a polynomial they all vanish at — what SHPLONK's
+ * div_by_vanishing does with one kate_division per point (poly/kzg/multiopen/shplonk/prover.rs [RECALL]) — in ONE round:
+ * d_out[j] = sum_i weights[i] * (a / (X - roots[i]))[j] for j < n - 1, with weights[i] = 1 / prod_{k != i} (roots[i] - roots[k])
+ * computed by the caller (partial fractions; the m quotients are independent, the chain of m dependent divisions is not).
+ * roots, roots_inv, weights: m x 4 limbs, Montgomery.  d_out[n - 1] is left untouched; the top m - 1 written coefficients
+ * come out as exact zeros. */
+int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t* roots, const uint64_t* roots_inv, const uint64_t* weights,
+                                    size_t m, void* d_out, h2mi_stream_t stream);
 /* out[i] = sum_k scalars[k] * polys[k][i], count <= 24 (the challenge-weighted sums of SHPLONK) */
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars /* count*4 */, size_t count, size_t n, void* d_out,
                         h2mi_stream_t stream);

@@ -597,6 +597,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)n_sets * bf);
   for (uint32_t s = 0; s < n_sets; s++)
     check(h2mi_memcpy_h2d_async((char*)zs[s]->p + (size_t)(u + 1) * 32, &zblind[(size_t)s * bf], bf * 32), "z blinding rows");
+  // the grand products' coefficient / extended forms: side stream, behind the columns and AHEAD of their commitments'
+  // partition kernels (which a dense accumulation in flight starves for milliseconds at DEGREE 22)
+  check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
+  std::vector<Forms> z_f;
+  for (uint32_t s = 0; s < n_sets; s++) z_f.push_back(forms(*zs[s], ws.side));
   size_t slot = 0;
   for (uint32_t s = 0; s < n_sets; s++) commit(true, zs[s]->p, slot++);
   std::vector<Fr> lzblind;
@@ -606,13 +611,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
           "lookup_product");
     lzblind = uniform_fr(seed + 5, bf);
     check(h2mi_memcpy_h2d_async((char*)lz->p + (size_t)(u + 1) * 32, lzblind.data(), bf * 32), "lookup z blinding rows");
+    check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
+    lz_f = forms(*lz, ws.side);
     commit(true, lz->p, slot++);
   }
   slot++;  // the random polynomial's slot
   check(h2mi_msm_flush(), "flush");
-  std::vector<Forms> z_f;
-  for (uint32_t s = 0; s < n_sets; s++) z_f.push_back(forms(*zs[s], nullptr));
-  if (cs.lookup) lz_f = forms(*lz, nullptr);
   check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");
   write_points(slot);
   const Fr y = tr.squeeze_challenge();

@@ -456,6 +456,20 @@ inline void add_head(DeviceVec& poly, const std::vector<Fr>& head, h2mi_stream_t
 // zero); intermediate quotients alternate between tmp and tmp2 — without a tmp2, src is clobbered when there are >= 2 roots
 inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out, h2mi_stream_t stream = nullptr,
                        DeviceVec* tmp2 = nullptr) {
+  if (roots.size() >= 2 && roots.size() <= 4) {  // one round: independent divisions weighted by 1 / prod_{k != i} (r_i - r_k)
+    std::vector<Fr> inv, w;
+    for (size_t i = 0; i < roots.size(); i++) {
+      Fr d = fr::ONE;
+      for (size_t k = 0; k < roots.size(); k++)
+        if (k != i) d = fr::mul(d, fr::sub(roots[i], roots[k]));
+      w.push_back(fr::invert(d));
+      inv.push_back(fr::invert(roots[i]));
+    }
+    check(h2mi_fr_kate_division_multi_dev(src.p, n, (const uint64_t*)roots.data(), (const uint64_t*)inv.data(), (const uint64_t*)w.data(), roots.size(),
+                                          out.p, stream),
+          "kate_division_multi");
+    return;
+  }
   DeviceVec* cur = &src;
   DeviceVec* bufs[2] = {&tmp, tmp2 ? tmp2 : &src};
   size_t len = n;

@@ -292,3 +292,45 @@ def test_eval_polys_batched_matches_oracle(gpu):
         for b in bufs + [out]:
             b.free()
     assert gpu.lib.h2mi_fr_eval_polys_dev(None, 1, 4, None, None, None) == -1
+
+
+@pytest.mark.parametrize("n,m", [(64, 2), (1000, 3), (1 << 13, 4), (70001, 4)])
+def test_kate_division_multi_matches_chained_divisions(gpu, n, m):
+    """h2mi_fr_kate_division_multi_dev: N / prod (X - r_i) in one round (partial fractions over independent divisions) equals
+    the oracle's chain of kate_division calls — what SHPLONK's div_by_vanishing computes — coefficient for coefficient,
+    including the exact zeros at the top."""
+    from halo2_scaffold_amd import field as F
+
+    rng = np.random.default_rng(n + m)
+    roots = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(m)]
+    quot = o.unpack(o.random_field_limbs(n - m, 77 + n), o.R)
+    num = quot
+    for r in roots:  # N = Q * prod (X - r)
+        nxt = [0] * (len(num) + 1)
+        for i, c in enumerate(num):
+            nxt[i + 1] = (nxt[i + 1] + c) % o.R
+            nxt[i] = (nxt[i] - c * r) % o.R
+        num = nxt
+    assert len(num) == n
+    want = num
+    for r in roots:
+        want = o.kate_division(want, r)
+    assert want == quot
+    d_in = gpu.DevBuf.from_numpy(o.pack(num, o.R))
+    d_out = gpu.DevBuf.from_numpy(o.pack([0xBAD] * n, o.R))
+    weights = []
+    for i, r in enumerate(roots):
+        d = 1
+        for k, rk in enumerate(roots):
+            if k != i:
+                d = d * (r - rk) % o.R
+        weights.append(pow(d, -1, o.R))
+    rl = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(r) for r in roots]))
+    ri = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(pow(r, -1, o.R)) for r in roots]))
+    wl = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(w) for w in weights]))
+    assert gpu.lib.h2mi_fr_kate_division_multi_dev(d_in.ptr, n, rl.ctypes.data, ri.ctypes.data, wl.ctypes.data, m, d_out.ptr, None) == 0
+    got = _vals(d_out, n)
+    assert got[: n - m] == quot and got[n - m : n - 1] == [0] * (m - 1) and got[n - 1] == 0xBAD  # the last slot is not written
+    assert gpu.lib.h2mi_fr_kate_division_multi_dev(d_in.ptr, n, rl.ctypes.data, ri.ctypes.data, wl.ctypes.data, 5, d_out.ptr, None) == -1
+    d_in.free()
+    d_out.free()
