@@ -88,6 +88,7 @@ def _load():
         "h2mi_plonk_evaluate_h_standard_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_permutation_product_dev": ([vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_lookup_permute_dev": ([vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64p, vp], C.c_int),
+        "h2mi_plonk_instance_coset_dev": ([vp, C.c_uint32, C.c_uint32, vp, sz, vp, vp], C.c_int),
         "h2mi_plonk_lookup_product_dev": ([vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_evaluate_h_range_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_g1_fixed_base_mul_dev": ([vp, sz, vp, vp], C.c_int),

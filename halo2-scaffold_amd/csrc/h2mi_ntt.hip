@@ -449,6 +449,25 @@ __global__ void __launch_bounds__(256) k_kate_finish(const fe* local, const fe* 
 }
 
 // out[i] = sum_k scalar_k * poly_k[i]
+// Extended-coset form of an instance column WITHOUT transforms (round 3).  The column holds `count` public inputs v_r on rows
+// r < count and zeros elsewhere, so its polynomial is sum_r v_r L_r(X) with L_r(X) = L_0(omega^-r X), and on the extended coset
+// X_j = g w^j (omega = w^rot): L_r(X_j) = L_0(X_(j - r rot)) — values the proving key already holds as l_0's coset.  out[j] =
+// sum_r v_r l0[(j - r rot) mod 2^ext_k]: one pass instead of an iNTT(n) + coset NTT(2^ext_k) (2.8 ms at DEGREE 22).
+struct InstanceArgs {
+  fe v[16];  // Montgomery-2^256 values times 2^5 (the mixed-domain product's level, see k_kate_finish_multi)
+};
+__global__ void __launch_bounds__(256) k_instance_coset(const fe* l0, uint32_t ext_k, uint32_t rot, InstanceArgs a, uint32_t count, fe* out) {
+  const uint32_t size = 1u << ext_k;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= size) return;
+  f29 acc = f29_zero();
+  for (uint32_t r = 0; r < count; r++)
+    acc = f29_add(acc, f29_mul<F9>(load_unpack(&l0[(j + size - r * rot) & (size - 1)]), f29_unpack(a.v[r].v)));
+  fe o;
+  f29_pack(f29_reduce_loose<F9>(f29_normalize(acc)), o.v);
+  fe_store(&out[j], o);
+}
+
 // Division by a product of up to four distinct linear factors in ONE round (round 3): for Z(X) = prod (X - r_i) dividing N(X),
 // N / Z = sum_i c_i * (N / (X - r_i)), c_i = 1 / prod_{j != i} (r_i - r_j) (partial fractions; every N / (X - r_i) is exact).
 // SHPLONK divided a rotation set's numerator by its points one after the other — a chain of up to four dependent three-launch
@@ -1658,6 +1677,22 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   H2_LAUNCH("k_kate_finish", k_kate_finish, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, (const fe*)pi.lo,
             (const fe*)pi.hi, pi.h, (fe*)d_out);
   return release_tmp(s);
+}
+
+int h2mi_plonk_instance_coset_dev(const void* d_l0_coset, uint32_t k, uint32_t extended_k, const uint64_t* values, size_t count, void* d_out,
+                                  h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_l0_coset || !d_out || (count && !values) || count > 16) return H2MI_EINVAL;
+  if (k == 0 || extended_k < k || extended_k > H2MI_MAX_LOG_N || count > ((size_t)1 << k)) return H2MI_ERANGE;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  InstanceArgs a;
+  memset(&a, 0, sizeof(a));
+  for (size_t r = 0; r < count; r++) a.v[r] = h_level(host_fe(values + 4 * r), -1);
+  const uint32_t size = 1u << extended_k;
+  H2_LAUNCH("k_instance_coset", k_instance_coset, ceil_div_u32(size, 256), 256, 0, s, (const fe*)d_l0_coset, extended_k, 1u << (extended_k - k), a,
+            (uint32_t)count, (fe*)d_out);
+  return H2MI_OK;
 }
 
 int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t* roots, const uint64_t* roots_inv, const uint64_t* weights,

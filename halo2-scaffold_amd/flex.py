@@ -433,7 +433,13 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     side = ws.side
     side.after_library()
     advice_f = [forms(c, side.handle) for c in advice]
-    instance_f = forms(instance, side.handle)
+    if len(asg.instance) <= 16:  # a handful of public inputs: sum_r v_r * (l_0's coset rotated by r rows), no transform (round 3)
+        inst_coset = dev(ext)
+        vals = np.ascontiguousarray(np.stack([_m(v) for v in asg.instance])) if asg.instance else np.zeros((1, 4), dtype=np.uint64)
+        check(lib.h2mi_plonk_instance_coset_dev(pk.l0.ptr, d.k, d.extended_k, vals.ctypes.data, len(asg.instance), inst_coset.ptr, side.handle), "instance coset")
+        instance_f = (None, inst_coset)
+    else:
+        instance_f = forms(instance, side.handle)
     _write_points(ws, transcript, len(advice))
     theta = sq()
     # lookup: permuted input / table columns

@@ -25,10 +25,11 @@ R = F.FR_MODULUS
 _m = F.fr_to_mont_limbs
 
 
-def _interpolate(points, evals):
-    """coefficients (low to high) of the polynomial of degree < len(points) through the given values"""
+def _lagrange_basis(points):
+    """coefficient lists (low to high) of the Lagrange basis polynomials of `points`: the part of an interpolation that depends
+    on the points alone — computed once per rotation set, its modular inversions included, instead of once per member"""
     k = len(points)
-    out = [0] * k
+    basis = []
     for j in range(k):
         num, den = [1], 1
         for m in range(k):
@@ -40,9 +41,18 @@ def _interpolate(points, evals):
                 nxt[i] = (nxt[i] - c * points[m]) % R
             num = nxt
             den = den * (points[j] - points[m]) % R
-        scale = evals[j] * pow(den, -1, R) % R
-        for i, c in enumerate(num):
-            out[i] = (out[i] + c * scale) % R
+        inv = pow(den, -1, R)
+        basis.append([c * inv % R for c in num])
+    return basis
+
+
+def _interpolate(points, evals, basis=None):
+    """coefficients (low to high) of the polynomial of degree < len(points) through the given values"""
+    basis = basis if basis is not None else _lagrange_basis(points)
+    out = [0] * len(points)
+    for ev, bj in zip(evals, basis):
+        for i, c in enumerate(bj):
+            out[i] = (out[i] + c * ev) % R
     return out
 
 
@@ -172,8 +182,9 @@ class ProverSHPLONK:
             ypow = [pow(y, j, R) for j in range(len(rs.members))]
             _lincomb([p for p, _ in rs.members], ypow, n, self._s[i], stream)
             rsum = [0] * len(rs.points)
+            basis = _lagrange_basis(rs.points)
             for (_, evals), yp in zip(rs.members, ypow):
-                for t, c in enumerate(_interpolate(rs.points, evals)):
+                for t, c in enumerate(_interpolate(rs.points, evals, basis)):
                     rsum[t] = (rsum[t] - yp * c) % R
             _add_head(self._s[i], rsum, stream)
             remainders.append([(-c) % R for c in rsum])  # R_i(X) = sum_j y^j R_ij(X), low to high

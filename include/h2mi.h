@@ -273,6 +273,12 @@ int h2mi_plonk_permutation_products_sparse_dev(const void* const* d_values, cons
 int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorted_canonical, const void* d_table_sorted_mont,
                                   const void* d_table_mult /* u32 x n_unique */, uint32_t n_unique, uint32_t k, uint32_t usable_rows,
                                   void* d_permuted_input, void* d_permuted_table, uint64_t* not_in_table_out, h2mi_stream_t stream);
+/* extended-coset form of an instance column from the proving key's l_0 coset, without transforms: the column holds `count`
+ * <= 16 public inputs on rows 0 .. count - 1 (what the scaffold's builders constrain: src/scaffold.rs:411, 480) and zeros
+ * elsewhere, so its coset values are sum_r values[r] * l0_coset[(j - r 2^(extended_k - k)) mod 2^extended_k] — the same field
+ * elements coeff_to_extended(lagrange_to_coeff(column)) yields.  values: count x 4 limbs, Montgomery. */
+int h2mi_plonk_instance_coset_dev(const void* d_l0_coset, uint32_t k, uint32_t extended_k, const uint64_t* values, size_t count, void* d_out,
+                                  h2mi_stream_t stream);
 /* commit_product: z[0] = 1, z[i+1] = z[i] (a_i + beta)(t_i + gamma) / ((a'_i + beta)(s'_i + gamma)), i < usable_rows;
  * blinding rows untouched; one field inversion per call */
 int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,

@@ -542,7 +542,16 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // coefficient / extended forms that wait for no challenge: on the side stream, beside the transcript round trips
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
-  Forms advice_f = forms(advice, ws.side), instance_f = forms(instance, ws.side);
+  Forms advice_f = forms(advice, ws.side);
+  Forms instance_f{nullptr, nullptr};
+  if (asg.instance.size() <= 16) {  // a handful of public inputs: sum_r v_r * (l_0's coset rotated by r rows), no transform
+    instance_f.coset = &ws.take(ext);
+    check(h2mi_plonk_instance_coset_dev(pk.l0->p, d.k(), d.extended_k(), (const uint64_t*)asg.instance.data(), asg.instance.size(), instance_f.coset->p,
+                                        ws.side),
+          "instance coset");
+  } else {
+    instance_f = forms(instance, ws.side);
+  }
   write_points(1);
   (void)tr.squeeze_challenge();  // theta
   // lookup: input expression rows q_lookup * a, permuted input / table columns
