@@ -157,13 +157,17 @@ inline Fr from_u64(uint64_t v) {
   return mul(a, R2);
 }
 inline Fr pow(const Fr& a, const uint64_t e[4]) {
+  int top = 255;  // a small exponent (omega^i, delta^j) must not cost 256 squarings
+  while (top >= 0 && !((e[top >> 6] >> (top & 63)) & 1)) top--;
   Fr r = ONE;
-  for (int i = 255; i >= 0; i--) {
+  for (int i = top; i >= 0; i--) {
     r = mul(r, r);
     if ((e[i >> 6] >> (i & 63)) & 1) r = mul(r, a);
   }
   return r;
 }
+// Montgomery's trick: the inverses of k nonzero elements for one inversion and 3 (k - 1) multiplications
+inline std::vector<Fr> batch_invert(const std::vector<Fr>& v);
 inline Fr pow_u64(const Fr& a, uint64_t e) {
   uint64_t ee[4] = {e, 0, 0, 0};
   return pow(a, ee);
@@ -171,6 +175,21 @@ inline Fr pow_u64(const Fr& a, uint64_t e) {
 inline Fr invert(const Fr& a) {  // a^(r-2); the crate returns CtOption, callers here never pass zero
   uint64_t e[4] = {MODULUS[0] - 2, MODULUS[1], MODULUS[2], MODULUS[3]};
   return pow(a, e);
+}
+inline std::vector<Fr> batch_invert(const std::vector<Fr>& v) {
+  std::vector<Fr> out(v.size());
+  if (v.empty()) return out;
+  Fr acc = ONE;
+  for (size_t i = 0; i < v.size(); i++) {
+    out[i] = acc;
+    acc = mul(acc, v[i]);
+  }
+  Fr inv = invert(acc);
+  for (size_t i = v.size(); i-- > 0;) {
+    out[i] = mul(out[i], inv);
+    inv = mul(inv, v[i]);
+  }
+  return out;
 }
 // ROOT_OF_UNITY = 7^((r-1)/2^28); ZETA = 7^((r-1)/3)
 inline Fr root_of_unity() {
@@ -262,6 +281,23 @@ class EvaluationDomain {
   const Fr& get_omega() const { return omega_; }
   const Fr& get_omega_inv() const { return omega_inv_; }
   const Fr& get_extended_omega() const { return extended_omega_; }
+  const Fr& get_extended_omega_inv() const { return extended_omega_inv_; }
+  const Fr& get_g_coset() const { return g_coset_; }
+  const Fr& get_g_coset_inv() const { return g_coset_inv_; }
+  const Fr& get_ifft_divisor() const { return ifft_divisor_; }
+  const Fr& get_extended_ifft_divisor() const { return extended_ifft_divisor_; }
+  // (X^n - 1)^-1 on the extended coset: 2^(extended_k - k) distinct values (what evaluate_h divides by); computed once
+  const std::vector<Fr>& t_inv() const {
+    if (t_inv_.empty()) {
+      std::vector<Fr> t;
+      for (uint64_t i = 0; i < ((uint64_t)1 << (extended_k_ - k_)); i++) {
+        Fr X = fr::mul(g_coset_, fr::pow_u64(extended_omega_, i));
+        t.push_back(fr::sub(fr::pow_u64(X, n_), fr::ONE));
+      }
+      t_inv_ = fr::batch_invert(t);
+    }
+    return t_inv_;
+  }
 
   std::vector<Fr> lagrange_to_coeff(std::vector<Fr> a) const {
     require(a.size() == n_, "lagrange_to_coeff");
@@ -296,6 +332,7 @@ class EvaluationDomain {
   uint32_t k_, extended_k_;
   uint64_t n_, quotient_poly_degree_;
   Fr omega_, omega_inv_, extended_omega_, extended_omega_inv_, g_coset_, g_coset_inv_, ifft_divisor_, extended_ifft_divisor_;
+  mutable std::vector<Fr> t_inv_;
 };
 
 namespace kzg {

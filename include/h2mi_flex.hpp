@@ -512,7 +512,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   auto write_points = [&](size_t k) {
     std::vector<G1> jac(k);
     check(h2mi_memcpy_d2h(jac.data(), points.p, k * 96), "d2h");  // joins the MSM pipeline
-    for (const G1& p : jac) tr.write_point(normalize_host(p));
+    for (const G1Affine& a : normalize_host_batch(jac)) tr.write_point(a);
   };
   auto commit = [&](bool lagrange, const void* col, size_t slot) {
     check(h2mi_msm_bn254_g1_dev(lagrange ? params.g_lagrange_handle() : params.g_handle(), col, n, (char*)points.p + 96 * slot, nullptr), "commit");
@@ -657,18 +657,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
       rc.lookup_permuted_table = sp_f.coset->p;
       rc.lookup_z = lz_f.coset->p;
     }
-    const uint32_t rot = 1u << (d.extended_k() - d.k());
-    const Fr zeta = fr::zeta();
-    std::vector<Fr> t_inv;
-    for (uint32_t i = 0; i < rot; i++) {
-      Fr X = fr::mul(zeta, fr::pow_u64(d.get_extended_omega(), i));
-      t_inv.push_back(fr::invert(fr::sub(fr::pow_u64(X, n), fr::ONE)));
-    }
+    const Fr& zeta = d.get_g_coset();
+    const std::vector<Fr>& t_inv = d.t_inv();  // (X^n - 1)^-1 on the coset: cached in the domain
     check(h2mi_plonk_evaluate_h_range_dev(&rc, d.k(), d.extended_k(), bf, beta.l, gamma.l, y.l, delta.l, zeta.l, d.get_extended_omega().l,
                                           (const uint64_t*)t_inv.data(), h.p, nullptr), "evaluate_h");
-    Fr eo_inv = fr::invert(d.get_extended_omega()), zeta_inv = fr::mul(zeta, zeta), en_inv = fr::invert(fr::from_u64(ext));
-    check(h2mi_ntt_bn254_fr_dev(h.p, d.extended_k(), eo_inv.l, nullptr, nullptr, nullptr), "extended_to_coeff");
-    check(h2mi_fr_scale_powers_dev(h.p, ext, zeta_inv.l, en_inv.l, nullptr), "distribute_powers_zeta");
+    check(h2mi_ntt_bn254_fr_dev(h.p, d.extended_k(), d.get_extended_omega_inv().l, nullptr, nullptr, nullptr), "extended_to_coeff");
+    check(h2mi_fr_scale_powers_dev(h.p, ext, d.get_g_coset_inv().l, d.get_extended_ifft_divisor().l, nullptr), "distribute_powers_zeta");
   }
   const uint32_t pieces = cs.degree - 1;
   for (uint32_t i = 0; i < pieces; i++) commit(false, (char*)h.p + (size_t)i * n * 32, i);

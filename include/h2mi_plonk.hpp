@@ -132,6 +132,31 @@ inline G1Affine normalize_host(const G1& p) {
   return a;
 }
 
+// G1::batch_normalize: one inversion for the whole phase (Montgomery's trick), as the crate does before hashing the points
+inline std::vector<G1Affine> normalize_host_batch(const std::vector<G1>& pts) {
+  std::vector<fq::E> z(pts.size()), pre(pts.size());
+  fq::E acc = fq::ONE;
+  for (size_t i = 0; i < pts.size(); i++) {
+    if (pts[i].is_identity()) throw Error(H2MI_EINVAL, "cannot write points at infinity to the transcript");
+    std::memcpy(z[i].l, pts[i].z, 32);
+    pre[i] = acc;
+    acc = fq::mul(acc, z[i]);
+  }
+  fq::E inv = pts.empty() ? fq::ONE : fq::invert(acc);
+  std::vector<G1Affine> out(pts.size());
+  for (size_t i = pts.size(); i-- > 0;) {
+    const fq::E zi = fq::mul(pre[i], inv), zi2 = fq::mul(zi, zi);
+    inv = fq::mul(inv, z[i]);
+    fq::E x, y;
+    std::memcpy(x.l, pts[i].x, 32);
+    std::memcpy(y.l, pts[i].y, 32);
+    const fq::E ax = fq::mul(x, zi2), ay = fq::mul(fq::mul(y, zi2), zi);
+    std::memcpy(out[i].x, ax.l, 32);
+    std::memcpy(out[i].y, ay.l, 32);
+  }
+  return out;
+}
+
 // counter-based SplitMix64 field elements — the stream h2mi_fr_random_dev produces on the device
 inline uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ULL;
@@ -314,17 +339,17 @@ inline void to_poly_and_coset(const poly::EvaluationDomain& dom, const DeviceVec
   const size_t n = (size_t)1 << dom.k();
   poly.reset(new DeviceVec(n));
   coset.reset(new DeviceVec(dom.extended_len()));
-  Fr n_inv = fr::invert(fr::from_u64(n));
-  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly->p, dom.k(), dom.get_omega_inv().l, nullptr, n_inv.l, nullptr), "lagrange_to_coeff");
-  Fr zeta = fr::zeta();
-  check(h2mi_ntt_bn254_fr_oop_dev(poly->p, n, coset->p, dom.extended_k(), dom.get_extended_omega().l, zeta.l, nullptr, nullptr), "coeff_to_extended");
+  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly->p, dom.k(), dom.get_omega_inv().l, nullptr, dom.get_ifft_divisor().l, nullptr), "lagrange_to_coeff");
+  check(h2mi_ntt_bn254_fr_oop_dev(poly->p, n, coset->p, dom.extended_k(), dom.get_extended_omega().l, dom.get_g_coset().l, nullptr, nullptr),
+        "coeff_to_extended");
 }
 inline void to_poly_and_coset_into(const poly::EvaluationDomain& dom, const DeviceVec& lagr, DeviceVec& poly, DeviceVec& coset,
                                    h2mi_stream_t stream = nullptr) {
   const size_t n = (size_t)1 << dom.k();
-  Fr n_inv = fr::invert(fr::from_u64(n)), zeta = fr::zeta();
-  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly.p, dom.k(), dom.get_omega_inv().l, nullptr, n_inv.l, stream), "lagrange_to_coeff");
-  check(h2mi_ntt_bn254_fr_oop_dev(poly.p, n, coset.p, dom.extended_k(), dom.get_extended_omega().l, zeta.l, nullptr, stream), "coeff_to_extended");
+  // the domain holds n^-1 and the coset generator: two 254-bit exponentiations per call otherwise (round 3)
+  check(h2mi_ntt_bn254_fr_oop_dev(lagr.p, n, poly.p, dom.k(), dom.get_omega_inv().l, nullptr, dom.get_ifft_divisor().l, stream), "lagrange_to_coeff");
+  check(h2mi_ntt_bn254_fr_oop_dev(poly.p, n, coset.p, dom.extended_k(), dom.get_extended_omega().l, dom.get_g_coset().l, nullptr, stream),
+        "coeff_to_extended");
 }
 // commit columns (device-resident, n elements) -> affine points on the host
 inline std::vector<G1Affine> commit_points(uint64_t handle, const std::vector<const void*>& cols, size_t n) {
@@ -412,9 +437,12 @@ struct ProverQuery {
   Fr point, eval;
 };
 namespace detail {
-inline std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
+// coefficient lists (low to high) of the Lagrange basis polynomials of `pts`: the part of an interpolation that depends on the
+// points alone — once per rotation set, with ONE inversion, instead of one 254-bit exponentiation per basis polynomial per member
+inline std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
   const size_t m = pts.size();
-  std::vector<Fr> out(m, fr_zero());
+  std::vector<std::vector<Fr>> nums;
+  std::vector<Fr> dens;
   for (size_t j = 0; j < m; j++) {
     std::vector<Fr> num = {fr::ONE};
     Fr den = fr::ONE;
@@ -428,11 +456,21 @@ inline std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector
       num = nxt;
       den = fr::mul(den, fr::sub(pts[j], pts[t]));
     }
-    Fr scale = fr::mul(evals[j], fr::invert(den));
-    for (size_t i = 0; i < num.size(); i++) out[i] = fr::add(out[i], fr::mul(num[i], scale));
+    nums.push_back(num);
+    dens.push_back(den);
   }
+  const std::vector<Fr> inv = fr::batch_invert(dens);
+  for (size_t j = 0; j < m; j++)
+    for (Fr& c : nums[j]) c = fr::mul(c, inv[j]);
+  return nums;
+}
+inline std::vector<Fr> interpolate(const std::vector<std::vector<Fr>>& basis, const std::vector<Fr>& evals) {
+  std::vector<Fr> out(basis.size(), fr_zero());
+  for (size_t j = 0; j < basis.size(); j++)
+    for (size_t i = 0; i < basis[j].size(); i++) out[i] = fr::add(out[i], fr::mul(basis[j][i], evals[j]));
   return out;
 }
+inline std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) { return interpolate(lagrange_basis(pts), evals); }
 inline Fr horner(const std::vector<Fr>& c, const Fr& x) {
   Fr acc = fr_zero();
   for (size_t i = c.size(); i-- > 0;) acc = fr::add(fr::mul(acc, x), c[i]);
@@ -457,14 +495,15 @@ inline void add_head(DeviceVec& poly, const std::vector<Fr>& head, h2mi_stream_t
 inline void kate_chain(DeviceVec& src, size_t n, const std::vector<Fr>& roots, DeviceVec& tmp, DeviceVec& out, h2mi_stream_t stream = nullptr,
                        DeviceVec* tmp2 = nullptr) {
   if (roots.size() >= 2 && roots.size() <= 4) {  // one round: independent divisions weighted by 1 / prod_{k != i} (r_i - r_k)
-    std::vector<Fr> inv, w;
+    std::vector<Fr> both(roots);  // the roots and the partial-fraction denominators, inverted together
     for (size_t i = 0; i < roots.size(); i++) {
       Fr d = fr::ONE;
       for (size_t k = 0; k < roots.size(); k++)
         if (k != i) d = fr::mul(d, fr::sub(roots[i], roots[k]));
-      w.push_back(fr::invert(d));
-      inv.push_back(fr::invert(roots[i]));
+      both.push_back(d);
     }
+    both = fr::batch_invert(both);
+    const std::vector<Fr> inv(both.begin(), both.begin() + roots.size()), w(both.begin() + roots.size(), both.end());
     check(h2mi_fr_kate_division_multi_dev(src.p, n, (const uint64_t*)roots.data(), (const uint64_t*)inv.data(), (const uint64_t*)w.data(), roots.size(),
                                           out.p, stream),
           "kate_division_multi");
@@ -573,8 +612,9 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
     for (auto& m : rs.members) polys.push_back(m.first);
     lincomb(polys, ypow, n, *ssum[i], stream);
     std::vector<Fr> rsum(rs.points.size(), fr_zero());
+    const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points);
     for (size_t j = 0; j < rs.members.size(); j++) {
-      std::vector<Fr> r = interpolate(rs.points, rs.members[j].second);
+      std::vector<Fr> r = interpolate(basis, rs.members[j].second);
       for (size_t t = 0; t < r.size(); t++) rsum[t] = fr::sub(rsum[t], fr::mul(ypow[j], r[t]));
     }
     add_head(*ssum[i], rsum, stream);
@@ -674,7 +714,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   auto write_phase_points = [&](size_t k) {  // join, G1::batch_normalize (host: k modular inversions), write_point
     std::vector<G1> jac(k);
     check(h2mi_memcpy_d2h(jac.data(), points.p, k * 96), "d2h");  // joins the MSM pipeline
-    for (const G1& p : jac) tr.write_point(normalize_host(p));
+    for (const G1Affine& a : normalize_host_batch(jac)) tr.write_point(a);
   };
   auto commit = [&](uint64_t handle, const void* col, size_t slot) { check(h2mi_msm_bn254_g1_dev(handle, col, n, (char*)points.p + 96 * slot, nullptr), "commit"); };
 
@@ -744,18 +784,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     cs.l0 = pk.l0->p;
     cs.l_last = pk.l_last->p;
     cs.l_active = pk.l_active->p;
-    const uint32_t rot = 1u << (d.extended_k() - d.k());
-    const Fr zeta = fr::zeta();
-    std::vector<Fr> t_inv;
-    for (uint32_t i = 0; i < rot; i++) {  // (X^n - 1)^-1 on the coset: 2^(extended_k - k) distinct values
-      Fr X = fr::mul(zeta, fr::pow_u64(d.get_extended_omega(), i));
-      t_inv.push_back(fr::invert(fr::sub(fr::pow_u64(X, n), fr::ONE)));
-    }
+    const Fr& zeta = d.get_g_coset();
+    const std::vector<Fr>& t_inv = d.t_inv();  // (X^n - 1)^-1 on the coset: cached in the domain
     check(h2mi_plonk_evaluate_h_standard_dev(&cs, d.k(), d.extended_k(), bf, beta.l, gamma.l, y.l, delta.l, zeta.l, d.get_extended_omega().l,
                                              (const uint64_t*)t_inv.data(), h.p, nullptr), "evaluate_h");
-    Fr eo_inv = fr::invert(d.get_extended_omega()), zeta_inv = fr::mul(zeta, zeta), en_inv = fr::invert(fr::from_u64(ext));
-    check(h2mi_ntt_bn254_fr_dev(h.p, d.extended_k(), eo_inv.l, nullptr, nullptr, nullptr), "extended_to_coeff");
-    check(h2mi_fr_scale_powers_dev(h.p, ext, zeta_inv.l, en_inv.l, nullptr), "distribute_powers_zeta");
+    check(h2mi_ntt_bn254_fr_dev(h.p, d.extended_k(), d.get_extended_omega_inv().l, nullptr, nullptr, nullptr), "extended_to_coeff");
+    check(h2mi_fr_scale_powers_dev(h.p, ext, d.get_g_coset_inv().l, d.get_extended_ifft_divisor().l, nullptr), "distribute_powers_zeta");
   }
   const uint32_t pieces = StandardPlonk::CS_DEGREE - 1;
   for (uint32_t i = 0; i < pieces; i++) commit(params.g_handle(), (char*)h.p + (size_t)i * n * 32, i);
