@@ -76,6 +76,7 @@ struct Slot {
   uint32_t* bincnt = nullptr;   // [nbins][ntiles] entries per (bin, tile), + 1 trailing zero
   uint32_t* binbase = nullptr;  // its exclusive scan; [nbins * ntiles] = number of entries
   uint32_t* binseg = nullptr;   // sums of the SCAN_SEG_BINS-cell segments of bincnt
+  uint32_t* tile_live = nullptr;  // per partition tile: does it hold a non-zero scalar (k_msm_bin_count -> k_msm_bin_scatter)
   uint32_t* off = nullptr;      // first entry of each bucket in vals[1] (nb+1; last = number of entries)
   uint32_t* s0_dev = nullptr;   // chunk length of this MSM's accumulation (chosen by k_msm_bin_sort)
   uint32_t* np[2] = {nullptr, nullptr};    // per bucket: partial sums the accumulation leaves, fold tasks (nb+1 entries, last = 0)
@@ -302,18 +303,25 @@ __device__ __forceinline__ fe msm_scalar(const fe* scalars, size_t i, size_t n, 
 
 template <uint32_t CT>
 __global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb,
-                                                         uint32_t nbins, uint32_t ntiles, uint32_t* cnt_out) {
+                                                         uint32_t nbins, uint32_t ntiles, uint32_t* cnt_out, uint32_t* tile_live) {
   __shared__ uint32_t cnt[NBINS_MAX];
+  __shared__ uint32_t any_live;
   const uint32_t tid = threadIdx.x;
   if (tid < NBINS_MAX) cnt[tid] = 0;
+  if (tid == 0) any_live = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * P1_TS + tid;
   if (i < n + (shift ? 1 : 0)) {
     fe s = msm_scalar(scalars, i, n, shift);
-    if (!fe_is_zero(s))
+    if (!fe_is_zero(s)) {
+      any_live = 1;  // benign race: every writer stores the same value
       for_each_digit<CT>(s, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&cnt[bin_of<(CT >= WIDE_MIN_C)>(bucket, lb)], 1u); });
+    }
   }
   __syncthreads();
+  // a tile of zero scalars (most tiles of a sparse column) has nothing to scatter: k_msm_bin_scatter returns on this flag before
+  // it reads a single scalar — the partition of a sparse column is then ONE pass over the scalars, not two
+  if (tid == 0) tile_live[blockIdx.x] = any_live;
   if (tid < nbins) cnt_out[(size_t)tid * ntiles + blockIdx.x] = cnt[tid];
   if (blockIdx.x == 0 && tid == 0) cnt_out[(size_t)nbins * ntiles] = 0;  // the scan leaves the total there
 }
@@ -323,8 +331,9 @@ extern __shared__ uint4 h2_msm_smem[];
 template <uint32_t CT>
 __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W,
                                                            uint32_t lb, uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
-                                                           void* keys_out_) {
+                                                           void* keys_out_, const uint32_t* tile_live) {
   constexpr bool WIDE = CT >= WIDE_MIN_C;  // in-bin keys of up to 10 bits: staged and written as 16-bit values
+  if (!tile_live[blockIdx.x]) return;  // no non-zero scalar in this tile (k_msm_bin_count): block-uniform, before any barrier
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
   uint32_t* stage_val = reinterpret_cast<uint32_t*>(h2_msm_smem);             // P1_TS * W payloads
   uint16_t* stage_key = reinterpret_cast<uint16_t*>(stage_val + P1_TS * W);   // P1_TS * W bucket ids
@@ -1039,7 +1048,7 @@ static void free_bases(Bases* B) {
   hipFree(B->host_stage);
   for (Slot& S : B->slot) {
     hipFree(S.vals[0]); hipFree(S.vals[1]);
-    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.binseg);
+    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.binseg); hipFree(S.tile_live);
     hipFree(S.off); hipFree(S.s0_dev);
     for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
     hipFree(S.dense); hipFree(S.dense2); hipFree(S.vsum); hipFree(S.tseg[0]); hipFree(S.tseg[1]);
@@ -1098,6 +1107,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     H2_ALLOC(S.bincnt, bin_cells * 4);
     H2_ALLOC(S.binbase, bin_cells * 4);
     H2_ALLOC(S.binseg, (bin_cells / SCAN_SEG_BINS + 2) * 4);
+    H2_ALLOC(S.tile_live, (ntiles_max + 1) * 4);
     H2_ALLOC(S.off, (size_t)(B->nb + 1) * 4);
     H2_ALLOC(S.s0_dev, 4);
     for (int i = 0; i < 2; i++) {
@@ -1274,10 +1284,10 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     // the partition's first level reads the scalars twice (count, scatter): both stay on s, so work queued
     // on s after this call may overwrite them
 #define H2_BIN_COUNT(CT) \
-  H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, shift, B->c, W, B->lb, B->nbins, ntiles, S.bincnt)
+  H2_LAUNCH("k_msm_bin_count", k_msm_bin_count<CT>, ntiles, P1_TS, 0, s, (const fe*)d_scalars, n, shift, B->c, W, B->lb, B->nbins, ntiles, S.bincnt, S.tile_live)
 #define H2_BIN_SCATTER(CT)                                                                                                                        \
   H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter<CT>, ntiles, P1_TS, (size_t)P1_TS * W * 6, s, (const fe*)d_scalars, n, shift, B->stride, B->c, W, \
-            B->lb, B->nbins, ntiles, (const uint32_t*)S.binbase, S.vals[0], S.bkeys)
+            B->lb, B->nbins, ntiles, (const uint32_t*)S.binbase, S.vals[0], S.bkeys, (const uint32_t*)S.tile_live)
     if (shifted) H2_LAUNCH("k_msm_pick_shift", k_msm_pick_shift, 1, 64, 0, s, (const fe*)d_scalars, n, S.shift);
     switch (B->c) {
       case 13: H2_BIN_COUNT(13); break;
