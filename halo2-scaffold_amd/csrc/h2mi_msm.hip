@@ -98,10 +98,11 @@ struct Slot {
   uint32_t tasks1 = 0;          // its fold grid bound
 };
 // slots per handle = MSMs that can be in flight between two joins before a flush is forced
-// Eight for base sets up to 2^22 (round 3): with four, every fifth back-to-back MSM waited for the reduction batch of the four
-// before it — the pipeline drained every four MSMs (2^17: 290 us per MSM with four slots; the accumulation alone is 167 us).
-// A prover phase queues at most four commitments, so this matters to commitment streams (keygen, many-column circuits), not to
-// the proofs measured here.  Beyond 2^22 a slot is > 1 GB: four.
+// Eight for base sets up to 2^17 (round 3): with four, every fifth back-to-back MSM waited for the reduction batch of the four
+// before it — the pipeline drained every four MSMs (2^17: 290 -> 262 us per MSM, 2^16: 214 -> 171, 2^14: 134 -> 105; the
+// accumulation alone is 167 us at 2^17).  A prover phase queues at most four commitments, so this matters to commitment streams
+// (keygen, many-column circuits, 8-GPU slices), not to the proofs measured here.  From 2^18 four: the 2^20 replay step was 1 %
+// SLOWER with eight (19.6 - 19.7 vs 19.8 - 19.9 ms, three alternating pairs on one box: twice the workspace to walk through).
 constexpr int NSLOT = 8;
 
 struct Bases {
@@ -1099,7 +1100,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   // the own scans (k_scan_seg) take 16-byte vectors: the [bin][tile] matrix has 512 rows and the task arrays
   // 2^(c-1) >= 1024 entries for every window width pick_window() can return
   if ((B->nbins & 3u) || B->nb < 4 || (B->nb > SCAN_SEG_TASKS && !B->seg_log) || B->nbins > NBINS_MAX || (1u << B->lb) > NQW) { free_bases(B); return H2MI_ERANGE; }
-  B->nslot = n > ((size_t)1 << 22) ? 4 : NSLOT;
+  B->nslot = n > ((size_t)1 << 17) ? 4 : NSLOT;
+  if (const char* ev = getenv("H2MI_MSM_SLOTS"))  // A/B knob
+    if (atoi(ev) >= 2 && atoi(ev) <= NSLOT) B->nslot = atoi(ev);
   for (int si_ = 0; si_ < B->nslot; si_++) {
     Slot& S = B->slot[si_];
     for (int i = 0; i < 2; i++) H2_ALLOC(S.vals[i], nW * 4);
