@@ -280,7 +280,10 @@ int h2mi_plonk_lookup_permute_dev(const void* d_input, const void* d_table_sorte
 int h2mi_plonk_instance_coset_dev(const void* d_l0_coset, uint32_t k, uint32_t extended_k, const uint64_t* values, size_t count, void* d_out,
                                   h2mi_stream_t stream);
 /* commit_product: z[0] = 1, z[i+1] = z[i] (a_i + beta)(t_i + gamma) / ((a'_i + beta)(s'_i + gamma)), i < usable_rows;
- * blinding rows untouched; one field inversion per call */
+ * blinding rows untouched; one field inversion per call.  From 4096 usable rows the product runs over the rows whose ratio can
+ * differ from one ((a_i, t_i) != (a'_i, s'_i): all but ~2^17 of 2^22 rows of a range check are skipped) when they are at most
+ * a quarter of all rows; the call reads that count back, i.e. it waits for the work queued on `stream` before it (the library's
+ * other streams keep running) */
 int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input, const void* d_permuted_table, uint32_t k,
                                   uint32_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], void* d_z, h2mi_stream_t stream);
 /* evaluate_h + vanishing division for the halo2-lib constraint systems [halo2-base shapes restated from memory]: gate
