@@ -463,7 +463,10 @@ __global__ void __launch_bounds__(256) k_instance_coset(const fe* l0, uint32_t e
   f29 acc = f29_zero();
 #pragma unroll
   for (uint32_t r = 0; r < 16; r++)  // unrolled: a run-time index into the by-value argument would send it through scratch
-    if (r < count) acc = f29_add(acc, f29_mul<F9>(load_unpack(&l0[(j + size - r * rot) & (size - 1)]), f29_unpack(a.v[r].v)));
+    if (r < count) {
+      acc = f29_add(acc, f29_mul<F9>(load_unpack(&l0[(j + size - r * rot) & (size - 1)]), f29_unpack(a.v[r].v)));
+      if ((r & 3u) == 3u) acc = f29_normalize(acc);  // four normalized addends at most between carries (limbs stay below 2^32)
+    }
   fe o;
   f29_pack(f29_reduce_loose<F9>(f29_normalize(acc)), o.v);
   fe_store(&out[j], o);

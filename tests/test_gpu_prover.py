@@ -334,3 +334,57 @@ def test_kate_division_multi_matches_chained_divisions(gpu, n, m):
     assert gpu.lib.h2mi_fr_kate_division_multi_dev(d_in.ptr, n, rl.ctypes.data, ri.ctypes.data, wl.ctypes.data, 5, d_out.ptr, None) == -1
     d_in.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("k,degree,count", [(5, 3, 1), (6, 5, 3), (7, 3, 16), (6, 5, 0)])
+def test_instance_coset_matches_transforms(gpu, k, degree, count):
+    """h2mi_plonk_instance_coset_dev: the extended-coset form of an instance column holding `count` public inputs, formed from
+    l_0's coset (sum_r v_r * l0_coset[(j - r rot) mod 2^ext_k]), equals coeff_to_extended(lagrange_to_coeff(column)) of the
+    oracle's EvaluationDomain value for value."""
+    from halo2_scaffold_amd import field as F
+
+    d = o.Domain(k, degree)
+    n, ext = 1 << k, 1 << d.extended_k
+    l0 = d.coeff_to_extended(d.lagrange_to_coeff([1] + [0] * (n - 1)))
+    vals = o.unpack(o.random_field_limbs(max(count, 1), 321 + k), o.R)[:count]
+    want = d.coeff_to_extended(d.lagrange_to_coeff(vals + [0] * (n - count)))
+    d_l0 = gpu.DevBuf.from_numpy(o.pack(l0, o.R))
+    d_out = gpu.DevBuf(ext * 32)
+    vl = np.ascontiguousarray(np.stack([F.fr_to_mont_limbs(v) for v in vals])) if count else np.zeros((1, 4), dtype=np.uint64)
+    assert gpu.lib.h2mi_plonk_instance_coset_dev(d_l0.ptr, k, d.extended_k, vl.ctypes.data, count, d_out.ptr, None) == 0
+    assert _vals(d_out, ext) == want
+    assert gpu.lib.h2mi_plonk_instance_coset_dev(d_l0.ptr, k, d.extended_k, vl.ctypes.data, 17, d_out.ptr, None) == -1
+    d_l0.free()
+    d_out.free()
+
+
+def test_lookup_product_sparse_equals_dense(gpu):
+    """the lookup grand product over the flagged rows only (rows whose ratio differs from one) against the dense form of the
+    same call (H2MI_LOOKUP_DENSE in a child process would need a second library instance: instead both are compared with the
+    oracle's row-by-row product) at a size where the sparse form is taken: k = 13, a range-check-like input (a handful of limbs,
+    zeros elsewhere) in a 2^8-row table."""
+    from halo2_scaffold_amd import plonk as gp
+    from oracle import lookup as L
+
+    k, bits = 13, 8
+    n = 1 << k
+    u = n - 7
+    inputs = [0] * u
+    for i, v in enumerate([3, 200, 255, 17, 17, 0, 99]):
+        inputs[5 + 3 * i] = v
+    table = list(range(1 << bits)) + [0] * (u - (1 << bits))
+    blind = o.unpack(o.random_field_limbs(14, 5), o.R)
+    a_perm, s_perm = L.permute_expression_pair(inputs, table, u, blind[:7], blind[7:])
+    beta, gamma = 0x1234567 % o.R, 0x7654321 % o.R
+    want = L.lookup_product(inputs, table, a_perm, s_perm, beta, gamma, u, o.unpack(o.random_field_limbs(6, 9), o.R))
+    pad = lambda col: gpu.DevBuf.from_numpy(o.pack(list(col) + [0] * (n - len(col)), o.R))
+    d_in, d_tab, d_ap, d_sp = pad(inputs), pad(table), pad(a_perm), pad(s_perm)
+    d_z = gpu.DevBuf.from_numpy(o.pack([0xDEAD] * n, o.R))
+    gp.lookup_product(k, d_in, d_tab, d_ap, d_sp, beta, gamma, u, d_z)
+    got = _vals(d_z, n)
+    assert got[: u + 1] == want[: u + 1]           # z_0 .. z_u; the blinding rows are the caller's
+    assert got[u + 1 :] == [0xDEAD] * (n - u - 1)
+    changes = sum(1 for i in range(u) if want[i + 1] != want[i])
+    assert 0 < changes <= 2 * (1 << bits) + 16       # the product moves on a few hundred of 8185 rows: the sparse form was taken
+    for b in (d_in, d_tab, d_ap, d_sp, d_z):
+        b.free()
