@@ -216,11 +216,12 @@ def main():
     }
 
     # the binding resource, stated next to the (contractual) HBM roofline: 32-bit integer multiply issue.
-    # One mixed addition = 8 multiplications + 2 squarings in 9 x 29-bit limbs = 1548 v_mad_u64_u32; the peak
+    # One mixed addition = 6 multiplications + 2 squarings + one two-product multiplication with a shared reduction (Y3) in
+    # 9 x 29-bit limbs = 6 * 162 + 2 * 126 + 243 = 1467 v_mad_u64_u32 (1548 before round 3's f29_mul2); the peak
     # is the chip's measured v_mad_u64_u32 rate (tools/ubench.hip: 4.82 cycles per wavefront instruction per
     # SIMD at 2.4 GHz = 32.6 T lane-multiplies/s).  Other instructions of the loop (masks, shifts, the m = t * p'
     # products) share the same issue port, so ~0.7 is the practical ceiling of this fraction.
-    MADS_PER_MIXED_ADD, MAD_PEAK = 1548, 32.6e12
+    MADS_PER_MIXED_ADD, MAD_PEAK = 1467, 32.6e12
     entries_per_launch = adds_local / max(shape.msm_per_proof, 1)  # bucket insertions (+ reduction adds) per MSM, this rank
     issue = {
         "kernel": "k_msm_accum",

@@ -10,8 +10,9 @@
 //     P  = U2 - X + 6p < 7.007      R  = S2 - Y + 4p < 5.014          (normalized before squaring)
 //     PP = P^2 < 1.29               PPP = P*PP < 1.054                Q = X*PP < 1.046
 //     RR = R^2 < 1.149              X3 = RR - PPP - 2Q + 4p < 5.149   (< 6: invariant holds)
-//     T  = Q - X3 + 6p < 7.05 (lazy operand)   T1 = R*T < 1.209       T2 = Y*PPP < 1.025
-//     Y3 = T1 - T2 + 2p < 3.209    (< 4: invariant holds)             ZZ3, ZZZ3 < 1.01
+//     T  = Q - X3 + 6p < 7.05 (lazy operand)   Y' = 4p - Y < 4 (lazy operand)
+//     Y3 = (T*R + Y'*PPP) / 2^261 < 1 + eps * (35.4 + 4.3) = 1.24  (< 4: invariant holds; one reduction, f29_mul2)
+//     ZZ3, ZZZ3 < 1.01
 #pragma once
 #include "f29.cuh"
 
@@ -46,9 +47,7 @@ H2_HD xyzz29 xyzz29_dbl_affine(const f29& x, const f29& y_any) {
   f29 mm = f29_sqr<F>(m);                                      // (< 1.06)
   r.x = f29_normalize(f29_sub(mm, f29_dbl(s), F::KW4));        // X3 = M^2 - 2S + 4p (< 5.1); 2S limbs < 2^30
   f29 t = f29_sub(s, r.x, F::K6);                              // S - X3 + 6p  (lazy, < 7.1)
-  f29 t1 = f29_mul<F>(t, m);
-  f29 t2 = f29_mul<F>(w, y);
-  r.y = f29_normalize(f29_sub(t1, t2, F::K2));                 // (< 3.1)
+  r.y = f29_mul2<F>(t, m, f29_sub(f29_zero(), y, F::K4), w);   // (T*M + (4p - Y)*W) / 2^261  (< 1.2)
   r.zz = v;
   r.zzz = w;
   return r;
@@ -83,17 +82,16 @@ H2_HD void xyzz29_madd(xyzz29& acc, const f29& x2, const f29& y2) {
   f29 sub3 = f29_add(ppp, f29_dbl(q));
   f29 x3 = f29_normalize(f29_sub(rr, sub3, F::KW4));
   f29 t = f29_sub(q, x3, F::K6);  // lazy operand (limbs < 1.5 * 2^30)
-  f29 t1 = f29_mul<F>(t, r);
-  f29 t2 = f29_mul<F>(acc.y, ppp);
+  f29 ny = f29_sub(f29_zero(), acc.y, F::K4);  // 4p - Y (lazy, limbs < 2^30)
   acc.x = x3;
-  acc.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  acc.y = f29_mul2<F>(t, r, ny, ppp);  // Y3 = (T*R + (4p - Y)*PPP) / 2^261: one reduction for both products
   acc.zz = f29_mul<F>(acc.zz, pp);
   acc.zzz = f29_mul<F>(acc.zzz, ppp);
 }
 
 // 2 * p (XYZZ, dbl-2008-s-1).  Invariant in / out: X < 6, Y < 4, ZZ, ZZZ < 1.5 (units of p), normalized.
 //   U = 2Y < 8    V = U^2 < 1.38    W = U*V < 1.07    S = X*V < 1.05    M = 3X^2 < 3.64
-//   X3 = M^2 - 2S + 4p < 5.1    T = S - X3 + 6p < 7.1    Y3 = M*T - W*Y + 2p < 3.2    ZZ3, ZZZ3 < 1.02
+//   X3 = M^2 - 2S + 4p < 5.1    T = S - X3 + 6p < 7.1    Y3 = (M*T + W*(4p - Y)) / 2^261 < 1.2    ZZ3, ZZZ3 < 1.02
 H2_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
   using F = Fq29;
   if (xyzz29_is_identity(p)) return p;
@@ -107,9 +105,7 @@ H2_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
   f29 mm = f29_sqr<F>(m);
   r.x = f29_normalize(f29_sub(mm, f29_dbl(s), F::KW4));
   f29 t = f29_sub(s, r.x, F::K6);
-  f29 t1 = f29_mul<F>(t, m);
-  f29 t2 = f29_mul<F>(w, p.y);
-  r.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  r.y = f29_mul2<F>(t, m, f29_sub(f29_zero(), p.y, F::K4), w);  // Y3 = (T*M + (4p - Y)*W) / 2^261 < 1.2: one reduction
   r.zz = f29_mul<F>(v, p.zz);
   r.zzz = f29_mul<F>(w, p.zzz);
   return r;
@@ -118,7 +114,7 @@ H2_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
 // a += b (both XYZZ, add-2008-s, complete).  Same invariant as xyzz29_dbl.
 //   U1, U2 < 1.06   S1, S2 < 1.04   P = U2 - U1 + 2p < 3.1   R = S2 - S1 + 2p < 3.1
 //   PP < 1.06  PPP < 1.02  Q = U1*PP < 1.01  X3 = R^2 - PPP - 2Q + 4p < 5.1
-//   T = Q - X3 + 6p < 7.1   Y3 = R*T - S1*PPP + 2p < 3.2
+//   T = Q - X3 + 6p < 7.1   Y3 = (R*T + (2p - S1)*PPP) / 2^261 < 1.2
 H2_HD void xyzz29_add(xyzz29& a, const xyzz29& b) {
   using F = Fq29;
   if (xyzz29_is_identity(b)) return;
@@ -141,12 +137,10 @@ H2_HD void xyzz29_add(xyzz29& a, const xyzz29& b) {
   f29 rr = f29_sqr<F>(r);
   f29 x3 = f29_normalize(f29_sub(rr, f29_add(ppp, f29_dbl(q)), F::KW4));
   f29 t = f29_sub(q, x3, F::K6);
-  f29 t1 = f29_mul<F>(t, r);
-  f29 t2 = f29_mul<F>(s1, ppp);
   f29 zz = f29_mul<F>(f29_mul<F>(a.zz, b.zz), pp);
   f29 zzz = f29_mul<F>(f29_mul<F>(a.zzz, b.zzz), ppp);
   a.x = x3;
-  a.y = f29_normalize(f29_sub(t1, t2, F::K2));
+  a.y = f29_mul2<F>(t, r, f29_sub(f29_zero(), s1, F::K2), ppp);  // Y3 = (T*R + (2p - S1)*PPP) / 2^261 < 1.2: one reduction
   a.zz = zz;
   a.zzz = zzz;
 }

@@ -1034,7 +1034,10 @@ static uint32_t pick_window(size_t n) {
   // Smaller sizes, same sweep (`tools/msm_sweep.py`, back-to-back / latency in us): 2^17: c = 13: 307 / 517, 15: 287 / 494,
   // 16: 286 / 476; 2^18: 15: 475 / 706, 16: 458 / 666; 2^19: 15: 832 / 1112, 16: 809 / 1058; 2^15: 13: 180 / 334, 16: 164 /
   // 324; 2^14: 13: 149 / 296, 15: 135 / 282, 16: 153 / 309; 2^10: 13 is best.  (c = 14 leaves a 3-bit top window: 50 % slower.)
-  int c = lg >= 22 ? 20 : lg >= 21 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
+  // Round 3, after the shared-reduction Y3 (f29_mul2) and the cheaper reductions: c = 17 re-measured against 16, alternating on one
+  // box: 2^20: create_proof 13.2 - 14.4 -> 12.8 - 13.0 ms (minimum of 12), replay step 19.2 - 19.9 -> 18.8 - 19.1 ms; 2^19: neutral
+  // (MSM 764 -> 732 us back-to-back, proofs 8.0 - 8.2 either way); 2^18 and 2^17: 16 stays (434 -> 455, 249 -> 266 us) — 17 from 2^20.
+  int c = lg >= 22 ? 20 : lg >= 20 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
   return (uint32_t)c;
 }
 

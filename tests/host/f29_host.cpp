@@ -53,6 +53,18 @@ void f29t_reduce_loose(int field, const uint32_t* in, uint32_t* out, size_t n) {
   }
 }
 
+// f29_mul2 on raw limb patterns (9 words each): out = (a*b + c*d) / 2^261, normalized limbs
+void f29t_mul2_raw(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    f29 x[4], r;
+    const uint32_t* src[4] = {a, b, c, d};
+    for (int q = 0; q < 4; q++)
+      for (int k = 0; k < 9; k++) x[q].v[k] = src[q][9 * i + k];
+    r = field == 0 ? f29_mul2<Fq29>(x[0], x[1], x[2], x[3]) : f29_mul2<Fr29>(x[0], x[1], x[2], x[3]);
+    for (int k = 0; k < 9; k++) out[9 * i + k] = r.v[k];
+  }
+}
+
 // accumulate n affine points (Mont256, 16 words each; (0,0) skipped) with signs[i] != 0 meaning -P_i;
 // writes the XYZZ result as 4 x 8 words Mont256 (canonical)
 void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz, int tree) {

@@ -167,3 +167,29 @@ def test_extreme_limb_patterns(host):
         assert o.unpack(out, mod) == [(x + y) * (x - y) % mod for x, y in zip(av, bv)]
         host.f29t_mul(field, 4, A.ctypes.data, B.ctypes.data, out.ctypes.data, n)
         assert o.unpack(out, mod) == [x * x % mod for x in av]
+
+
+def test_mul2_shared_reduction_at_the_contract_limits(host):
+    """f29_mul2 = (a b + c d) / 2^261 with one reduction (the Y3 of the mixed addition): random operands and the
+    largest limbs its contract allows (a < 1.5 * 2^30, c < 2^30, b and d < 2^29 per limb) — the 64-bit column
+    accumulators must not wrap."""
+    host.f29t_mul2_raw.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_size_t]
+    rng = np.random.default_rng(29)
+    n = 4000
+    lim = {"a": 3 << 29, "b": 1 << 29, "c": 1 << 30, "d": 1 << 29}
+    ops = {k: rng.integers(0, v, size=(n, 9), dtype=np.uint32) for k, v in lim.items()}
+    for k, v in lim.items():
+        ops[k][:8] = v - 1        # every limb at its maximum, all four operands together
+        ops[k][8:16, ::2] = v - 1
+    ops["b"][:, 8] &= (1 << 25) - 1  # top limbs of normalized values below 8p
+    ops["d"][:, 8] &= (1 << 25) - 1
+    val = lambda row: sum(int(x) << (29 * i) for i, x in enumerate(row))
+    for field, mod in [(0, o.Q), (1, o.R)]:
+        out = np.zeros((n, 9), dtype=np.uint32)
+        host.f29t_mul2_raw(field, ops["a"].ctypes.data, ops["b"].ctypes.data, ops["c"].ctypes.data, ops["d"].ctypes.data, out.ctypes.data, n)
+        assert (out[:, :8] < (1 << 29)).all()
+        for i in range(n):
+            a, b, c, d = (val(ops[k][i]) for k in "abcd")
+            got = val(out[i])
+            assert got * (1 << 261) % mod == (a * b + c * d) % mod
+            assert got < (a * b + c * d) // (1 << 261) + mod + 1
