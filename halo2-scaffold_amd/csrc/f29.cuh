@@ -123,66 +123,9 @@ H2_HD void f29_mac_first(uint64_t& acc, uint32_t x, uint32_t y) {
 #endif
 }
 
-#if defined(H2_F29_SEQ)
-// experiment: every column ONE dependent chain of multiply-adds (every other one as inline asm, so that the compiler can neither
-// split the chain nor see two asm statements back to back)
-template <int T>
-H2_HD void f29_mac_seq(uint64_t& acc, uint32_t x, uint32_t y) {
-  if constexpr ((T & 1) == 0) f29_mac_first(acc, x, y);
-  else acc += (uint64_t)x * y;
-}
-template <class F, int K, int J = 0>
-H2_HD void f29_col_lo(uint64_t& acc, const f29& a, const f29& b, const uint32_t (&m)[9]) {  // column K < 9
-  if constexpr (J <= K) {
-    f29_mac_seq<J>(acc, a.v[J], b.v[K - J]);
-    f29_col_lo<F, K, J + 1>(acc, a, b, m);
-  } else if constexpr (J <= 2 * K) {
-    f29_mac_seq<J>(acc, m[J - K - 1], F::P[K - (J - K - 1)]);
-    f29_col_lo<F, K, J + 1>(acc, a, b, m);
-  }
-}
-template <class F, int K, int J = 0>
-H2_HD void f29_col_hi(uint64_t& acc, const f29& a, const f29& b, const uint32_t (&m)[9]) {  // column 9 <= K < 17
-  constexpr int N = 17 - K;  // products of each kind: j = K-8 .. 8
-  if constexpr (J < N) {
-    f29_mac_seq<J>(acc, a.v[K - 8 + J], b.v[8 - J]);
-    f29_col_hi<F, K, J + 1>(acc, a, b, m);
-  } else if constexpr (J < 2 * N) {
-    f29_mac_seq<J>(acc, m[K - 8 + (J - N)], F::P[8 - (J - N)]);
-    f29_col_hi<F, K, J + 1>(acc, a, b, m);
-  }
-}
-template <class F, int K = 0>
-H2_HD void f29_mul_cols(uint64_t& acc, const f29& a, const f29& b, uint32_t (&m)[9], f29& t) {
-  if constexpr (K < 9) {
-    f29_col_lo<F, K>(acc, a, b, m);
-    m[K] = ((uint32_t)acc * F::INV) & M29;
-    acc += (uint64_t)m[K] * F::P[0];
-    acc >>= 29;
-    f29_mul_cols<F, K + 1>(acc, a, b, m, t);
-  } else if constexpr (K < 17) {
-    f29_col_hi<F, K>(acc, a, b, m);
-    t.v[K - 9] = (uint32_t)acc & M29;
-    acc >>= 29;
-    f29_mul_cols<F, K + 1>(acc, a, b, m, t);
-  }
-}
-template <class F>
-H2_HD f29 f29_mul(const f29& a, const f29& b) {
-  uint32_t m[9];
-  f29 t;
-  uint64_t acc = 0;
-  f29_mul_cols<F>(acc, a, b, m, t);
-  t.v[8] = (uint32_t)acc;
-  return t;
-}
-template <class F>
-H2_HD f29 f29_mul_unused(const f29& a, const f29& b) {
-#else
 // Montgomery product a * b / 2^261 mod p (loosely reduced), output normalized.
 template <class F>
 H2_HD f29 f29_mul(const f29& a, const f29& b) {
-#endif
   uint32_t m[9];
   f29 t;
   uint64_t acc = 0;
@@ -326,6 +269,7 @@ H2_HD f29 f29_reduce_loose(const f29& a) {
 // is x == 0 mod p, for normalized x with value < 2p
 template <class F>
 H2_HD bool f29_is_zero_mod(const f29& a) {
+  if (a.v[0] != 0 && a.v[0] != F::P[0]) return false;  // all but 2^-28 of the values: two compares instead of 27 or / xor
   uint32_t z = 0, e = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
