@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of two builds of libh2mi.so on one box, interleaved (box-to-box variation is +-4 %): put the build to compare against next to the
+# library as halo2-scaffold_amd/libh2mi.so.prev (git-ignored, travels with gpurun) and run `gpurun -- bash tools/ab_lib.sh`.
 cd $GRAFT_REPO_ROOT
 L=halo2-scaffold_amd/libh2mi.so
 cp $L /tmp/new.so; cp $L.prev /tmp/old.so
