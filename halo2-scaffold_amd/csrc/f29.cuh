@@ -189,6 +189,45 @@ H2_HD f29 f29_mul2(const f29& a, const f29& b, const f29& c, const f29& d) {
   t.v[8] = (uint32_t)acc;
   return t;
 }
+// (a b + c d + e f) / 2^261 with one reduction — the dot products of the polynomial helpers (three terms of a linear combination).
+// Contract: all six operands normalized (limbs < 2^29): a column holds at most 27 * 2^58 + 9 * 2^58 = 36 * 2^58 < 2^64.
+template <class F>
+H2_HD f29 f29_mul3(const f29& a, const f29& b, const f29& c, const f29& d, const f29& e, const f29& f) {
+  uint32_t m[9];
+  f29 t;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    f29_mac_first(acc, a.v[0], b.v[k]);
+#pragma unroll
+    for (int j = 1; j <= k; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+#pragma unroll
+    for (int j = 0; j <= k; j++) acc += (uint64_t)c.v[j] * d.v[k - j];
+#pragma unroll
+    for (int j = 0; j <= k; j++) acc += (uint64_t)e.v[j] * f.v[k - j];
+#pragma unroll
+    for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P[k - j];
+    m[k] = ((uint32_t)acc * F::INV) & M29;
+    acc += (uint64_t)m[k] * F::P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    f29_mac_first(acc, a.v[k - 8], b.v[8]);
+#pragma unroll
+    for (int j = k - 7; j < 9; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+#pragma unroll
+    for (int j = k - 8; j < 9; j++) acc += (uint64_t)c.v[j] * d.v[k - j];
+#pragma unroll
+    for (int j = k - 8; j < 9; j++) acc += (uint64_t)e.v[j] * f.v[k - j];
+#pragma unroll
+    for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * F::P[k - j];
+    t.v[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  t.v[8] = (uint32_t)acc;
+  return t;
+}
 // a^2 / 2^261: the 36 cross products are taken once against 2a (limbs < 2^30) instead of twice,
 // 45 + 81 multiply-adds instead of 162.  Requires a normalized (limbs < 2^29).
 template <class F>

@@ -546,20 +546,29 @@ __global__ void __launch_bounds__(256) k_kate_finish_multi(const fe* local, cons
 constexpr uint32_t LINCOMB_MAX = 24;
 struct LincombArgs {
   const fe* poly[LINCOMB_MAX];
-  fe scalar[LINCOMB_MAX];  // Mont256
+  f29 scalar[LINCOMB_MAX];  // Montgomery-2^261 limbs, converted on the host: data (2^256 words as they lie) x scalar stays 2^256
   uint32_t count;
 };
+// out = sum_k scalar_k poly_k: terms in groups of three sharing ONE Montgomery reduction (f29_mul3: 108 instead of 162
+// multiply-adds per term), scalars already in the multiplier's radix (round 3: the kernel converted every scalar per thread
+// and term — a second multiplication per term on the vector unit, not the scalar unit as its comment claimed).
 __global__ void __launch_bounds__(256) k_lincomb(LincombArgs args, size_t n, fe* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   f29 acc = f29_zero();
-  for (uint32_t k = 0; k < args.count; k++) {
-    f29 s = f29_from_mont256<F9>(args.scalar[k].v);  // uniform: evaluated on the scalar unit
-    f29 t = f29_mul<F9>(load_unpack(&args.poly[k][i]), s);
-    acc = f29_normalize(f29_add(acc, t));            // < 24 * 1.01p, far below the 169p capacity
+  uint32_t k = 0;
+  for (; k + 3 <= args.count; k += 3) {
+    f29 t = f29_mul3<F9>(load_unpack(&args.poly[k][i]), args.scalar[k], load_unpack(&args.poly[k + 1][i]), args.scalar[k + 1],
+                         load_unpack(&args.poly[k + 2][i]), args.scalar[k + 2]);
+    acc = f29_normalize(f29_add(acc, t));  // each group < 1.02p: at most 8 groups, < 8.2p
   }
-  f29 r = f29_mul<F9>(acc, f29_const<F9>(F9::ONE));  // back below 2p
-  pack_store(&out[i], r);
+  if (args.count - k == 2)
+    acc = f29_normalize(f29_add(acc, f29_mul2<F9>(load_unpack(&args.poly[k][i]), args.scalar[k], load_unpack(&args.poly[k + 1][i]), args.scalar[k + 1])));
+  else if (args.count - k == 1)
+    acc = f29_normalize(f29_add(acc, f29_mul<F9>(load_unpack(&args.poly[k][i]), args.scalar[k])));
+  fe o;
+  f29_pack(f29_reduce_loose<F9>(acc), o.v);  // < 10p -> canonical without a multiplication
+  fe_store(&out[i], o);
 }
 
 // out[i] = value
@@ -1748,7 +1757,8 @@ int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, siz
   for (size_t k = 0; k < count; k++) {
     if (!d_polys[k]) return H2MI_EINVAL;
     args.poly[k] = (const fe*)d_polys[k];
-    args.scalar[k] = host_fe(scalars + 4 * k);
+    const fe sc = host_fe(scalars + 4 * k);
+    args.scalar[k] = f29_from_mont256<F9>(sc.v);  // host-side: the same header code
   }
   H2_LAUNCH("k_lincomb", k_lincomb, ceil_div_u32(n, 256), 256, 0, s, args, n, (fe*)d_out);
   return H2MI_OK;

@@ -65,6 +65,17 @@ void f29t_mul2_raw(int field, const uint32_t* a, const uint32_t* b, const uint32
   }
 }
 
+// f29_mul3 on raw limb patterns (six operands, 9 words each): out = (a*b + c*d + e*f) / 2^261
+void f29t_mul3_raw(int field, const uint32_t* ops /* [6][n][9] */, uint32_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    f29 x[6], r;
+    for (int q = 0; q < 6; q++)
+      for (int k = 0; k < 9; k++) x[q].v[k] = ops[((size_t)q * n + i) * 9 + k];
+    r = field == 0 ? f29_mul3<Fq29>(x[0], x[1], x[2], x[3], x[4], x[5]) : f29_mul3<Fr29>(x[0], x[1], x[2], x[3], x[4], x[5]);
+    for (int k = 0; k < 9; k++) out[9 * i + k] = r.v[k];
+  }
+}
+
 // accumulate n affine points (Mont256, 16 words each; (0,0) skipped) with signs[i] != 0 meaning -P_i;
 // writes the XYZZ result as 4 x 8 words Mont256 (canonical)
 void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz, int tree) {

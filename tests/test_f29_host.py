@@ -193,3 +193,26 @@ def test_mul2_shared_reduction_at_the_contract_limits(host):
             got = val(out[i])
             assert got * (1 << 261) % mod == (a * b + c * d) % mod
             assert got < (a * b + c * d) // (1 << 261) + mod + 1
+
+
+def test_mul3_shared_reduction_at_the_contract_limits(host):
+    """f29_mul3 = (a b + c d + e f) / 2^261 (three terms of a linear combination, one reduction): every limb of all six
+    operands at 2^29 - 1 and random normalized operands."""
+    host.f29t_mul3_raw.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(31)
+    n = 3000
+    ops = rng.integers(0, 1 << 29, size=(6, n, 9), dtype=np.uint32)
+    ops[:, :8, :] = (1 << 29) - 1
+    ops[:, 8:16, ::2] = (1 << 29) - 1
+    ops[:, 16:, 8] &= (1 << 25) - 1
+    val = lambda row: sum(int(x) << (29 * i) for i, x in enumerate(row))
+    for field, mod in [(0, o.Q), (1, o.R)]:
+        out = np.zeros((n, 9), dtype=np.uint32)
+        host.f29t_mul3_raw(field, ops.ctypes.data, out.ctypes.data, n)
+        assert (out[:, :8] < (1 << 29)).all()
+        for i in range(n):
+            v = [val(ops[q, i]) for q in range(6)]
+            want = v[0] * v[1] + v[2] * v[3] + v[4] * v[5]
+            got = val(out[i])
+            assert got * (1 << 261) % mod == want % mod
+            assert got < want // (1 << 261) + mod + 1

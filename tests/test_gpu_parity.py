@@ -579,13 +579,21 @@ def test_eval_polynomial_and_kate_division(gpu, n):
         assert ((z - b) * o.eval_polynomial(q, z) + o.eval_polynomial(vals, b)) % o.R == o.eval_polynomial(vals, z)
 
 
-def test_lincomb(gpu):
-    n, K = 3000, 5
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 23, 24])
+def test_lincomb(gpu, K):
+    """terms are taken three at a time with one shared reduction (f29_mul3), a remainder of two (f29_mul2) or one: every
+    remainder, the largest term count, and scalars / coefficients at the ends of the field"""
+    n = 3000
     polys = [o.random_field_limbs(n, 200 + k) for k in range(K)]
-    sc = o.random_field_limbs(K, 9)
+    edge = [0, 1, o.R - 1, o.R - 2, (1 << 253) % o.R, (1 << 232) - 1]
+    for k in range(K):
+        polys[k][: len(edge)] = o.pack([edge[(j + k) % len(edge)] for j in range(len(edge))], o.R)
+    sv = [int(v) for v in o.unpack(o.random_field_limbs(K, 9), o.R)]
+    for k in range(min(K, len(edge))):
+        sv[k] = edge[-1 - k]
+    sc = o.pack(sv, o.R)
     got = o.unpack(gpu.lincomb(polys, sc), o.R)
     pv = [o.unpack(p, o.R) for p in polys]
-    sv = o.unpack(sc, o.R)
     assert got == [sum(sv[k] * pv[k][i] for k in range(K)) % o.R for i in range(n)]
 
 
