@@ -335,19 +335,30 @@ __global__ void __launch_bounds__(256) k_powers(fe* out, size_t n, const fe* lo,
 // ---- polynomial helpers of the opening argument: eval_polynomial, kate_division,
 // linear combinations.  Bandwidth-leaning vector kernels over HBM-resident coefficient vectors. ----------
 
-// Horner in y = x^T over the interleaved coefficient classes i = t (mod T): coalesced loads, one
-// multiplication per coefficient; thread t contributes x^t * P_t(y); block sums go to `partial`.
+// Thread t of T sums the coefficient class i = t (mod T): x^t * P_t(y), y = x^T (coalesced loads); block sums go to `partial`.
+// P_t by Horner's rule in y^3, three coefficients per step: acc <- acc y^3 + c2 y^2 + c1 y + c0 as ONE three-product multiplication
+// with a shared Montgomery reduction (f29_mul3) — 16 products + 6 reductions per 16 coefficients where the plain rule spent 16 + 16,
+// and a dependent chain a third as long.  (Sixteen coefficients at a time as a dot product with y^0 .. y^15 was SLOWER — 24.5 -> 30.5
+// us at 2^20: sixteen loads in flight cost 144 registers.)  y, y^2, y^3 come from the host (uniform operands).
 struct PolyList {
   const fe* p[24];
 };
-__global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uint32_t logT, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
+struct EvalPowers {
+  f29 y1, y2, y3;  // Montgomery-2^261
+};
+__global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uint32_t logT, EvalPowers yp, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
   __shared__ fe red[256];
   const fe* poly = polys.p[blockIdx.y];
   const uint32_t T = 1u << logT, t = blockIdx.x * blockDim.x + threadIdx.x;
-  f29 y = f29_mul<F9>(pow2tab(lo, hi, h, T - 1), pow2tab(lo, hi, h, 1));  // x^T (Mont261)
-  f29 acc = f29_zero();
   const size_t m = t < n ? (n - 1 - t) / T + 1 : 0;  // coefficients t, t+T, ... < n
-  for (size_t j = m; j-- > 0;) acc = f29_add(f29_mul<F9>(acc, y), load_unpack(&poly[t + j * T]));
+  f29 acc = f29_zero();
+  for (size_t g = (m + 2) / 3; g-- > 0;) {
+    const size_t j = 3 * g;  // j < m; the top group may run past m: zeros
+    const f29 c0 = load_unpack(&poly[t + j * T]);
+    const f29 c1 = j + 1 < m ? load_unpack(&poly[t + (j + 1) * T]) : f29_zero();
+    const f29 c2 = j + 2 < m ? load_unpack(&poly[t + (j + 2) * T]) : f29_zero();
+    acc = f29_normalize(f29_add(f29_mul3<F9>(acc, yp.y3, c2, yp.y2, c1, yp.y1), c0));  // < 1.02 p + p
+  }
   f29 term = f29_mul<F9>(acc, pow2tab(lo, hi, h, t));
   fe o;
   f29_pack(f29_reduce_canonical<F9>(term), o.v);
@@ -374,79 +385,15 @@ __global__ void __launch_bounds__(256) k_sum_fe(const fe* in, uint32_t count, fe
   if (threadIdx.x == 0) fe_store(&out[blockIdx.x], red[0]);
 }
 
-// kate_division: q_i = sum_{j > i} a_j b^(j-i-1) = b^-(i+1) * SUFFIX(i+1), SUFFIX(j) = sum_{l >= j} a_l b^l.
-// pass 1: s_j = a_j b^j and the inclusive suffix sums inside blocks of 1024 elements (+ block totals)
+// kate_division: q_i = sum_{j > i} a_j b^(j-i-1), in tile-relative form (round 3).  With tiles of 1024 coefficients (tile t =
+// [1024 t, 1024 t + 1024), loc = j - 1024 t) and B = b^1024:
+//   pass 1  local'_j = sum of a_l b^(l - 1024 t) over l >= j inside the tile (ONE multiplication per coefficient by the tile-relative
+//           power b^loc — a 1024-entry table shared by all tiles — and a suffix scan in LDS); T'_t = the tile's total
+//   pass 2  O'_t = sum_{t' > t} B^(t' - t) T'_t' = B^-t * SUFFIX_(t' > t)(B^t' T'_t')         (n / 1024 values: one workgroup per root)
+//   pass 3  q_i = b^-loc (local'_j + O'_t) for j = i + 1 in tile t                              (ONE multiplication per coefficient)
+// The round-2 form scaled by the absolute powers b^j and b^-(i+1): two multiplications per coefficient in each pass (the power
+// itself is a product of two table entries) plus the weight's in the several-roots form — five per root where there are now two.
 constexpr uint32_t KATE_TILE = 1024;
-__global__ void __launch_bounds__(256) k_kate_local(const fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, fe* local, fe* totals) {
-  __shared__ fe tile[KATE_TILE + 8];
-  __shared__ fe tsum[256];
-  const uint32_t tid = threadIdx.x;
-  const size_t base = (size_t)blockIdx.x * KATE_TILE;
-  for (uint32_t r = 0; r < 4; r++) {  // coalesced: element base + tid + 256 r
-    size_t i = base + tid + 256 * r;
-    fe o = fe_zero();
-    if (i < n) {
-      f29 x = f29_mul<F9>(load_unpack(&a[i]), pow2tab(lo, hi, h, (uint32_t)i));
-      f29_pack(f29_reduce_canonical<F9>(x), o.v);
-    }
-    tile[tid + 256 * r] = o;
-  }
-  __syncthreads();
-  // thread owns 4 consecutive elements: local suffix, then a suffix scan over the 256 thread totals
-  fe e3 = tile[4 * tid + 3], e2 = fe_add<Fr>(tile[4 * tid + 2], e3), e1 = fe_add<Fr>(tile[4 * tid + 1], e2), e0 = fe_add<Fr>(tile[4 * tid], e1);
-  tsum[tid] = e0;
-  __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive suffix scan (Hillis-Steele)
-    fe v = fe_zero();
-    if (tid + d < 256) v = tsum[tid + d];
-    __syncthreads();
-    tsum[tid] = fe_add<Fr>(tsum[tid], v);
-    __syncthreads();
-  }
-  fe right = tid + 1 < 256 ? tsum[tid + 1] : fe_zero();  // sum of everything to the right of this thread's 4
-  __syncthreads();
-  tile[4 * tid] = fe_add<Fr>(e0, right);
-  tile[4 * tid + 1] = fe_add<Fr>(e1, right);
-  tile[4 * tid + 2] = fe_add<Fr>(e2, right);
-  tile[4 * tid + 3] = fe_add<Fr>(e3, right);
-  __syncthreads();
-  for (uint32_t r = 0; r < 4; r++) {
-    size_t i = base + tid + 256 * r;
-    if (i < n) fe_store(&local[i], tile[tid + 256 * r]);
-  }
-  if (tid == 0) fe_store(&totals[blockIdx.x], tile[0]);
-}
-// pass 2: offsets[b] = sum of totals[b'] for b' > b (single block, sequential over chunks of 256)
-__global__ void __launch_bounds__(256) k_kate_offsets(const fe* totals, uint32_t nblocks, fe* offsets) {
-  __shared__ fe tsum[256];
-  const uint32_t tid = threadIdx.x;
-  fe carry = fe_zero();  // sum of all totals to the right of the current chunk
-  for (int64_t c0 = (int64_t)((nblocks + 255) / 256 - 1) * 256; c0 >= 0; c0 -= 256) {
-    uint32_t b = (uint32_t)c0 + tid;
-    tsum[tid] = b < nblocks ? fe_load(&totals[b]) : fe_zero();
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-      fe v = fe_zero();
-      if (tid + d < 256) v = tsum[tid + d];
-      __syncthreads();
-      tsum[tid] = fe_add<Fr>(tsum[tid], v);
-      __syncthreads();
-    }
-    fe excl = fe_add<Fr>(tid + 1 < 256 ? tsum[tid + 1] : fe_zero(), carry);
-    if (b < nblocks) fe_store(&offsets[b], excl);
-    fe chunk_total = tsum[0];
-    __syncthreads();
-    carry = fe_add<Fr>(carry, chunk_total);
-  }
-}
-// pass 3: q_i = (local[i+1] + offsets[block(i+1)]) * binv^(i+1), i < n-1
-__global__ void __launch_bounds__(256) k_kate_finish(const fe* local, const fe* offsets, size_t n, const fe* ilo, const fe* ihi, uint32_t ih, fe* q) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 >= n) return;
-  fe s = fe_add<Fr>(fe_load(&local[i + 1]), fe_load(&offsets[(i + 1) / KATE_TILE]));
-  f29 x = f29_mul<F9>(f29_unpack(s.v), pow2tab(ilo, ihi, ih, (uint32_t)(i + 1)));
-  pack_store(&q[i], x);
-}
 
 // out[i] = sum_k scalar_k * poly_k[i]
 // Extended-coset form of an instance column WITHOUT transforms (round 3).  The column holds `count` public inputs v_r on rows
@@ -479,67 +426,117 @@ __global__ void __launch_bounds__(256) k_instance_coset(const fe* l0, uint32_t e
 // three launches with blockIdx.y = root, the finish kernel summing the weighted quotients.
 constexpr uint32_t KATE_MULTI_MAX = 4;
 struct KateRoots {
-  const fe* lo[KATE_MULTI_MAX];   // b_r^i tables
+  const fe* lo[KATE_MULTI_MAX];   // b_r^i tables (split form: pow2tab)
   const fe* hi[KATE_MULTI_MAX];
   const fe* ilo[KATE_MULTI_MAX];  // b_r^-i tables
   const fe* ihi[KATE_MULTI_MAX];
   uint32_t h[KATE_MULTI_MAX], ih[KATE_MULTI_MAX];
-  fe c[KATE_MULTI_MAX];           // the partial-fraction weights, Montgomery-2^256
+  fe c[KATE_MULTI_MAX];           // the partial-fraction weights, Montgomery-2^261 (canonical words)
   uint32_t m;
 };
+// base^e for e < 1024 (and e below the table's range): a split table with 2^h >= 1024 low entries holds it as one entry
+__device__ __forceinline__ f29 kate_small_power(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {
+  return h >= 10 ? load_unpack(&lo[e]) : pow2tab(lo, hi, h, e);
+}
+__device__ __forceinline__ fe fe_shfl_down(const fe& a, uint32_t d) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d);
+  return r;
+}
+// inclusive suffix sums over the 64 lanes of a wavefront (lane l gets the sum of lanes >= l)
+__device__ __forceinline__ fe wave_suffix_fe(fe v) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    fe o = fe_shfl_down(v, d);
+    if (lane + d < 64) v = fe_add<Fr>(v, o);
+  }
+  return v;
+}
 __global__ void __launch_bounds__(256) k_kate_local_multi(const fe* a, size_t n, KateRoots R, uint32_t nblocks, fe* local, fe* totals) {
   __shared__ fe tile[KATE_TILE + 8];
-  __shared__ fe tsum[256];
-  const uint32_t tid = threadIdx.x, r = blockIdx.y;
+  __shared__ fe wtot[4];
+  const uint32_t tid = threadIdx.x, r = blockIdx.y, lane = tid & 63u, wave = tid >> 6;
   const size_t base = (size_t)blockIdx.x * KATE_TILE;
   local += (size_t)r * n;
   totals += (size_t)r * nblocks;
-  for (uint32_t q = 0; q < 4; q++) {
-    size_t i = base + tid + 256 * q;
+  for (uint32_t q = 0; q < 4; q++) {  // coalesced: element base + tid + 256 q
+    const uint32_t loc = tid + 256 * q;
     fe o = fe_zero();
-    if (i < n) {
-      f29 x = f29_mul<F9>(load_unpack(&a[i]), pow2tab(R.lo[r], R.hi[r], R.h[r], (uint32_t)i));
+    if (base + loc < n) {
+      f29 x = f29_mul<F9>(load_unpack(&a[base + loc]), kate_small_power(R.lo[r], R.hi[r], R.h[r], loc));
       f29_pack(f29_reduce_canonical<F9>(x), o.v);
     }
-    tile[tid + 256 * q] = o;
+    tile[loc] = o;
   }
   __syncthreads();
+  // a thread owns 4 consecutive elements: local suffix, a suffix scan of the thread totals inside the wavefront (shuffles), the four
+  // wavefront totals through LDS
   fe e3 = tile[4 * tid + 3], e2 = fe_add<Fr>(tile[4 * tid + 2], e3), e1 = fe_add<Fr>(tile[4 * tid + 1], e2), e0 = fe_add<Fr>(tile[4 * tid], e1);
-  tsum[tid] = e0;
+  const fe incl = wave_suffix_fe(e0);
+  if (lane == 0) wtot[wave] = incl;
+  fe right = fe_shfl_down(incl, 1);  // everything to the right of this thread's four, inside the wavefront
+  if (lane == 63) right = fe_zero();
   __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    fe v = fe_zero();
-    if (tid + d < 256) v = tsum[tid + d];
-    __syncthreads();
-    tsum[tid] = fe_add<Fr>(tsum[tid], v);
-    __syncthreads();
-  }
-  fe right = tid + 1 < 256 ? tsum[tid + 1] : fe_zero();
-  __syncthreads();
+  for (uint32_t w = wave + 1; w < 4; w++) right = fe_add<Fr>(right, wtot[w]);
   tile[4 * tid] = fe_add<Fr>(e0, right);
   tile[4 * tid + 1] = fe_add<Fr>(e1, right);
   tile[4 * tid + 2] = fe_add<Fr>(e2, right);
   tile[4 * tid + 3] = fe_add<Fr>(e3, right);
   __syncthreads();
   for (uint32_t q = 0; q < 4; q++) {
-    size_t i = base + tid + 256 * q;
-    if (i < n) fe_store(&local[i], tile[tid + 256 * q]);
+    const uint32_t loc = tid + 256 * q;
+    if (base + loc < n) fe_store(&local[base + loc], tile[loc]);
   }
   if (tid == 0) fe_store(&totals[blockIdx.x], tile[0]);
 }
-// q_i = sum_r c_r (local_r[i+1] + offsets_r[block(i+1)]) b_r^-(i+1)
-__global__ void __launch_bounds__(256) k_kate_finish_multi(const fe* local, const fe* offsets, size_t n, KateRoots R, uint32_t nblocks, fe* q) {
+// pass 2, one workgroup of 1024 threads per root: the tile offsets O'_t, and the root's weighted inverse powers ct[loc] = c b^-loc
+// (Montgomery-2^261) that pass 3 multiplies by.  A thread owns `per` consecutive tiles.
+__global__ void __launch_bounds__(1024) k_kate_offsets_multi(const fe* totals, uint32_t nblocks, size_t n, KateRoots R, fe* offsets, fe* ct) {
+  __shared__ fe wtot[16];
+  const uint32_t tid = threadIdx.x, r = blockIdx.x, lane = tid & 63u, wave = tid >> 6;
+  totals += (size_t)r * nblocks;
+  offsets += (size_t)r * nblocks;
+  ct += (size_t)r * KATE_TILE;
+  if (tid < n) pack_store(&ct[tid], f29_mul<F9>(kate_small_power(R.ilo[r], R.ihi[r], R.ih[r], tid), f29_unpack(R.c[r].v)));
+  const uint32_t per = (nblocks + 1023) / 1024;
+  const uint32_t t0 = min(tid * per, nblocks), t1 = min(t0 + per, nblocks);
+  auto weighted = [&](uint32_t t) {  // B^t T'_t, canonical
+    fe o;
+    f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(load_unpack(&totals[t]), pow2tab(R.lo[r], R.hi[r], R.h[r], t * KATE_TILE))), o.v);
+    return o;
+  };
+  fe mine = fe_zero();
+  for (uint32_t t = t0; t < t1; t++) mine = fe_add<Fr>(mine, weighted(t));
+  const fe incl = wave_suffix_fe(mine);
+  if (lane == 0) wtot[wave] = incl;
+  fe run = fe_shfl_down(incl, 1);  // the weighted totals of every tile to the right of this thread's
+  if (lane == 63) run = fe_zero();
+  __syncthreads();
+  for (uint32_t w = wave + 1; w < 16; w++) run = fe_add<Fr>(run, wtot[w]);
+  for (uint32_t t = t1; t-- > t0;) {
+    pack_store(&offsets[t], f29_mul<F9>(f29_unpack(run.v), pow2tab(R.ilo[r], R.ihi[r], R.ih[r], t * KATE_TILE)));
+    run = fe_add<Fr>(run, weighted(t));
+  }
+}
+// pass 3: q_i = sum_r (local'_r[j] + O'_r[tile(j)]) * ct_r[loc(j)], j = i + 1: the roots' products share one Montgomery reduction
+__global__ void __launch_bounds__(256) k_kate_finish_multi(const fe* local, const fe* offsets, const fe* ct, size_t n, uint32_t m, uint32_t nblocks, fe* q) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i + 1 >= n) return;
-  f29 acc = f29_zero();
-  for (uint32_t r = 0; r < R.m; r++) {
-    fe s = fe_add<Fr>(fe_load(&local[(size_t)r * n + i + 1]), fe_load(&offsets[(size_t)r * nblocks + (i + 1) / KATE_TILE]));
-    f29 x = f29_mul<F9>(f29_unpack(s.v), pow2tab(R.ilo[r], R.ihi[r], R.ih[r], (uint32_t)(i + 1)));  // Mont256 value, below 1.2 p
-    // weight: (x 2^256)(c 2^256) / 2^261 carries 2^-5 less than wanted; c arrives pre-multiplied by 2^5 (host)
-    acc = f29_add(acc, f29_mul<F9>(x, f29_unpack(R.c[r].v)));
+  const size_t j = i + 1;
+  const uint32_t t = (uint32_t)(j / KATE_TILE), loc = (uint32_t)(j % KATE_TILE);
+  auto x = [&](uint32_t r) { return f29_unpack(fe_add<Fr>(fe_load(&local[(size_t)r * n + j]), fe_load(&offsets[(size_t)r * nblocks + t])).v); };
+  auto w = [&](uint32_t r) { return load_unpack(&ct[(size_t)r * KATE_TILE + loc]); };
+  f29 acc;
+  if (m == 1) acc = f29_mul<F9>(x(0), w(0));
+  else if (m == 2) acc = f29_mul2<F9>(x(0), w(0), x(1), w(1));
+  else {
+    acc = f29_mul3<F9>(x(0), w(0), x(1), w(1), x(2), w(2));
+    if (m == 4) acc = f29_normalize(f29_add(acc, f29_mul<F9>(x(3), w(3))));
   }
   fe o;
-  f29_pack(f29_reduce_loose<F9>(f29_normalize(acc)), o.v);  // up to four products below 1.2 p each
+  f29_pack(f29_reduce_loose<F9>(acc), o.v);
   fe_store(&q[i], o);
 }
 
@@ -1643,7 +1640,12 @@ static int eval_polys(const void* const* d_polys, size_t count, size_t n, const 
   PolyList pl;
   memset(&pl, 0, sizeof(pl));
   for (size_t i = 0; i < count; i++) pl.p[i] = (const fe*)d_polys[i];
-  H2_LAUNCH("k_eval_poly", k_eval_poly, dim3(nblocks, (uint32_t)count), 256, 0, s, pl, n, logT, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
+  EvalPowers yp;  // y = x^T, y^2, y^3 on the host (logT squarings of the same header code)
+  yp.y1 = f29_from_mont256<F9>(host_fe(point).v);
+  for (uint32_t i = 0; i < logT; i++) yp.y1 = f29_sqr<F9>(yp.y1);
+  yp.y2 = f29_sqr<F9>(yp.y1);
+  yp.y3 = f29_mul<F9>(yp.y2, yp.y1);
+  H2_LAUNCH("k_eval_poly", k_eval_poly, dim3(nblocks, (uint32_t)count), 256, 0, s, pl, n, logT, yp, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
   H2_LAUNCH("k_sum_fe", k_sum_fe, (uint32_t)count, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
   return release_tmp(s);
 }
@@ -1666,6 +1668,21 @@ int h2mi_fr_eval_polys_dev(const void* const* d_polys, size_t count, size_t n, c
   return eval_polys(d_polys, count, n, point, d_out, pick_stream(stream));
 }
 
+static int kate_multi(const void* d_poly, size_t n, const struct KateRoots& R, void* d_out, hipStream_t s) {
+  const uint32_t nblocks = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE), m = R.m;
+  int rc = ensure_tmp(m * (n + 2 * (size_t)nblocks + KATE_TILE) + 16, s);
+  if (rc) return rc;
+  fe* local = g_tmp;
+  fe* totals = g_tmp + m * n;
+  fe* offsets = totals + m * nblocks;
+  fe* ct = offsets + m * nblocks;
+  H2_LAUNCH("k_kate_local", k_kate_local_multi, dim3(nblocks, m), 256, 0, s, (const fe*)d_poly, n, R, nblocks, local, totals);
+  H2_LAUNCH("k_kate_offsets", k_kate_offsets_multi, m, 1024, 0, s, (const fe*)totals, nblocks, n, R, offsets, ct);
+  H2_LAUNCH("k_kate_finish", k_kate_finish_multi, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, (const fe*)ct, n, m, nblocks,
+            (fe*)d_out);
+  return release_tmp(s);
+}
+
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
   if (!d_poly || !b || !b_inv || !d_out || n < 2) return H2MI_EINVAL;
@@ -1679,17 +1696,13 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   int rc = get_powtab(b, log_n, s, &pb);
   if (!rc) rc = get_powtab(b_inv, log_n, s, &pi);  // exponents i + 1 <= n - 1 < 2^log_n
   if (rc) return rc;
-  const uint32_t nblocks = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
-  rc = ensure_tmp(n + 2 * (size_t)nblocks + 16, s);
-  if (rc) return rc;
-  fe* local = g_tmp;
-  fe* totals = g_tmp + n;
-  fe* offsets = totals + nblocks;
-  H2_LAUNCH("k_kate_local", k_kate_local, nblocks, 256, 0, s, (const fe*)d_poly, n, (const fe*)pb.lo, (const fe*)pb.hi, pb.h, local, totals);
-  H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)totals, nblocks, offsets);
-  H2_LAUNCH("k_kate_finish", k_kate_finish, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, (const fe*)pi.lo,
-            (const fe*)pi.hi, pi.h, (fe*)d_out);
-  return release_tmp(s);
+  KateRoots R;
+  memset(&R, 0, sizeof(R));
+  R.m = 1;
+  R.lo[0] = pb.lo; R.hi[0] = pb.hi; R.h[0] = pb.h;
+  R.ilo[0] = pi.lo; R.ihi[0] = pi.hi; R.ih[0] = pi.h;
+  f29_pack(f29_reduce_canonical<F9>(f29_const<F9>(F9::ONE)), R.c[0].v);  // weight one, Montgomery-2^261
+  return kate_multi(d_poly, n, R, d_out, s);
 }
 
 int h2mi_plonk_instance_coset_dev(const void* d_l0_coset, uint32_t k, uint32_t extended_k, const uint64_t* values, size_t count, void* d_out,
@@ -1732,17 +1745,7 @@ int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t
     fe c = host_fe(weights + 4 * r);
     R.c[r] = h_level(c, -1);
   }
-  const uint32_t nblocks = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
-  int rc = ensure_tmp(m * (n + 2 * (size_t)nblocks) + 16, s);
-  if (rc) return rc;
-  fe* local = g_tmp;
-  fe* totals = g_tmp + m * n;
-  fe* offsets = totals + m * nblocks;
-  H2_LAUNCH("k_kate_local", k_kate_local_multi, dim3(nblocks, (uint32_t)m), 256, 0, s, (const fe*)d_poly, n, R, nblocks, local, totals);
-  for (size_t r = 0; r < m; r++)  // tiny: one workgroup per root
-    H2_LAUNCH("k_kate_offsets", k_kate_offsets, 1, 256, 0, s, (const fe*)(totals + r * nblocks), nblocks, offsets + r * nblocks);
-  H2_LAUNCH("k_kate_finish", k_kate_finish_multi, ceil_div_u32(n - 1, 256), 256, 0, s, (const fe*)local, (const fe*)offsets, n, R, nblocks, (fe*)d_out);
-  return release_tmp(s);
+  return kate_multi(d_poly, n, R, d_out, s);
 }
 
 int h2mi_fr_lincomb_dev(const void* const* d_polys, const uint64_t* scalars, size_t count, size_t n, void* d_out, h2mi_stream_t stream) {
