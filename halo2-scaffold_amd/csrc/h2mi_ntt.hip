@@ -666,36 +666,33 @@ __global__ void __launch_bounds__(256) k_evaluate_h_standard_plonk(PlonkCosets c
   if (idx >= size) return;
   const uint32_t r_next = (idx + rot) & (size - 1), r_last = (idx + size - last_rot * rot) & (size - 1);
   const f29 adv[3] = {load_unpack(&c.advice[0][idx]), load_unpack(&c.advice[1][idx]), load_unpack(&c.advice[2][idx])};
+  // Sums of products at one level share ONE Montgomery reduction (f29_mul3 / f29_mul2, round 3): 33 products and 20 reductions per
+  // point where every product had its own (33 + 33).  Operands of the shared forms are normalized (loads, constants, products,
+  // hsub results); the one lazy operand — a three-term sum, limbs < 1.5 * 2^30 — sits where f29_mul2 allows it.
   // gate
-  f29 g1 = f29_add(f29_add(hmul(load_unpack(&c.fixed[0][idx]), adv[0]), hmul(load_unpack(&c.fixed[1][idx]), adv[1])),
-                   hmul(load_unpack(&c.fixed[2][idx]), adv[2]));                                  // level 1, lazy
-  f29 g2 = hmul(hmul(load_unpack(&c.fixed[3][idx]), adv[0]), adv[1]);                               // level 2
-  f29 acc = f29_add(f29_add(hmul(g1, hc(h.y[0])), hmul(g2, hc(h.y[1]))), hmul(load_unpack(&c.fixed[4][idx]), hc(h.y[2])));
+  const f29 g1 = f29_mul3<F9>(load_unpack(&c.fixed[0][idx]), adv[0], load_unpack(&c.fixed[1][idx]), adv[1], load_unpack(&c.fixed[2][idx]), adv[2]);  // level 1
+  const f29 g2 = hmul(hmul(load_unpack(&c.fixed[3][idx]), adv[0]), adv[1]);                          // level 2
+  f29 acc = f29_mul3<F9>(g1, hc(h.y[0]), g2, hc(h.y[1]), load_unpack(&c.fixed[4][idx]), hc(h.y[2]));  // level 0
   const f29 zs[3] = {load_unpack(&c.z[0][idx]), load_unpack(&c.z[1][idx]), load_unpack(&c.z[2][idx])};
   const f29 one = hc(h.one0), gamma = hc(h.gamma0);
-  {  // l_0 terms: (1 - z_0), (z_1 - z_0(w^last X)), (z_2 - z_1(w^last X))
-    f29 s0 = hmul(hsub(one, zs[0]), hc(h.y[3]));
-    s0 = f29_add(s0, hmul(hsub(zs[1], load_unpack(&c.z[0][r_last])), hc(h.y[4])));
-    s0 = f29_add(s0, hmul(hsub(zs[2], load_unpack(&c.z[1][r_last])), hc(h.y[5])));
-    acc = f29_add(acc, hmul(s0, load_unpack(&c.l0[idx])));
-  }
+  // l_0 terms: (1 - z_0), (z_1 - z_0(w^last X)), (z_2 - z_1(w^last X))
+  const f29 s0 = f29_mul3<F9>(hsub(one, zs[0]), hc(h.y[3]), hsub(zs[1], load_unpack(&c.z[0][r_last])), hc(h.y[4]),
+                              hsub(zs[2], load_unpack(&c.z[1][r_last])), hc(h.y[5]));
   // l_last term: z_2^2 - z_2 = z_2 (z_2 - 1)
-  acc = f29_add(acc, hmul(hmul(hmul(zs[2], hsub(zs[2], one)), hc(h.y[6])), load_unpack(&c.l_last[idx])));
-  {  // permutation terms: z_m(wX) (a_m + beta sigma_m + gamma) - z_m (a_m + beta DELTA^m X + gamma), X = zeta * extended_omega^idx
-    const f29 X = pow2tab(xlo, xhi, xh, idx);
-    f29 sa = f29_zero();
-    auto term = [&](const f29& a_m, const f29& z_m, const fe* sigma, const fe* z_col, const fe& cur, const fe& ym) {
-      f29 inner_l = f29_add(f29_add(a_m, hmul(load_unpack(&sigma[idx]), hc(h.beta_m1))), gamma);
-      f29 left = hmul(inner_l, load_unpack(&z_col[r_next]));
-      f29 inner_r = f29_add(f29_add(a_m, hmul(X, hc(cur))), gamma);
-      f29 right = hmul(inner_r, z_m);
-      sa = f29_add(sa, hmul(hsub(left, right), hc(ym)));
-    };
-    term(adv[0], zs[0], c.sigma[0], c.z[0], h.cur[0], h.y[7]);
-    term(adv[1], zs[1], c.sigma[1], c.z[1], h.cur[1], h.y[8]);
-    term(adv[2], zs[2], c.sigma[2], c.z[2], h.cur[2], h.y[9]);
-    acc = f29_add(acc, hmul(sa, load_unpack(&c.l_active[idx])));
-  }
+  const f29 tl = hmul(hmul(zs[2], hsub(zs[2], one)), hc(h.y[6]));
+  // permutation terms: z_m(wX) (a_m + beta sigma_m + gamma) - z_m (a_m + beta DELTA^m X + gamma), X = zeta * extended_omega^idx
+  const f29 X = pow2tab(xlo, xhi, xh, idx);
+  auto term = [&](const f29& a_m, const f29& z_m, const fe* sigma, const fe* z_col, const fe& cur) {
+    const f29 inner_l = f29_add(f29_add(a_m, hmul(load_unpack(&sigma[idx]), hc(h.beta_m1))), gamma);  // lazy: limbs < 1.5 * 2^30, value < 3.1 p
+    const f29 inner_r = f29_normalize(f29_add(f29_add(a_m, hmul(X, hc(cur))), gamma));
+    const f29 neg_r = f29_sub(f29_zero(), inner_r, F9::K4);                                           // 4p - inner_r: lazy, limbs < 2^30
+    return f29_mul2<F9>(inner_l, load_unpack(&z_col[r_next]), neg_r, z_m);                            // left - right, level 1
+  };
+  const f29 d0 = term(adv[0], zs[0], c.sigma[0], c.z[0], h.cur[0]);
+  const f29 d1 = term(adv[1], zs[1], c.sigma[1], c.z[1], h.cur[1]);
+  const f29 d2 = term(adv[2], zs[2], c.sigma[2], c.z[2], h.cur[2]);
+  const f29 sa = f29_mul3<F9>(d0, hc(h.y[7]), d1, hc(h.y[8]), d2, hc(h.y[9]));
+  acc = f29_add(acc, f29_mul3<F9>(s0, load_unpack(&c.l0[idx]), tl, load_unpack(&c.l_last[idx]), sa, load_unpack(&c.l_active[idx])));
   hstore(&out[idx], acc, h.tinv[idx & (rot - 1)]);
 }
 
@@ -1006,52 +1003,78 @@ __device__ __forceinline__ void evaluate_h_range_body(const RangeCosets& c, uint
   auto at = [&](int r) { return (idx + size + (uint32_t)(r * (int)rot)) & (size - 1); };
   const uint32_t r_next = at(1), r_prev = at(-1), r_last = at(-(int)last_rot);
   const f29 one = hc(h.one0), gamma = hc(h.gamma0), beta = hc(h.beta0);
+  // Sums of products at one level share a Montgomery reduction (round 3, as in k_evaluate_h_standard_plonk): Dot gathers the terms of a
+  // group (NORMALIZED values, each with its power of y) and multiplies them two at a time (f29_mul2); its branches depend on the
+  // constraint system only (uniform).  Differences of two products (left - right of a permutation set, of the lookup) are one f29_mul2 with the second
+  // product's first factor negated (4p - x).
+  struct Dot {  // pairs (value, index of its y constant), multiplied two at a time: one pending value is all the state (three at a
+                // time held four operands across the permutation products: 269 registers, one wavefront per SIMD)
+    f29 a0, sum;
+    uint32_t i0;
+    bool pending;
+    const HConsts& h;
+    __device__ __forceinline__ Dot(const HConsts& hh) : i0(0), pending(false), h(hh) { sum = f29_zero(); }
+    __device__ __forceinline__ void add(const f29& a, uint32_t yi) {
+      if (!pending) { a0 = a; i0 = yi; pending = true; }
+      else { sum = f29_normalize(f29_add(sum, f29_mul2<F9>(a0, hc(h.y[i0]), a, hc(h.y[yi])))); pending = false; }
+    }
+    __device__ __forceinline__ f29 result() {  // normalized
+      if (pending) sum = f29_normalize(f29_add(sum, f29_mul<F9>(a0, hc(h.y[i0]))));
+      pending = false;
+      return sum;
+    }
+  };
+  auto neg4 = [](const f29& x_norm) { return f29_sub(f29_zero(), x_norm, F9::K4); };  // 4p - x for normalized x < 4p - 2^232: limbs < 2^30
   // gate: q (a + a(wX) a(w^2 X) - a(w^3 X))
   f29 acc;
   {
-    f29 w = hmul(load_unpack(&c.a[at(1)]), load_unpack(&c.a[at(2)]));                  // level 1
-    f29 u = hmul(hsub(load_unpack(&c.a[idx]), load_unpack(&c.a[at(3)])), one);        // level 0 -> 1
-    acc = hmul(hmul(f29_add(w, u), load_unpack(&c.q[idx])), hc(h.y[0]));
+    f29 wu = f29_mul2<F9>(load_unpack(&c.a[at(1)]), load_unpack(&c.a[at(2)]), hsub(load_unpack(&c.a[idx]), load_unpack(&c.a[at(3)])), one);  // level 1
+    acc = hmul(hmul(wu, load_unpack(&c.q[idx])), hc(h.y[0]));
   }
   const uint32_t sets = (c.n_perm + c.chunk - 1) / c.chunk;
   const f29 z_first = load_unpack(&c.perm_z[0][idx]);
   const f29 z_lastset = load_unpack(&c.perm_z[sets - 1][idx]);
-  f29 s0 = hmul(hsub(one, z_first), hc(h.y[1]));                                      // l_0 group (level -1 after the y factor)
-  f29 sl = hmul(hmul(z_lastset, hsub(z_lastset, one)), hc(h.y[2]));                   // l_last group
-  for (uint32_t s = 1; s < sets; s++)
-    s0 = f29_add(s0, hmul(hsub(load_unpack(&c.perm_z[s][idx]), load_unpack(&c.perm_z[s - 1][r_last])), hc(h.y[2 + s])));
+  Dot s0(h), sa(h);                                                                    // l_0 group, l_active group (level -1 after the y factors)
+  s0.add(hsub(one, z_first), 1);
+  const f29 pl = hmul(z_lastset, hsub(z_lastset, one));                                // l_last group: z (z - 1), level 1
+  for (uint32_t s = 1; s < sets; s++) s0.add(hsub(load_unpack(&c.perm_z[s][idx]), load_unpack(&c.perm_z[s - 1][r_last])), 2 + s);
   const f29 X = pow2tab(xlo, xhi, xh, idx);
-  f29 sa = f29_zero();                                                                // l_active group
   const uint32_t p0 = 2 + sets;
   for (uint32_t s = 0; s < sets; s++) {
     f29 left = load_unpack(&c.perm_z[s][r_next]), right = load_unpack(&c.perm_z[s][idx]);
-    for (uint32_t j = c.chunk * s; j < c.n_perm && j < c.chunk * (s + 1); j++) {
+    const uint32_t j0 = c.chunk * s, j1 = min(c.n_perm, c.chunk * (s + 1));
+    for (uint32_t j = j0; j + 1 < j1; j++) {
       const f29 val = load_unpack(&c.perm_value[j][idx]);
       left = hmul(f29_add(f29_add(val, hmul(load_unpack(&c.perm_sigma[j][idx]), hc(h.beta_m1))), gamma), left);
       right = hmul(f29_add(f29_add(val, hmul(X, hc(h.cur[j]))), gamma), right);
     }
-    sa = f29_add(sa, hmul(hsub(left, right), hc(h.y[p0 + s])));
+    {  // the set's last column: both products' final factors in one two-product multiplication, left - right
+      const uint32_t j = j1 - 1;
+      const f29 val = load_unpack(&c.perm_value[j][idx]);
+      const f29 inner_l = f29_add(f29_add(val, hmul(load_unpack(&c.perm_sigma[j][idx]), hc(h.beta_m1))), gamma);  // lazy, limbs < 1.5 * 2^30
+      const f29 inner_r = f29_normalize(f29_add(f29_add(val, hmul(X, hc(h.cur[j]))), gamma));
+      sa.add(f29_mul2<F9>(inner_l, left, neg4(inner_r), right), p0 + s);
+    }
   }
+  f29 sl;
   if (c.has_lookup) {
     const uint32_t lb = p0 + sets;
     const f29 ap = load_unpack(&c.lk_input[idx]), sp = load_unpack(&c.lk_table[idx]), zl = load_unpack(&c.lk_z[idx]);
-    s0 = f29_add(s0, hmul(hsub(one, zl), hc(h.y[lb])));
-    sl = f29_add(sl, hmul(hmul(zl, hsub(zl, one)), hc(h.y[lb + 1])));
+    s0.add(hsub(one, zl), lb);
+    sl = f29_mul2<F9>(pl, hc(h.y[2]), hmul(zl, hsub(zl, one)), hc(h.y[lb + 1]));
     {  // z(wX) (A' + beta) (S' + gamma) - z (A + beta) (S + gamma)
-      f29 lhs = hmul(f29_add(sp, gamma), hmul(f29_add(ap, beta), load_unpack(&c.lk_z[r_next])));
+      const f29 li = hmul(f29_add(ap, beta), load_unpack(&c.lk_z[r_next]));
       const f29 a_in = c.ql ? hmul(hmul(load_unpack(&c.ql[idx]), load_unpack(&c.a[idx])), hc(h.one_m2)) : load_unpack(&c.la[idx]);
-      f29 tv = hmul(f29_add(a_in, beta), f29_normalize(f29_add(load_unpack(&c.table[idx]), gamma)));
-      f29 rhs = hmul(tv, zl);
-      sa = f29_add(sa, hmul(hsub(lhs, rhs), hc(h.y[lb + 2])));
+      const f29 tv = hmul(f29_add(a_in, beta), f29_normalize(f29_add(load_unpack(&c.table[idx]), gamma)));
+      sa.add(f29_mul2<F9>(f29_add(sp, gamma), li, neg4(tv), zl), lb + 2);
     }
     const f29 a_minus_s = hsub(ap, sp);
-    s0 = f29_add(s0, hmul(a_minus_s, hc(h.y[lb + 3])));
-    sa = f29_add(sa, hmul(hmul(a_minus_s, hsub(ap, load_unpack(&c.lk_input[r_prev]))), hc(h.y[lb + 4])));
+    s0.add(a_minus_s, lb + 3);
+    sa.add(hmul(a_minus_s, hsub(ap, load_unpack(&c.lk_input[r_prev]))), lb + 4);
+  } else {
+    sl = hmul(pl, hc(h.y[2]));
   }
-  // l_0 group: up to 1 + 3 + 2 = 6 normalized addends (limbs < 6 * 2^29 exceeds the multiplier's 1.9 * 2^30 bound)
-  acc = f29_add(acc, hmul(f29_normalize(s0), load_unpack(&c.l0[idx])));
-  acc = f29_add(acc, hmul(sl, load_unpack(&c.l_last[idx])));
-  acc = f29_add(acc, hmul(f29_normalize(sa), load_unpack(&c.l_active[idx])));
+  acc = f29_add(acc, f29_mul3<F9>(s0.result(), load_unpack(&c.l0[idx]), sl, load_unpack(&c.l_last[idx]), sa.result(), load_unpack(&c.l_active[idx])));
   hstore(&out[idx], acc, h.tinv[idx & (rot - 1)]);
 }
 // two register budgets of the same body (round 3): unconstrained it takes 169 VGPRs (two wavefronts per
