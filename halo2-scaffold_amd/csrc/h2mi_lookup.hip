@@ -52,12 +52,19 @@ __global__ void __launch_bounds__(1024) k_lk_rank(const fe* input, uint32_t u, c
   bool active = false;
   if (i < u) {
     const fe v = fe_from_mont<Fr>(fe_load(&input[i]));
-    uint32_t hi = n_unique;  // first index with sorted[idx] >= v
-    lo = 0;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (cmp256(fe_load(&sorted[mid]), v) < 0) lo = mid + 1;
-      else hi = mid;
+    // first index with sorted[idx] >= v.  A range-check table holds 0 .. 2^bits - 1, where a value IS its rank: the guess "rank = low
+    // word of v" is tried first (one load instead of seventeen dependent ones); any other table falls through to the binary search
+    const uint32_t guess = min(v.v[0], n_unique - 1);
+    if (cmp256(fe_load(&sorted[guess]), v) == 0) {
+      lo = guess;
+    } else {
+      uint32_t hi = n_unique;
+      lo = 0;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cmp256(fe_load(&sorted[mid]), v) < 0) lo = mid + 1;
+        else hi = mid;
+      }
     }
     if (lo < n_unique && cmp256(fe_load(&sorted[lo]), v) == 0) {
       active = true;
