@@ -563,7 +563,7 @@ def test_degree22_sizes(gpu, k):
     assert np.array_equal(back[:n], a) and not back[n:].any()
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 255, 1024, 4097, 70000])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 1024, 1025, 4097, 70000, (1 << 19) + 3])
 def test_eval_polynomial_and_kate_division(gpu, n):
     a = o.random_field_limbs(n, 77 + n)
     vals = o.unpack(a, o.R)

@@ -294,7 +294,7 @@ def test_eval_polys_batched_matches_oracle(gpu):
     assert gpu.lib.h2mi_fr_eval_polys_dev(None, 1, 4, None, None, None) == -1
 
 
-@pytest.mark.parametrize("n,m", [(64, 2), (1000, 3), (1 << 13, 4), (70001, 4)])
+@pytest.mark.parametrize("n,m", [(64, 2), (1000, 3), (1 << 13, 4), (70001, 4), ((1 << 19) + 5, 2)])  # the last: split tables with >= 1024 low entries, a partial last tile
 def test_kate_division_multi_matches_chained_divisions(gpu, n, m):
     """h2mi_fr_kate_division_multi_dev: N / prod (X - r_i) in one round (partial fractions over independent divisions) equals
     the oracle's chain of kate_division calls — what SHPLONK's div_by_vanishing computes — coefficient for coefficient,
