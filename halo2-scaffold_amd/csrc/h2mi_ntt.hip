@@ -85,7 +85,7 @@ struct PassParams {
   uint32_t ph;
   uint32_t tfull, pfull;  // the twiddle / pre-scale table holds every power: fetch instead of hi * lo
   int has_post;
-  fe post;        // Mont256 (as passed by the caller)
+  f29 post;       // Montgomery-2^261 limbs (converted on the host: every thread of the last pass multiplies by it)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
   uint32_t remap;         // XCD-aware block remap on/off
   size_t in_len;          // elements of `in` that exist; indices beyond read as zero (first pass of a
@@ -298,8 +298,8 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   stage_twiddles(tw, p.loc, m);
   __syncthreads();
   local_ntt(lds, dstride, tw, m, logC);
-  // the caller's post-scale (Mont256 -> Mont261 first) also brings the lazily accumulated value back below 2p
-  f29 fin = p.has_post ? f29_from_mont256<F9>(p.post.v) : f29_zero();
+  // the caller's post-scale also brings the lazily accumulated value back below 2p
+  const f29 fin = p.post;
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
     f29 x = lds_get(lds, dstride, (c << m) | k);
@@ -315,12 +315,12 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
 }
 
 // a[i] = a[i] * base^i (* post)
-__global__ void __launch_bounds__(256) k_scale_powers(fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, int has_post, fe post) {
+__global__ void __launch_bounds__(256) k_scale_powers(fe* a, size_t n, const fe* lo, const fe* hi, uint32_t h, int has_post, f29 post261) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   f29 x = load_unpack(&a[i]);
   x = f29_mul<F9>(x, pow2tab(lo, hi, h, (uint32_t)i));
-  if (has_post) x = f29_mul<F9>(x, f29_from_mont256<F9>(post.v));
+  if (has_post) x = f29_mul<F9>(x, post261);  // converted to the multiplier's radix on the host, once
   pack_store(&a[i], x);
 }
 // out[i] = base^i in the ABI's Montgomery-2^256 form
@@ -1528,7 +1528,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       H2_NTT_LAUNCH("k_ntt_pass_col", k_ntt_pass_col);
     } else {
       pp.has_post = post ? 1 : 0;
-      if (post) pp.post = host_fe(post);
+      pp.post = post ? f29_from_mont256<F9>(host_fe(post).v) : f29_zero();
       if (pl.P == 1) {
         pp.logN1 = 0;
         pp.logN2 = 0;
@@ -1625,7 +1625,7 @@ int h2mi_fr_scale_powers_dev(void* d_a, size_t n, const uint64_t base[4], const 
   PowTab pt;
   int rc = get_powtab(base, log_n, s, &pt);
   if (rc) return rc;
-  fe p = post ? host_fe(post) : fe{};
+  f29 p = post ? f29_from_mont256<F9>(host_fe(post).v) : f29_zero();
   H2_LAUNCH("k_scale_powers", k_scale_powers, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_a, n, (const fe*)pt.lo, (const fe*)pt.hi, pt.h,
             post ? 1 : 0, p);
   return H2MI_OK;
