@@ -140,12 +140,17 @@ __device__ __forceinline__ void pack_store(fe* p, const f29& a_lt2p) {
 // (32 B each: 4-way bank conflicts at the late stages, where every lane needs its own twiddle)
 // The table is kept as eight 4-byte word planes (word l of entry e at tw[l * 2^(m-1) + e]): consecutive lanes read
 // consecutive words, where 32-byte packed entries made every 16-byte read a two-way conflict.
+// Only the first TW_STAGED = 128 staged entries live in LDS (4 KB): they serve every round up to stages (6, 7).  The last round of
+// a 2^9 / 2^10 DFT (stages 8, 9: entries up to 511) fetches its twiddles from the global table, which is 8 / 16 KB and stays in the
+// L1 / L2 (round 3).  Why: a 2^10 tile with 16 KB of staged twiddles takes 52 KB of LDS — three workgroups per CU, so the 1024 tiles
+// of a 2^20 pass ran as 768 + 256: a second, one-third-full round.  With 4 KB it is 40 KB: four per CU, all 1024 tiles resident at once.
+constexpr uint32_t TW_STAGED = 128;
+__device__ __forceinline__ uint32_t tw_staged_count(uint32_t m) { return min(1u << (m - 1), TW_STAGED); }
 __device__ __forceinline__ void stage_twiddles(uint32_t* tw, const fe* loc, uint32_t m) {
   if (m == 0) return;
-  const uint32_t cnt = 1u << (m - 1);
-  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const fe x = fe_load(&loc[i]);
-    const uint32_t j = bitrev(i, m - 1);
+  const uint32_t cnt = tw_staged_count(m);
+  for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+    const fe x = fe_load(&loc[bitrev(j, m - 1)]);
 #pragma unroll
     for (int l = 0; l < 8; l++) tw[l * cnt + j] = x.v[l];
   }
@@ -156,10 +161,15 @@ __device__ __forceinline__ f29 tw_get(const uint32_t* tw, uint32_t cnt, uint32_t
   for (int l = 0; l < 8; l++) w[l] = tw[l * cnt + j];
   return f29_unpack(w);
 }
-__device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const uint32_t* tw, uint32_t m, uint32_t logC) {
+// staged index j of a round that starts at stage s: LDS while the round's entries (j < 2^(s+1)) are all staged, else the global table
+__device__ __forceinline__ f29 tw_fetch(const uint32_t* tw, uint32_t cnt, const fe* loc, uint32_t m, uint32_t s, uint32_t j) {
+  if ((2u << s) <= cnt) return tw_get(tw, cnt, j);
+  return load_unpack(&loc[bitrev(j, m - 1)]);
+}
+__device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const uint32_t* tw, const fe* loc, uint32_t m, uint32_t logC) {
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   if (m == 0) return;
-  const uint32_t tcnt = 1u << (m - 1);
+  const uint32_t tcnt = tw_staged_count(m);
   uint32_t s = 0;
   if (m >= 2) {
     const uint32_t nq = 1u << (m - 2 + logC);
@@ -181,18 +191,18 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
         f29 t1 = x1, t3 = x3;
         const uint32_t pb = bitrev(pos, s);  // the twiddle table is staged in bit-reversed order (see stage_twiddles)
         if (s != 0) {
-          f29 wa = tw_get(tw, tcnt, pb);
+          f29 wa = tw_fetch(tw, tcnt, loc, m, s, pb);
           t1 = f29_mul<F9>(x1, wa);
           t3 = f29_mul<F9>(x3, wa);
         }
         f29 a0 = f29_add(x0, t1), a1 = f29_sub(x0, t1, F9::K2);
         f29 a2 = f29_add(x2, t3), a3 = f29_sub(x2, t3, F9::K2);
-        f29 u3 = f29_mul<F9>(a3, tw_get(tw, tcnt, 2 * pb + 1));
+        f29 u3 = f29_mul<F9>(a3, tw_fetch(tw, tcnt, loc, m, s, 2 * pb + 1));
         if (s == 0) {  // pos = 0: the twiddle of (a0, a2) is omega^0 — no multiplication; a2 = x2 + x3 < 4p, limbs < 2^30
           lds_put(lds, dstride, i, f29_normalize(f29_add(a0, a2)));
           lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, a2, F9::KW4)));
         } else {
-          f29 u2 = f29_mul<F9>(a2, tw_get(tw, tcnt, 2 * pb));
+          f29 u2 = f29_mul<F9>(a2, tw_fetch(tw, tcnt, loc, m, s, 2 * pb));
           lds_put(lds, dstride, i, f29_normalize(f29_add(a0, u2)));
           lds_put(lds, dstride, i + 2 * h, f29_normalize(f29_sub(a0, u2, F9::K2)));
         }
@@ -213,7 +223,7 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
       uint32_t i = (c << m) | (grp << (s + 1)) | pos;
       f29 u = lds_get(lds, dstride, i), v = lds_get(lds, dstride, i + half);
       f29 t = v;
-      if (s != 0) t = f29_mul<F9>(v, tw_get(tw, tcnt, bitrev(pos, s)));
+      if (s != 0) t = f29_mul<F9>(v, tw_fetch(tw, tcnt, loc, m, s ? s - 1 : 0, bitrev(pos, s)));
       lds_put(lds, dstride, i, f29_normalize(f29_add(u, t)));
       lds_put(lds, dstride, i + half, f29_normalize(f29_sub(u, t, F9::K2)));
     }
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   const uint32_t m = M ? M : p.m, logC = (DS && M) ? (uint32_t)(__builtin_ctz(DS ? DS : 1u) - M) : p.logC, C = 1u << logC;
   const uint32_t dstride = DS ? DS : (C << m);
   uint32_t* lds = h2_smem;
-  uint32_t* tw = lds + 9 * dstride;  // 8 word planes of packed twiddles: keeps a 2^10 tile at 52 KiB = 3 blocks/CU
+  uint32_t* tw = lds + 9 * dstride;  // 8 word planes of packed twiddles, at most TW_STAGED entries: a 2^10 tile is 40 KiB = 4 blocks/CU
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t logS = p.log_seg - m;
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   }
   stage_twiddles(tw, p.loc, m);
   __syncthreads();
-  local_ntt(lds, dstride, tw, m, logC);
+  local_ntt(lds, dstride, tw, p.loc, m, logC);
   const uint32_t sh = p.log_n - p.log_seg;
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   }
   stage_twiddles(tw, p.loc, m);
   __syncthreads();
-  local_ntt(lds, dstride, tw, m, logC);
+  local_ntt(lds, dstride, tw, p.loc, m, logC);
   // the caller's post-scale also brings the lazily accumulated value back below 2p
   const f29 fin = p.post;
   for (uint32_t o = tid; o < (C << m); o += T) {
@@ -1319,6 +1329,15 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
 
 static void choose_split(uint32_t log_n, Plan* pl) {
   static const uint32_t MAXM = getenv("H2MI_NTT_MAXM") ? (uint32_t)atoi(getenv("H2MI_NTT_MAXM")) : 10;  // tuning knob (7 .. 10)
+  if (const char* ev = getenv("H2MI_NTT_SPLIT")) {  // tuning knob: "8,8,4" — used for the size whose log_n the parts add up to
+    uint32_t a = 0, b = 0, c = 0;
+    const int got = sscanf(ev, "%u,%u,%u", &a, &b, &c);
+    if (got >= 2 && a + b + c == log_n && a >= 1 && b >= 1 && a <= 10 && b <= 10 && c <= 10) {
+      pl->P = c ? 3 : 2;
+      pl->m[0] = a; pl->m[1] = b; pl->m[2] = c;
+      return;
+    }
+  }
   if (log_n <= MAXM) {
     pl->P = 1;
     pl->m[0] = log_n;
@@ -1476,6 +1495,9 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
   H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_col<DS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
   H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass_row<DS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     H2_NTT_ATTR(0, 0);
+    H2_NTT_ATTR(1024, 4);
+    H2_NTT_ATTR(1024, 5);
+    H2_NTT_ATTR(1024, 6);
     H2_NTT_ATTR(1024, 7);
     H2_NTT_ATTR(1024, 8);
     H2_NTT_ATTR(1024, 9);
@@ -1492,6 +1514,9 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     else if (fixed_ && pp.m == 9) H2_LAUNCH(NAME, (KERNEL<1024, 9>), nblocks, nthreads, shmem, s, pp);                     \
     else if (fixed_ && pp.m == 8) H2_LAUNCH(NAME, (KERNEL<1024, 8>), nblocks, nthreads, shmem, s, pp);                     \
     else if (fixed_ && pp.m == 7) H2_LAUNCH(NAME, (KERNEL<1024, 7>), nblocks, nthreads, shmem, s, pp);                     \
+    else if (fixed_ && pp.m == 6) H2_LAUNCH(NAME, (KERNEL<1024, 6>), nblocks, nthreads, shmem, s, pp);                     \
+    else if (fixed_ && pp.m == 5) H2_LAUNCH(NAME, (KERNEL<1024, 5>), nblocks, nthreads, shmem, s, pp);                     \
+    else if (fixed_ && pp.m == 4) H2_LAUNCH(NAME, (KERNEL<1024, 4>), nblocks, nthreads, shmem, s, pp);                     \
     else H2_LAUNCH(NAME, (KERNEL<0, 0>), nblocks, nthreads, shmem, s, pp);                                                 \
   } while (0)
   // buffer schedule: P=1: a->a ; P=2: a->tmp, tmp->a ; P=3: a->tmp, tmp->tmp, tmp->a
@@ -1524,7 +1549,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       if (logC > logS) logC = logS;
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
-      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + ((size_t)1 << (pp.m - 1)) * 32;
+      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + std::min<size_t>((size_t)1 << (pp.m - 1), TW_STAGED) * 32;
       H2_NTT_LAUNCH("k_ntt_pass_col", k_ntt_pass_col);
     } else {
       pp.has_post = post ? 1 : 0;
@@ -1542,7 +1567,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       if (logC > pp.logN1) logC = pp.logN1;
       pp.logC = logC;
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
-      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + (pp.m ? ((size_t)1 << (pp.m - 1)) : 1) * 32;
+      size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + (pp.m ? std::min<size_t>((size_t)1 << (pp.m - 1), TW_STAGED) : 1) * 32;
       H2_NTT_LAUNCH("k_ntt_pass_row", k_ntt_pass_row);
     }
     log_seg -= pp.m;
