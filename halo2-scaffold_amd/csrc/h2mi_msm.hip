@@ -1037,7 +1037,10 @@ static uint32_t pick_window(size_t n) {
   // Round 3, after the shared-reduction Y3 (f29_mul2) and the cheaper reductions: c = 17 re-measured against 16, alternating on one
   // box: 2^20: create_proof 13.2 - 14.4 -> 12.8 - 13.0 ms (minimum of 12), replay step 19.2 - 19.9 -> 18.8 - 19.1 ms; 2^19: neutral
   // (MSM 764 -> 732 us back-to-back, proofs 8.0 - 8.2 either way); 2^18 and 2^17: 16 stays (434 -> 455, 249 -> 266 us) — 17 from 2^20.
-  int c = lg >= 22 ? 20 : lg >= 20 ? 17 : lg >= 15 ? 16 : lg >= 11 ? 15 : 13;
+  // 2^15 / 2^16 re-measured inside whole proofs (C++ host, alternating, late round 3): 15-bit windows 3.04 / 3.24 ms against 3.10 / 3.37 with
+  // 16 (the halo2_lib shape at 2^16: 3.32 against 3.58) — half the buckets for the latency-bound reductions outweigh one more window;
+  // equal at 2^17 and 2^18: 16 from 2^17.
+  int c = lg >= 22 ? 20 : lg >= 20 ? 17 : lg >= 17 ? 16 : lg >= 11 ? 15 : 13;
   return (uint32_t)c;
 }
 

@@ -812,7 +812,7 @@ def test_task_size_override_is_clamped_to_buffer_capacity(gpu):
     params.release()
 
 
-@pytest.mark.parametrize("c", [17, 14, 12, 11])
+@pytest.mark.parametrize("c", [17, 16, 14, 12, 11])  # 16: the default from 2^17, which no oracle-sized case reaches by itself
 def test_window_width_override_matches_default(gpu, c):
     """H2MI_MSM_C picks another window width at registration: 17 is the widest supported (2^16 buckets, 128
     per partition bin), 14 leaves a thin top window (hot buckets), 12 and 11 take the run-time digit loop, 11
