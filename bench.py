@@ -465,6 +465,19 @@ def time_halo2_lib_examples(h2, R):
     big = ParamsKZG.setup(22, 0x5EC2E7 + 0x48324D49)
     out["range_lookup16_k22"] = run(big, rng, lambda x: flex.range_closure(rng, x, 16), 3)
     big.release()
+    # the same three proofs through the C++ host (examples/halo2_lib.cpp over include/h2mi_flex.hpp: same C ABI, same proof bytes —
+    # tests/test_gpu_big_golden.py), as a child process; optional evidence, never allowed to lose the headline line
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "halo2_lib")
+    for name, shape, k, bits, proofs in (("halo2_lib_k20", "halo2_lib", 20, 0, 8), ("poseidon_k20", "poseidon", 20, 0, 8), ("range_lookup16_k22", "range", 22, 16, 4)):
+        try:
+            r = subprocess.run([exe, shape, str(k), str(bits), "77", hex(0x5EC2E7 + 0x48324D49), "1"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, H2MI_PROOFS=str(proofs)))
+            line = next(l for l in r.stdout.splitlines() if l.startswith("steady_ms_per_proof"))
+            out[name]["cpp_host_ms"] = round(float(line.split()[1]), 3)
+        except Exception as e:
+            out[name]["cpp_host_error"] = repr(e)[:200]
     return out
 
 
