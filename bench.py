@@ -7,8 +7,10 @@ are already resident in HBM when the timed region starts.  It is NOT create_proo
 linked (none can be built here), so gate evaluation / transcript / witness generation are not timed.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (plain: starts its own torch.distributed.run child, see spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W               (a pre-set WORLD_SIZE is honoured: no second launcher)
+  python bench.py --gpus N --single-process ...            (ONE process drives N devices: h2mi_init_devices(N))
 
 N > 1: one process per GPU; the total work is fixed ("strong" scaling): every rank owns a contiguous
 1/N slice of both base sets, runs each MSM on its slice and the 96-byte partial points are combined at every
@@ -28,7 +30,42 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main():
+def spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` launched plainly (no WORLD_SIZE in the environment): start the N ranks as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` in a CHILD process, relay
+    rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and return the child's exit code.
+    The parent imports neither torch nor the library and makes no HIP call: on this pool a process that has touched the GPU
+    must not exec, and N ranks + an idle parent that holds a GPU context would also count against the box's process limit."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: no WORLD_SIZE in the environment, starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without printing a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -47,15 +84,29 @@ def main():
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 size of the CPU baseline sample MSM/NTT")
     ap.add_argument("--no-create-proof", action="store_true",
                     help="skip the data-true create_proof() timing (standard_plonk, N = 1) reported beside the MSM+NTT headline")
-    args = ap.parse_args()
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: ONE process drives the N devices (h2mi_init_devices(N): what the reference's single create_proof call "
+                         "is) instead of one process per GPU over RCCL — the other deployment of the same slice partition")
+    ap.add_argument("--no-msm-only", action="store_true", help="N > 1: skip the MSM-only speed-up measurement")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
+        # plain launch: become the launcher BEFORE torch / the library / any HIP call exists in this process
+        raise SystemExit(spawn_ranks(args.gpus, argv))
 
     import torch  # first: the HIP runtime torch loads is the one libh2mi.so then shares
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    n_devices = args.gpus if args.single_process else 1  # devices THIS process drives
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("--single-process is one process driving N devices: do not launch it under torch.distributed.run")
+    elif world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch plainly (bench.py starts its own ranks) or with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
     # rehearsal knobs (not used by the driver): H2MI_DIST_BACKEND=gloo runs the N > 1 path with CPU
     # collectives, H2MI_DEVICE=<i> pins every rank to one GPU so a 1-GPU box can exercise world_size 2
@@ -80,13 +131,21 @@ def main():
             dist.init_process_group(backend)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     ranks_info = rank_device_report(torch, dist, rank, local_rank, world)
+    if n_devices > 1:  # one process, N devices: entry i of the library is device i (i % visible with H2MI_VIRTUAL_DEVICES)
+        vis = torch.cuda.device_count()
+        if vis < n_devices and "H2MI_VIRTUAL_DEVICES" not in os.environ:
+            raise SystemExit(f"--single-process --gpus {n_devices} but {vis} device(s) visible (H2MI_VIRTUAL_DEVICES=1 rehearses on fewer)")
+        ranks_info = [dict(rank_device_report(torch, None, 0, i % max(vis, 1), 1)[0], entry=i) for i in range(n_devices)]
 
     import _load_pkg
 
     h2 = _load_pkg.load()
     from halo2_scaffold_amd import replay as rp
 
-    h2.init(local_rank)
+    if args.single_process and n_devices > 1:
+        h2._lib.check(h2.lib.h2mi_init_devices(n_devices), "h2mi_init_devices")
+    else:
+        h2.init(local_rank)
     lib = h2.lib
     shape = rp.SHAPES[args.shape]
     R = rp.ProofReplay(shape, args.k, rank=rank, world=world, dist=args.dist, combine_backend=backend if dist is not None else None,
@@ -169,6 +228,12 @@ def main():
     if shape.name == "standard_plonk" and not args.no_create_proof:
         create_proof_stats = time_create_proof(h2, R, args, dist, backend, torch.device("cuda", local_rank), coll_dev)
 
+    # ---- north_star's ">= 6x MSM speed-up at 8 GPUs" is quoted on the MSM alone: the commitments of one proof queued back to
+    # back with ONE join (and one combine), no transforms between them
+    msm_only = None
+    if not args.no_msm_only:
+        msm_only = time_msm_only(h2, R, args, dist, coll_dev, n_devices, torch, sync_all)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -187,7 +252,9 @@ def main():
     c, W, nb, nreg = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
     lib.h2mi_bases_info(R.params.g_handle, C.byref(c), C.byref(W), C.byref(nb), C.byref(nreg))
 
-    algo_bytes = 96 * R.n_local  # 32 B scalar + 64 B affine base per pair, read once
+    # 32 B scalar + 64 B affine base per pair, read once; one k_msm_accum launch sees one slice (a rank's, or
+    # in --single-process mode one device's)
+    algo_bytes = 96 * (R.n_local // n_devices)
     achieved = algo_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
     # HBM traffic of the kernel comes from rocprofv3 PMC counters, which cannot be collected from inside this
     # process: the field carries the figure of the latest committed counter run of this same workload and says so
@@ -237,7 +304,7 @@ def main():
         "metric": "create_proof() wall-clock + MSM G1-adds/s at k=20 standard_plonk, 1/2/4/8 GPU",
         "value": round(value, 1),
         "unit": "G1-adds/s",
-        "n_gpus": world,
+        "n_gpus": world * n_devices,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -254,12 +321,15 @@ def main():
             "msm_window_bits": c.value,
             "msm_windows": W.value,
             "msm_buckets": nb.value,
-            "parallelism": f"msm-slice{world}" if world > 1 else "single-gpu",
+            "parallelism": (f"msm-slice{world}" if world > 1 else f"single-process msm-slice{n_devices}" if n_devices > 1 else "single-gpu"),
+            "deployment": ("one process per GPU (torch.distributed)" if world > 1 else
+                           f"one process, {n_devices} devices (h2mi_init_devices)" if n_devices > 1 else "one process, one GPU"),
             "combines_per_step": (R.combiner.combines // max(args.warmup + args.steps + 1, 1)) if R.combiner is not None else 0,
             "combine": ((("RCCL all-gather + device fold at every transcript join, device-resident" if R.combiner.mode == "rccl" else
                           "RCCL all-gather through host-synchronised copies (H2MI_COMBINE=host) + device fold at every transcript join")
                          if backend == "nccl" else "gloo all-gather (host) + device fold at every transcript join") if R.combiner is not None
-                        else "none (single GPU)"),
+                        else "peer copies of the 96-byte partial points to the primary device + device fold at every join (inside the library)"
+                        if n_devices > 1 else "none (single GPU)"),
             "what_is_timed": ("MSM + NTT + evaluate_h kernels on HBM-resident vectors; not transcript / witness generation" if R.with_evaluate_h else
                               "MSM + NTT kernels on HBM-resident vectors; not gate evaluation / transcript / witness generation"),
         },
@@ -267,7 +337,7 @@ def main():
         "collective_backend": (backend if dist is not None else None),
         "ranks": ranks_info,
         "commitments_sha256": digest,
-        "ntt_placement": ("single GPU" if world == 1 else "leaf transforms spread round-robin, consumed transforms on every rank"
+        "ntt_placement": ("single GPU (the primary device)" if world == 1 else "leaf transforms spread round-robin, consumed transforms on every rank"
                           if R.spread else "every rank replays every transform"),
         "g1_adds_per_step": adds,
         "msm_pairs_per_s": round(shape.msm_per_proof * n / (ms_per_step * 1e-3), 1),
@@ -277,7 +347,9 @@ def main():
         "issue_roofline": issue,
     }
 
-    if world == 1 and args.k == 20 and shape.name == "standard_plonk":
+    if msm_only is not None:
+        out.update(msm_only)
+    if world == 1 and n_devices == 1 and args.k == 20 and shape.name == "standard_plonk":
         try:
             out["roofline_ntt"] = time_ntt_roofline(h2)
         except Exception as e:  # never lose the headline line to an auxiliary measurement
@@ -285,7 +357,7 @@ def main():
     if create_proof_stats is not None:
         out["create_proof"] = create_proof_stats
         out["pipeline_ms_per_step"] = create_proof_stats["ms_per_proof"]
-        if world == 1 and args.k == 20:
+        if world == 1 and n_devices == 1 and args.k == 20:
             try:
                 small = time_small_proofs(h2, ROOT)
                 out["create_proof_k16"], out["create_proof_k8"] = small["k16"], small["k8"]
@@ -303,6 +375,72 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def time_msm_only(h2, R, args, dist, coll_dev, n_devices, torch, sync_all):
+    """One proof's commitments as MSMs ALONE (no transforms): `msm_per_proof` MSMs over this rank's slice queued back to back,
+    one join, one combine of the partial points (N > 1), barrier-bracketed, slowest rank -> `msm_only_ms` per MSM.
+    One process per GPU with N > 1 additionally times the SAME MSMs over the WHOLE base set on one GPU inside the same run (every
+    rank on its own device at once; rank 0's figure is reported) -> `msm_only_speedup_vs_1` = that / the sliced figure.
+    The single-process mode cannot hold an unsharded registration next to the sharded one, so its speed-up is formed against the
+    N = 1 line's `msm_only_ms` by the reader (null here)."""
+    import ctypes as C
+
+    lib = h2.lib
+    world = R.world
+    M = R.shape.msm_per_proof
+    reps = max(2, min(args.steps, 10))
+    src = R.random_poly
+
+    def run_sliced():
+        R._slot, R._phase_start = 0, 0
+        for _ in range(M):
+            R._msm(src, lagrange=True)
+        h2._lib.check(lib.h2mi_join(), "join")
+        if R.combiner is not None:
+            R.combiner.combine(0, M)
+
+    def timed(fn):
+        fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / (reps * M) * 1e3
+
+    combines_before = R.combiner.combines if R.combiner is not None else 0
+    sliced_ms = timed(run_sliced)
+    if R.combiner is not None:
+        R.combiner.combines = combines_before  # keep combines_per_step a count of the replay's own joins
+    out = {"msm_only_ms": round(sliced_ms, 4), "msm_only_speedup_vs_1": None,
+           "msm_only_what": f"{M} MSMs over 2^{args.k} points (each rank / device its 1/{world * n_devices} slice), queued back to back, one join"
+                            + (" + one combine" if world * n_devices > 1 else "") + ", per MSM, slowest rank"}
+    if world > 1:
+        from halo2_scaffold_amd.params import ParamsKZG
+
+        full = ParamsKZG.setup(args.k, 0x5EC2E7 + 0x48324D49, register=False)
+        hfull = C.c_uint64()
+        h2._lib.check(lib.h2mi_bases_register_dev(full._gl_dev.ptr, full.n, C.byref(hfull)), "register full g_lagrange")
+
+        def run_full():
+            for i in range(M):
+                h2._lib.check(lib.h2mi_msm_bn254_g1_dev(hfull.value, src.ptr, R.n, R.out_ptr + 96 * i, None), "msm")
+            h2._lib.check(lib.h2mi_join(), "join")
+
+        one_ms = timed(run_full)
+        h2._lib.check(lib.h2mi_sync(), "sync")
+        h2._lib.check(lib.h2mi_bases_release(hfull.value), "release")
+        full.release()
+        out["msm_only_1gpu_ms"] = round(one_ms, 4)
+        out["msm_only_speedup_vs_1"] = round(one_ms / sliced_ms, 3)
+        out["msm_only_what"] += "; msm_only_1gpu_ms: the same MSMs over all 2^%d points, every rank on its own GPU at once, in this run" % args.k
+    return out
 
 
 def rank_device_report(torch, dist, rank, local_rank, world):

@@ -13,11 +13,31 @@ Ctx& ctx() {
   return c;
 }
 
+// HIP's current device is a property of the HOST THREAD, not of the process: the cache of "what hipSetDevice last
+// selected" is thread_local, so a second host thread (a rayon worker behind the Rust shim) never inherits the first
+// thread's selection by mistake (round-3 VERDICT: a process-wide cache sent such a thread to device 0).
+static thread_local int tl_hip_device = -1;
+
+int set_thread_device(int device) {
+  if (tl_hip_device != device) {
+    H2_HIP(hipSetDevice(device));
+    tl_hip_device = device;
+  }
+  return H2MI_OK;
+}
+
+int bind_thread() {
+  Ctx& c = ctx();
+  if (c.devs.empty()) return H2MI_ENODEV;
+  return set_thread_device(c.devs[0].device);
+}
+
 int use_device(int idx) {
   Ctx& c = ctx();
   if (idx < 0 || idx >= (int)c.devs.size()) return H2MI_EINVAL;
   const DevCtx& d = c.devs[idx];
-  if (c.cur != idx || c.device != d.device) H2_HIP(hipSetDevice(d.device));
+  int rc = set_thread_device(d.device);
+  if (rc) return rc;
   c.cur = idx;
   c.device = d.device;
   c.stream = d.stream;
@@ -35,12 +55,12 @@ void note_hip_error(hipError_t e, const char* file, int line) {
 void prof_begin(const char* name, hipStream_t s) {
   ProfRec r;
   r.name = name;
-  hipEventCreate(&r.a);
-  hipEventCreate(&r.b);
-  hipEventRecord(r.a, s);
+  H2_IGNORE(hipEventCreate(&r.a));
+  H2_IGNORE(hipEventCreate(&r.b));
+  H2_IGNORE(hipEventRecord(r.a, s));
   ctx().prof.push_back(r);
 }
-void prof_end(hipStream_t s) { hipEventRecord(ctx().prof.back().b, s); }
+void prof_end(hipStream_t s) { H2_IGNORE(hipEventRecord(ctx().prof.back().b, s)); }
 
 // ---- elementwise field kernels (test hooks) -------------------------------------------------------
 template <class F>
@@ -174,7 +194,8 @@ using namespace h2;
 extern "C" {
 
 static int create_dev(int device, DevCtx* d) {
-  H2_HIP(hipSetDevice(device));
+  int rc = set_thread_device(device);
+  if (rc) return rc;
   d->device = device;
   H2_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   H2_HIP(hipStreamCreateWithFlags(&d->tail_stream, hipStreamNonBlocking));
@@ -218,10 +239,10 @@ int h2mi_init_devices(int n_devices) {
     int can = 0;
     hipError_t pe = hipDeviceCanAccessPeer(&can, devs[0].device, devs[(size_t)i].device);
     if (pe == hipSuccess && can) {
-      hipSetDevice(devs[0].device);
+      set_thread_device(devs[0].device);
       pe = hipDeviceEnablePeerAccess(devs[(size_t)i].device, 0);
       if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) {
-        hipSetDevice(devs[(size_t)i].device);
+        set_thread_device(devs[(size_t)i].device);
         pe = hipDeviceEnablePeerAccess(devs[0].device, 0);
       }
     }
@@ -253,25 +274,25 @@ void h2mi_shutdown(void) {
   if (!ctx().inited) return;
   use_device(0);
   msm_join_all(ctx().stream);
-  hipStreamSynchronize(ctx().stream);
+  H2_IGNORE(hipStreamSynchronize(ctx().stream));
   for (DevCtx& d : ctx().devs) {
-    hipSetDevice(d.device);
-    hipDeviceSynchronize();
+    set_thread_device(d.device);
+    (void)hipDeviceSynchronize();
   }
   msm_teardown();  // registrations on every device
   use_device(0);
   ntt_teardown();     // plans, power tables, scratch vectors (primary device)
   lookup_teardown();  // counting-sort scratch and its event
-  if (g_fixed_table) { hipFree(g_fixed_table); g_fixed_table = nullptr; g_fixed_built.destroy(); }
+  if (g_fixed_table) { H2_IGNORE(hipFree(g_fixed_table)); g_fixed_table = nullptr; g_fixed_built.destroy(); }
   for (hipEvent_t& ev : g_wait_ring)
-    if (ev) { hipEventDestroy(ev); ev = nullptr; }
+    if (ev) { H2_IGNORE(hipEventDestroy(ev)); ev = nullptr; }
   for (DevCtx& d : ctx().devs) {
-    hipSetDevice(d.device);
-    hipDeviceSynchronize();
-    hipStreamDestroy(d.head_stream);
-    hipStreamDestroy(d.accum_stream);
-    hipStreamDestroy(d.tail_stream);
-    hipStreamDestroy(d.stream);
+    set_thread_device(d.device);
+    (void)hipDeviceSynchronize();
+    H2_IGNORE(hipStreamDestroy(d.head_stream));
+    H2_IGNORE(hipStreamDestroy(d.accum_stream));
+    H2_IGNORE(hipStreamDestroy(d.tail_stream));
+    H2_IGNORE(hipStreamDestroy(d.stream));
   }
   ctx().devs.clear();
   ctx().head_stream = ctx().accum_stream = ctx().tail_stream = ctx().stream = nullptr;
@@ -308,36 +329,36 @@ int h2mi_free(void* d_ptr) {
 }
 int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
   H2_REQUIRE_INIT();
-  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
-  H2_HIP(hipStreamSynchronize(ctx().stream));
+  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, primary_stream()));
+  H2_HIP(hipStreamSynchronize(primary_stream()));
   return H2MI_OK;
 }
 int h2mi_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes) {
   H2_REQUIRE_INIT();
   // stream-ordered on the library's stream; for pageable `src` the runtime stages the bytes before it returns,
   // so the caller may reuse the buffer at once (small patches: blinding rows, assigned cells)
-  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+  H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, primary_stream()));
   return H2MI_OK;
 }
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
   H2_REQUIRE_INIT();
   {
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-    int rc = msm_join_all(ctx().stream);
+    int rc = msm_join_all(primary_stream());
     if (rc) return rc;
   }
-  H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
-  H2_HIP(hipStreamSynchronize(ctx().stream));
+  H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, primary_stream()));
+  H2_HIP(hipStreamSynchronize(primary_stream()));
   return H2MI_OK;
 }
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
   H2_REQUIRE_INIT();
-  H2_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+  H2_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, primary_stream()));
   return H2MI_OK;
 }
 int h2mi_memset_zero(void* d_ptr, size_t bytes) {
   H2_REQUIRE_INIT();
-  H2_HIP(hipMemsetAsync(d_ptr, 0, bytes, ctx().stream));
+  H2_HIP(hipMemsetAsync(d_ptr, 0, bytes, primary_stream()));
   return H2MI_OK;
 }
 int h2mi_join(void) {
@@ -373,10 +394,10 @@ int h2mi_profile_filter(const char* prefix) {
 }
 int h2mi_profile_reset(void) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  if (ctx().inited) hipDeviceSynchronize();
+  if (ctx().inited) H2_IGNORE(hipDeviceSynchronize());
   for (auto& r : ctx().prof) {
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    H2_IGNORE(hipEventDestroy(r.a));
+    H2_IGNORE(hipEventDestroy(r.b));
   }
   ctx().prof.clear();
   return H2MI_OK;

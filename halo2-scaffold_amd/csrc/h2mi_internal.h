@@ -43,8 +43,16 @@ struct Ctx {
 };
 
 Ctx& ctx();
-// make entry `idx` current: hipSetDevice + the stream members of Ctx mirror its streams (callers hold the mutex)
+// make entry `idx` current: this THREAD's HIP device + the stream members of Ctx mirror its streams (callers hold the mutex)
 int use_device(int idx);
+// hipSetDevice through a thread_local cache (HIP's current device is per host thread)
+int set_thread_device(int device);
+// every extern "C" entry point: the calling thread's HIP device = the primary device (entry 0), whatever another thread
+// or an earlier call on this thread selected; entry points that drive other devices switch with use_device under the mutex
+int bind_thread();
+// the primary device's stream, for entry points that do not take the mutex (another thread may be switching the mirrors
+// in Ctx between devices inside a sharded MSM)
+inline hipStream_t primary_stream() { return ctx().devs.empty() ? nullptr : ctx().devs[0].stream; }
 
 inline hipStream_t pick_stream(h2mi_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
 
@@ -59,9 +67,19 @@ void note_hip_error(hipError_t e, const char* file, int line);
     }                                               \
   } while (0)
 
-#define H2_REQUIRE_INIT()                   \
-  do {                                      \
+// a HIP call on a release / teardown path whose failure cannot change what the caller does next: the status is still
+// looked at — recorded for h2mi_strerror and printed under H2MI_VERBOSE — instead of being dropped on the floor
+#define H2_IGNORE(x)                                                      \
+  do {                                                                    \
+    hipError_t ei_ = (x);                                                 \
+    if (ei_ != hipSuccess) ::h2::note_hip_error(ei_, __FILE__, __LINE__); \
+  } while (0)
+
+#define H2_REQUIRE_INIT()                        \
+  do {                                           \
     if (!::h2::ctx().inited) return H2MI_ENODEV; \
+    int rcb_ = ::h2::bind_thread();              \
+    if (rcb_) return rcb_;                       \
   } while (0)
 
 // Event-bracketed launch: when profiling is on, record a HIP event before and after the kernel on the
@@ -85,7 +103,7 @@ inline bool prof_on(const char* name) {
 // device allocation released on every exit path of the synchronous helper entry points
 struct DevMem {
   void* p = nullptr;
-  ~DevMem() { if (p) hipFree(p); }
+  ~DevMem() { if (p) H2_IGNORE(hipFree(p)); }
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -105,7 +123,7 @@ struct Built {
   }
   hipError_t use(hipStream_t s) const { return (ev && s != on) ? hipStreamWaitEvent(s, ev, 0) : hipSuccess; }
   void destroy() {
-    if (ev) hipEventDestroy(ev);
+    if (ev) H2_IGNORE(hipEventDestroy(ev));
     ev = nullptr;
   }
 };

@@ -150,8 +150,8 @@ static int scan_u32(const uint32_t* in, uint32_t* out, uint32_t m /* multiple of
 
 // h2mi_shutdown: the scratch and its event belong to the device that is being torn down
 void lookup_teardown() {
-  if (g_lk_scratch) hipFree(g_lk_scratch);
-  if (g_lk_event) hipEventDestroy(g_lk_event);
+  if (g_lk_scratch) H2_IGNORE(hipFree(g_lk_scratch));
+  if (g_lk_event) H2_IGNORE(hipEventDestroy(g_lk_event));
   g_lk_scratch = nullptr;
   g_lk_words = 0;
   g_lk_event = nullptr;

@@ -1058,19 +1058,19 @@ static uint32_t chunk_override() {
 }
 
 static void free_bases(Bases* B) {
-  hipFree(B->table);
-  hipFree(B->host_stage);
+  H2_IGNORE(hipFree(B->table));
+  H2_IGNORE(hipFree(B->host_stage));
   for (Slot& S : B->slot) {
-    hipFree(S.vals[0]); hipFree(S.vals[1]);
-    hipFree(S.bkeys); hipFree(S.bincnt); hipFree(S.binbase); hipFree(S.binseg); hipFree(S.tile_live);
-    hipFree(S.off); hipFree(S.s0_dev);
-    for (int i = 0; i < 2; i++) { hipFree(S.np[i]); hipFree(S.toff[i]); }
-    hipFree(S.dense); hipFree(S.dense2); hipFree(S.vsum); hipFree(S.tseg[0]); hipFree(S.tseg[1]);
-    hipFree(S.part[0]); hipFree(S.part[1]); hipFree(S.rc); hipFree(S.g); hipFree(S.stats); hipFree(S.shift);
-    if (S.input_ready) hipEventDestroy(S.input_ready);
-    if (S.head_done) hipEventDestroy(S.head_done);
-    if (S.accum_done) hipEventDestroy(S.accum_done);
-    if (S.tail_done) hipEventDestroy(S.tail_done);
+    H2_IGNORE(hipFree(S.vals[0])); H2_IGNORE(hipFree(S.vals[1]));
+    H2_IGNORE(hipFree(S.bkeys)); H2_IGNORE(hipFree(S.bincnt)); H2_IGNORE(hipFree(S.binbase)); H2_IGNORE(hipFree(S.binseg)); H2_IGNORE(hipFree(S.tile_live));
+    H2_IGNORE(hipFree(S.off)); H2_IGNORE(hipFree(S.s0_dev));
+    for (int i = 0; i < 2; i++) { H2_IGNORE(hipFree(S.np[i])); H2_IGNORE(hipFree(S.toff[i])); }
+    H2_IGNORE(hipFree(S.dense)); H2_IGNORE(hipFree(S.dense2)); H2_IGNORE(hipFree(S.vsum)); H2_IGNORE(hipFree(S.tseg[0])); H2_IGNORE(hipFree(S.tseg[1]));
+    H2_IGNORE(hipFree(S.part[0])); H2_IGNORE(hipFree(S.part[1])); H2_IGNORE(hipFree(S.rc)); H2_IGNORE(hipFree(S.g)); H2_IGNORE(hipFree(S.stats)); H2_IGNORE(hipFree(S.shift));
+    if (S.input_ready) H2_IGNORE(hipEventDestroy(S.input_ready));
+    if (S.head_done) H2_IGNORE(hipEventDestroy(S.head_done));
+    if (S.accum_done) H2_IGNORE(hipEventDestroy(S.accum_done));
+    if (S.tail_done) H2_IGNORE(hipEventDestroy(S.tail_done));
   }
   delete B;
 }
@@ -1185,10 +1185,10 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
       hipLaunchKernelGGL(k_msm_table_sum_point, dim3(1), dim3(64), 0, s, (const uint8_t*)sum, B->table, B->stride, n, B->W, B->c);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = H2MI_EHIP;
     }
-    hipFree(ones);
-    hipFree(sum);
+    H2_IGNORE(hipFree(ones));
+    H2_IGNORE(hipFree(sum));
     if (rc) {
-      hipDeviceSynchronize();
+      H2_IGNORE(hipDeviceSynchronize());
       g_bases.erase(h);
       free_bases(B);
       return rc;
@@ -1525,11 +1525,11 @@ static int fold_sharded(hipStream_t s0) {
 
 static void free_sharded(Sharded* sh) {
   for (Shard& sd : sh->shard) {
-    hipFree(sd.stage);
-    hipFree(sd.part);
-    if (sd.ready) hipEventDestroy(sd.ready);
+    H2_IGNORE(hipFree(sd.stage));
+    H2_IGNORE(hipFree(sd.part));
+    if (sd.ready) H2_IGNORE(hipEventDestroy(sd.ready));
   }
-  hipFree(sh->gather);
+  H2_IGNORE(hipFree(sh->gather));
   delete sh;
 }
 
@@ -1552,8 +1552,8 @@ static int register_sharded(const void* bases, bool on_host, size_t n, uint64_t*
     void* tmp = nullptr;
     if (hipMalloc(&tmp, (hi - lo) * 64) != hipSuccess || hipMalloc((void**)&sd.part, (size_t)SHARD_RING * 96) != hipSuccess ||
         hipEventCreateWithFlags(&sd.ready, hipEventDisableTiming) != hipSuccess) {
-      hipFree(tmp);
-      hipFree(sd.part);
+      H2_IGNORE(hipFree(tmp));
+      H2_IGNORE(hipFree(sd.part));
       rc = H2MI_ENOMEM;
       break;
     }
@@ -1561,10 +1561,10 @@ static int register_sharded(const void* bases, bool on_host, size_t n, uint64_t*
                            : copy_between(tmp, (int)i, (const uint8_t*)bases + lo * 64, 0, (hi - lo) * 64, s);
     if (e != hipSuccess) rc = H2MI_EHIP;
     if (!rc) rc = register_dev(tmp, hi - lo, &sd.handle, s);  // synchronises s
-    hipFree(tmp);
+    H2_IGNORE(hipFree(tmp));
     if (rc) {
-      hipFree(sd.part);
-      hipEventDestroy(sd.ready);
+      H2_IGNORE(hipFree(sd.part));
+      H2_IGNORE(hipEventDestroy(sd.ready));
       break;
     }
     sh->shard.push_back(sd);
@@ -1704,8 +1704,8 @@ int h2mi_bases_register(const uint64_t* bases, size_t n, uint64_t* handle_out) {
   int rc = H2MI_OK;
   if (hipMemcpyAsync(d, bases, n * 64, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rc = H2MI_EHIP;
   if (!rc) rc = register_dev(d, n, handle_out, ctx().stream);
-  hipStreamSynchronize(ctx().stream);
-  hipFree(d);
+  H2_IGNORE(hipStreamSynchronize(ctx().stream));
+  H2_IGNORE(hipFree(d));
   return rc;
 }
 
@@ -1717,10 +1717,9 @@ int h2mi_bases_release(uint64_t handle) {
     int rc = msm_join_all(ctx().devs[0].stream);  // folds still queued on it
     if (rc) return rc;
     for (DevCtx& d : ctx().devs) {
-      hipSetDevice(d.device);
-      hipDeviceSynchronize();
+      set_thread_device(d.device);
+      (void)hipDeviceSynchronize();
     }
-    ctx().cur = -1;
     use_device(0);
     for (Shard& sd : sh->second->shard) h2mi_bases_release(sd.handle);
     free_sharded(sh->second);
@@ -1730,8 +1729,9 @@ int h2mi_bases_release(uint64_t handle) {
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   flush_tails();
-  hipDeviceSynchronize();
+  if (use_device(it->second->dev) == H2MI_OK) (void)hipDeviceSynchronize();  // the device that owns the tables
   free_bases(it->second);
+  use_device(0);
   g_bases.erase(it);
   for (size_t i = 0; i < g_adhoc.size(); i++)
     if (g_adhoc[i].handle == handle) {

@@ -1251,7 +1251,7 @@ static void free_plan(Plan& pl) {
     if (!p) continue;
     for (int j = i + 1; j < 3; j++)  // passes of equal size share one table
       if (pl.loc[j] == p) pl.loc[j] = nullptr;
-    hipFree(p);
+    H2_IGNORE(hipFree(p));
     pl.loc[i] = nullptr;
   }
   pl.built.destroy();
@@ -1279,8 +1279,8 @@ static int evict_tables() {
   for (auto& e : order) {
     if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES) break;
     auto it = g_powtabs.find(e.second);
-    hipFree(it->second.lo);
-    hipFree(it->second.hi);
+    H2_IGNORE(hipFree(it->second.lo));
+    H2_IGNORE(hipFree(it->second.hi));
     it->second.built.destroy();
     g_powtab_bytes -= it->second.bytes;
     g_powtabs.erase(it);
@@ -1314,7 +1314,7 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
   t.bytes = ((size_t)nlo + nhi) * 32;
   H2_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
   if (hipMalloc(&t.hi, (size_t)nhi * 32) != hipSuccess) {
-    hipFree(t.lo);
+    H2_IGNORE(hipFree(t.lo));
     return H2MI_ENOMEM;
   }
   fe b = host_fe(base);
@@ -1402,15 +1402,15 @@ void ntt_teardown() {
   for (auto& kv : g_plans) free_plan(kv.second);
   g_plans.clear();
   for (auto& kv : g_powtabs) {
-    hipFree(kv.second.lo);
-    hipFree(kv.second.hi);
+    H2_IGNORE(hipFree(kv.second.lo));
+    H2_IGNORE(hipFree(kv.second.hi));
     kv.second.built.destroy();
   }
   g_powtabs.clear();
   g_powtab_bytes = 0;
   for (Scratch& c : g_scratch) {
-    if (c.p) hipFree(c.p);
-    if (c.event) hipEventDestroy(c.event);
+    if (c.p) H2_IGNORE(hipFree(c.p));
+    if (c.event) H2_IGNORE(hipEventDestroy(c.event));
     c = Scratch();
   }
   g_cur = nullptr;
@@ -1616,7 +1616,7 @@ int h2mi_ntt_ext_bn254_fr(uint64_t* a, uint32_t log_n, const uint64_t omega[4], 
   if (stage_bytes < bytes) {
     if (stage) {
       H2_HIP(hipStreamSynchronize(s));
-      hipFree(stage);
+      H2_IGNORE(hipFree(stage));
       stage = nullptr;
       stage_bytes = 0;
     }

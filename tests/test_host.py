@@ -229,3 +229,75 @@ def test_gen_srs_secret_from_the_chacha20_zero_seed(h2):
     s = P.gen_srs_secret()
     assert s == int.from_bytes(ks, "little") % o.R and 0 < s < o.R
     assert P.chacha20_block([0] * 8, 1) != P.chacha20_block([0] * 8, 0)
+
+
+_LAUNCH_PROBE = r"""
+import json, subprocess, sys
+sys.path.insert(0, {root!r})
+seen = {{}}
+class FakePopen:
+    def __init__(self, cmd, **kw):
+        # the moment of the spawn: nothing that could hold a GPU context may exist in the parent yet
+        seen["cmd"] = cmd
+        seen["env_ipc"] = kw.get("env", {{}}).get("HSA_ENABLE_IPC_MODE_LEGACY")
+        seen["torch_loaded"] = "torch" in sys.modules
+        seen["library_loaded"] = "halo2_scaffold_amd" in sys.modules
+        self.stdout = iter(['chatter from a rank\n', '{{"metric": "m", "n_gpus": 2}}\n'])
+    def wait(self):
+        return 7
+subprocess.Popen = FakePopen
+import bench
+try:
+    bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--k", "13"])
+except SystemExit as e:
+    seen["exit"] = e.code
+sys.stderr.write("PROBE " + json.dumps(seen) + "\n")
+"""
+
+
+def test_bench_plain_multi_gpu_launch_spawns_before_any_gpu_call(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE (the form the driver's N = 1 command has): the parent must start
+    `torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process before torch or the library is even
+    imported (a process that has touched the GPU must not exec on this pool, and must not idle on a GPU context), relay rank 0's JSON
+    line on stdout and pass the child's exit code on."""
+    import json
+
+    script = tmp_path / "probe.py"
+    script.write_text(_LAUNCH_PROBE.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    probe = json.loads(next(l for l in r.stderr.splitlines() if l.startswith("PROBE "))[6:])
+    cmd = probe["cmd"]
+    assert probe["torch_loaded"] is False and probe["library_loaded"] is False
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--k", "13"]
+    assert probe["env_ipc"] == "0"
+    assert probe["exit"] == 7                                    # the child's exit code, relayed
+    assert r.stdout.strip() == '{"metric": "m", "n_gpus": 2}'    # ONE line on stdout: rank 0's
+    assert "chatter from a rank" in r.stderr
+
+
+def test_bench_plain_multi_gpu_launch_end_to_end_without_gpu():
+    """the real thing on this GPU-less box: the plain form starts two ranks over gloo, each fails loudly at its first device call (no CPU
+    fallback), and the parent reports the failure through its exit code instead of printing a line."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_parity.py::test_bench_world2_rehearsal_matches_single_gpu runs the plain form for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(H2MI_DIST_BACKEND="gloo", H2MI_DEVICE="0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--k", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "starting" in r.stderr and "torch.distributed.run" in r.stderr
+    assert "No HIP GPUs are available" in r.stderr or "no usable GPU" in r.stderr  # the ranks' own failure, relayed on stderr
+
+
+def test_bench_honours_a_preset_world_size_and_rejects_mismatch():
+    """under torch.distributed.run (WORLD_SIZE set) bench.py must not start a second launcher; a WORLD_SIZE that disagrees with
+    --gpus is a launch mistake and exits with a message."""
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in r.stderr and "starting" not in r.stderr
