@@ -6,7 +6,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libh2mi.so")
+    """the product library next to this file; H2MI_LIBRARY=<path> selects another build of the same sources (the -DH2MI_AB
+    build `make -C csrc ab` makes for the sweep tools: the product never needs it)"""
+    return os.environ.get("H2MI_LIBRARY") or os.path.join(_HERE, "libh2mi.so")
 
 
 class H2miError(RuntimeError):
@@ -53,6 +55,7 @@ def _load():
         "h2mi_msm_adhoc_builds": ([u64p], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),
         "h2mi_msm_set_canonical": ([C.c_int], C.c_int),
+        "h2mi_dbg_msm_small_path": ([C.c_int], C.c_int),
         "h2mi_fe_to_repr_dev": ([C.c_int, vp, sz, vp, vp], C.c_int),
         "h2mi_fe_from_repr_dev": ([C.c_int, vp, sz, vp, u64p], C.c_int),
         "h2mi_g1_compress_dev": ([vp, sz, vp, vp], C.c_int),

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -138,6 +139,16 @@ int msm_flush_all();
 void msm_teardown();
 void ntt_teardown();
 void lookup_teardown();
+
+// Tuning / A-B knobs (window overrides, occupancy experiments, measured losers kept for re-measurement) exist only in a library
+// built with -DH2MI_AB (`make ab` -> libh2mi_ab.so, used by tools/*sweep* and tools/ab_*.sh): the shipped libh2mi.so holds the
+// measured winners and reads no tuning variable.  Configuration that tests and rehearsals rely on (H2MI_VERBOSE,
+// H2MI_VIRTUAL_DEVICES, H2MI_MSM_C / H2MI_MSM_S0 / H2MI_MSM_NO_PIPELINE forced-path parity, H2MI_POWTAB_MAX) stays a plain getenv.
+#ifdef H2MI_AB
+inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+inline const char* ab_env(const char*) { return nullptr; }
+#endif
 
 inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 

@@ -96,6 +96,12 @@ struct Slot {
   bool tail_deferred = false;   // accumulation queued, bucket reduction not yet launched (see flush_tails)
   void* d_out = nullptr;        // where that reduction will write the result
   uint32_t tasks1 = 0;          // its fold grid bound
+  // small base sets (see "small base sets" below): signed digit bytes [Ws][n], per-workgroup partial sums and entry counts
+  uint8_t* sdig = nullptr;
+  uint8_t* spart = nullptr;
+  uint32_t* scnt = nullptr;
+  bool small_deferred = false;  // the deferred work of this slot is the small path's accumulate + final pair
+  uint32_t small_n = 0;         // points of that MSM
 };
 // slots per handle = MSMs that can be in flight between two joins before a flush is forced
 // Eight for base sets up to 2^17 (round 3): with four, every fifth back-to-back MSM waited for the reduction batch of the four
@@ -119,6 +125,10 @@ struct Bases {
   int nslot = NSLOT;            // slots in use (allocated) for this handle
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0;
+  // small base sets (n <= SMALL_MAX_N): second table with narrow windows, 2^(sc - 1) buckets, sS slices of sP points
+  bool small = false;
+  uint32_t sc = 0, sW = 0, sS = 0, sP = 0;
+  uint8_t* stable = nullptr;    // [sW][n] affine
 };
 
 static std::map<uint64_t, Bases*> g_bases;
@@ -133,6 +143,7 @@ static std::vector<AdHoc> g_adhoc;
 static uint64_t g_adhoc_clock = 0, g_adhoc_builds = 0;
 constexpr size_t ADHOC_MAX = 4;  // g, g_lagrange and a couple of slices
 static bool g_canonical = false;
+static bool g_small_path = true;  // h2mi_dbg_msm_small_path(0): small base sets take the general pipeline (parity tests, A/B)
 static uint64_t g_next_handle = 1;
 
 // ---- registration: table[w][i] = 2^(c*w) * P_i, stored as canonical Montgomery-2^261 words -------------
@@ -990,6 +1001,178 @@ __global__ void __launch_bounds__(128) k_msm_final(const TailBatch tb) {
   }
 }
 
+// ---- small base sets: n <= SMALL_MAX_N (round 4) --------------------------------------------------------------------
+// The pipeline above is built for throughput: nine partition kernels, an accumulation over >= 2^12 buckets and a
+// five-kernel bucket reduction whose chain of ~40 dependent point operations is the same at every size — 217 us for a
+// 256-point MSM (profiles/r03_op_bench.json), six times per proof of the reference's own example (k = 5 .. 8).  A small
+// MSM is pure latency, so it gets a path whose chain is as short as the arithmetic allows:
+//   * narrow signed windows cs = 3 .. 5 against a second table 2^(cs w) P_i (W = 51 .. 85 rows of n points: kilobytes to a few
+//     megabytes): 4 .. 16 buckets instead of 4096 .. 16384 — the weighted bucket sum needs 2 (cs - 1) + 3 levels, not ~35;
+//   * k_msm_small_digits (on the caller's stream: the only reader of the scalars): one thread per scalar, Montgomery ->
+//     canonical, W signed digits as bytes;
+//   * k_msm_small_accum, one workgroup per (bucket, slice of points): scans the slice's digit bytes, collects the entries
+//     of its bucket in LDS (no sort: 2^(cs-1) workgroups read the same bytes), every lane sums its share with mixed
+//     additions, then a quad tree in LDS -> one partial sum per workgroup;
+//   * k_msm_small_final, one workgroup per MSM: the <= 256 partial sums -> bucket sums (segmented tree), the bit-sliced
+//     weights A_j = sum over buckets with bit j of (b + 1) set, 2^j A_j by j doublings in parallel, a last tree, Jacobian out.
+// The last two are deferred and batched over the MSMs queued since the last join exactly like the bucket reductions above
+// (blockIdx.y = MSM): a prover phase of four commitments is four digit launches + two launches.
+constexpr size_t SMALL_MAX_N = 4096;
+constexpr uint32_t SMALL_THREADS = 256, SMALL_PARTS_MAX = 256, SMALL_BATCH = 8, SMALL_C_MAX = 7;
+constexpr uint32_t SMALL_LIST_MAX = 16384;  // entries a workgroup's slice can hold (points per slice x windows): 64 KB of LDS
+struct SmallDesc {
+  const uint8_t* dig;    // [W][n_reg]: sign << 7 | magnitude (0 = no entry)
+  const uint8_t* table;  // [W][n_reg] affine points 2^(c w) P_i (canonical Montgomery-2^261 words)
+  uint8_t* part;         // [NB][S] XYZZ partial sums
+  uint32_t* cnt;         // [NB * S] entries each workgroup added (statistics)
+  uint8_t* out;
+  uint64_t* stats;
+  uint32_t n, n_reg, W, c, S, P, canonical;
+};
+struct SmallBatch {
+  SmallDesc d[SMALL_BATCH];
+};
+
+__global__ void __launch_bounds__(64) k_msm_small_digits(const fe* scalars, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W, uint8_t* dig) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const fe s = msm_scalar(scalars, i, n, nullptr);
+  __shared__ uint32_t limbs[64][9];  // dynamically indexed limbs live in LDS, not scratch (row 8 = 0: the word above the top)
+#pragma unroll
+  for (int k = 0; k < 8; k++) limbs[threadIdx.x][k] = s.v[k];
+  limbs[threadIdx.x][8] = 0;
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    const uint32_t bit = w * c, limb = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (limb < 8) raw = (uint32_t)((((uint64_t)limbs[threadIdx.x][limb + 1] << 32) | limbs[threadIdx.x][limb]) >> sh) & mask;
+    const uint32_t d = raw + carry;  // 0 .. 2^c
+    uint32_t mag = d, neg = 0;
+    carry = 0;
+    if (d > half) {  // negative digit d - 2^c, carry 1
+      mag = (1u << c) - d;
+      neg = 1;
+      carry = 1;
+    }
+    dig[(size_t)w * n_reg + i] = (uint8_t)(mag ? (neg << 7 | mag) : 0u);
+  }
+}
+
+// segmented tree sums in LDS: nseg segments of len (a power of two) consecutive XYZZ values each; segment k's sum ends
+// in lds[k * len].  One quad per pair; a level's pairs are spread over the workgroup's quads.
+__device__ __forceinline__ void seg_tree_sum(xyzz29* lds, uint32_t nseg, uint32_t len) {
+  const uint32_t quad = threadIdx.x >> 2, nquads = blockDim.x >> 2;
+  for (uint32_t h = len >> 1; h > 0; h >>= 1) {
+    const uint32_t ops = nseg * h;
+    for (uint32_t op = quad; op < ops; op += nquads) {
+      const uint32_t at = (op / h) * len + (op % h);
+      xyzz29 r = xyzz29_add_quad(lds[at], lds[at + h]);
+      if ((threadIdx.x & 3u) == 0) lds[at] = r;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_accum(const SmallBatch sb) {
+  const SmallDesc& d = sb.d[blockIdx.y];
+  const uint32_t NB = 1u << (d.c - 1);
+  if (blockIdx.x >= NB * d.S) return;  // a batch is launched over its largest member
+  const uint32_t b = blockIdx.x / d.S, sl = blockIdx.x % d.S, tid = threadIdx.x;
+  const uint32_t lo = sl * d.P, hi = min(lo + d.P, d.n);
+  xyzz29* tree = reinterpret_cast<xyzz29*>(h2_msm_smem);                                   // SMALL_THREADS values
+  uint32_t* list = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(h2_msm_smem) + (size_t)SMALL_THREADS * PART_BYTES);
+  __shared__ uint32_t m_sh;
+  if (tid == 0) m_sh = 0;
+  __syncthreads();
+  if (lo < hi) {
+    const uint32_t np = hi - lo, cells = np * d.W, want = b + 1;
+    for (uint32_t idx = tid; idx < cells; idx += SMALL_THREADS) {
+      const uint32_t w = idx / np, at = w * d.n_reg + lo + (idx - w * np);
+      const uint32_t dg = d.dig[at];
+      if ((dg & 0x7fu) == want) list[atomicAdd(&m_sh, 1u)] = (dg >> 7) << 31 | at;
+    }
+  }
+  __syncthreads();
+  const uint32_t m = m_sh;
+  uint8_t* dst = d.part + (size_t)blockIdx.x * PART_BYTES;
+  if (m == 0) {  // wavefront-uniform
+    if (tid == 0) {
+      part_store(dst, xyzz29_identity());
+      d.cnt[blockIdx.x] = 0;
+    }
+    return;
+  }
+  xyzz29 acc = xyzz29_identity();
+  for (uint32_t k = tid; k < m; k += SMALL_THREADS) {
+    const uint32_t e = list[k];
+    const affine p = affine_load(d.table + (size_t)(e & 0x7fffffffu) * 64);
+    if (affine_is_identity(p)) continue;
+    f29 x2 = f29_unpack(p.x.v), y2 = f29_unpack(p.y.v);
+    if (e >> 31) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
+    xyzz29_madd(acc, x2, y2);
+  }
+  uint32_t T = 1;  // the tree covers the lanes that hold a sum: the next power of two >= min(m, 256)
+  while (T < min(m, SMALL_THREADS)) T <<= 1;
+  if (tid < T) tree[tid] = acc;
+  __syncthreads();
+  seg_tree_sum(tree, 1, T);
+  if (tid == 0) {
+    part_store(dst, tree[0]);
+    d.cnt[blockIdx.x] = m;
+  }
+}
+
+__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_final(const SmallBatch sb) {
+  const SmallDesc& d = sb.d[blockIdx.x];
+  const uint32_t c = d.c, NB = 1u << (c - 1), S = d.S, tid = threadIdx.x, quad = tid >> 2;
+  xyzz29* X = reinterpret_cast<xyzz29*>(h2_msm_smem);  // SMALL_PARTS_MAX values
+  xyzz29* Y = X + SMALL_PARTS_MAX;                      // c * NB <= 7 * 64 values
+  if (tid < NB * S) X[tid] = part_load(d.part + (size_t)tid * PART_BYTES);
+  __syncthreads();
+  seg_tree_sum(X, NB, S);  // bucket sums: X[b * S]
+  // bit-sliced weights: A_j = sum of the buckets whose weight b + 1 has bit j set (weights 1 .. 2^(c-1): bits 0 .. c-1)
+  for (uint32_t t = tid; t < c * NB; t += SMALL_THREADS) {
+    const uint32_t j = t / NB, b = t % NB;
+    Y[t] = (((b + 1) >> j) & 1u) ? X[b * S] : xyzz29_identity();
+  }
+  __syncthreads();
+  seg_tree_sum(Y, c, NB);  // A_j: Y[j * NB]
+  // 2^j A_j: quad j doubles j times; then one tree over the (<= 8) terms
+  xyzz29 v = xyzz29_identity();
+  if (quad < c) {
+    v = Y[quad * NB];
+    for (uint32_t k = 0; k < quad; k++) v = xyzz29_dbl_quad(v);
+  }
+  __syncthreads();
+  if (quad < 8 && (tid & 3u) == 0) X[quad] = v;
+  __syncthreads();
+  seg_tree_sum(X, 1, 8);
+  if (tid == 0) {
+    xyzz29 r = X[0];
+    jac j;
+    if (xyzz29_is_identity(r)) {
+      j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
+    } else if (d.canonical) {
+      f29 ax, ay;
+      xyzz29_to_affine(r, ax, ay);
+      f29_to_mont256<Fq29>(ax, j.x.v);
+      f29_to_mont256<Fq29>(ay, j.y.v);
+      j.z = fe_one<Fq>();
+    } else {
+      f29_to_mont256<Fq29>(f29_mul<Fq29>(r.x, r.zz), j.x.v);
+      f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
+      f29_to_mont256<Fq29>(r.zz, j.z.v);
+    }
+    jac_store(d.out, j);
+    if (d.stats) {
+      uint64_t ins = 0;
+      for (uint32_t t = 0; t < NB * S; t++) ins += d.cnt[t];
+      d.stats[0] = ins;
+    }
+  }
+}
+
 // debug hook for the lane-cooperative point operations (g1_29_quad.cuh): four lanes per element.
 // op 0: (P) + (Q) with both operands brought to non-trivial XYZZ representatives; op 1: 2 (P).
 __global__ void __launch_bounds__(256) k_dbg_quad(int op, const uint8_t* pp, const uint8_t* qq, uint8_t* out, size_t n) {
@@ -1051,6 +1234,23 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
+// small base sets: window width, slices (see "small base sets").  NB * S <= 256 partial sums (one workgroup of the final
+// kernel holds them in LDS), P * W <= SMALL_LIST_MAX entries per slice.  First guesses by depth count, then measured
+// (tools/msm_small_sweep.py -> profiles/r04_msm_small_sweep.txt).
+static void small_geometry(size_t n, uint32_t* c, uint32_t* S) {
+  uint32_t cc = n <= 256 ? 3 : n <= 1024 ? 4 : 5;
+  if (const char* ev = ab_env("H2MI_MSM_SMALL_C"))
+    if (atoi(ev) >= 2 && atoi(ev) <= (int)SMALL_C_MAX) cc = (uint32_t)atoi(ev);
+  const uint32_t NB = 1u << (cc - 1), W = (255 + cc - 1) / cc;
+  uint32_t SS = SMALL_PARTS_MAX / NB;  // as many slices as the final kernel takes ...
+  while (SS > 1 && (size_t)SS / 2 * 8 >= n) SS >>= 1;  // ... but at least ~8 points per slice
+  if (const char* ev = ab_env("H2MI_MSM_SMALL_S"))
+    if (atoi(ev) >= 1 && (uint32_t)atoi(ev) * NB <= SMALL_PARTS_MAX && (atoi(ev) & (atoi(ev) - 1)) == 0) SS = (uint32_t)atoi(ev);
+  while (((n + SS - 1) / SS) * W > SMALL_LIST_MAX && SS * 2 * NB <= SMALL_PARTS_MAX) SS <<= 1;
+  *c = cc;
+  *S = SS;
+}
+
 // H2MI_MSM_S0 fixes the chunk length (tuning / tests); 0 = chosen on the device from the entry count
 static uint32_t chunk_override() {
   const char* ev = getenv("H2MI_MSM_S0");
@@ -1059,6 +1259,7 @@ static uint32_t chunk_override() {
 
 static void free_bases(Bases* B) {
   H2_IGNORE(hipFree(B->table));
+  H2_IGNORE(hipFree(B->stable));
   H2_IGNORE(hipFree(B->host_stage));
   for (Slot& S : B->slot) {
     H2_IGNORE(hipFree(S.vals[0])); H2_IGNORE(hipFree(S.vals[1]));
@@ -1067,6 +1268,7 @@ static void free_bases(Bases* B) {
     for (int i = 0; i < 2; i++) { H2_IGNORE(hipFree(S.np[i])); H2_IGNORE(hipFree(S.toff[i])); }
     H2_IGNORE(hipFree(S.dense)); H2_IGNORE(hipFree(S.dense2)); H2_IGNORE(hipFree(S.vsum)); H2_IGNORE(hipFree(S.tseg[0])); H2_IGNORE(hipFree(S.tseg[1]));
     H2_IGNORE(hipFree(S.part[0])); H2_IGNORE(hipFree(S.part[1])); H2_IGNORE(hipFree(S.rc)); H2_IGNORE(hipFree(S.g)); H2_IGNORE(hipFree(S.stats)); H2_IGNORE(hipFree(S.shift));
+    H2_IGNORE(hipFree(S.sdig)); H2_IGNORE(hipFree(S.spart)); H2_IGNORE(hipFree(S.scnt));
     if (S.input_ready) H2_IGNORE(hipEventDestroy(S.input_ready));
     if (S.head_done) H2_IGNORE(hipEventDestroy(S.head_done));
     if (S.accum_done) H2_IGNORE(hipEventDestroy(S.accum_done));
@@ -1163,6 +1365,26 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
                        B->table + (size_t)w * B->stride * 64, n, B->c);
     if (prof_) prof_end(s);
   }
+  if (n <= SMALL_MAX_N) {  // second table with narrow windows for the latency path (see "small base sets")
+    small_geometry(n, &B->sc, &B->sS);
+    B->sW = (255 + B->sc - 1) / B->sc;
+    B->sP = (uint32_t)((n + B->sS - 1) / B->sS);
+    if ((size_t)B->sP * B->sW <= SMALL_LIST_MAX) {
+      const uint32_t NBs = 1u << (B->sc - 1);
+      H2_ALLOC(B->stable, (size_t)B->sW * n * 64);
+      for (int si_ = 0; si_ < B->nslot; si_++) {
+        Slot& S = B->slot[si_];
+        H2_ALLOC(S.sdig, (size_t)B->sW * n);
+        H2_ALLOC(S.spart, (size_t)NBs * B->sS * PART_BYTES);
+        H2_ALLOC(S.scnt, (size_t)NBs * B->sS * 4);
+      }
+      if (hipMemcpyAsync(B->stable, B->table, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
+      for (uint32_t w = 1; w < B->sW; w++)
+        hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 64)), dim3(64), 0, s, (const uint8_t*)(B->stable + (size_t)(w - 1) * n * 64),
+                           B->stable + (size_t)w * n * 64, n, B->sc);
+      B->small = true;
+    }
+  }
   // slot n of every window stays the identity until the sum point is known
   for (uint32_t w = 0; w < B->W; w++)
     if (hipMemsetAsync(B->table + ((size_t)w * B->stride + n) * 64, 0, 64, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
@@ -1171,7 +1393,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   // false), then its own table column.  Small base sets never use the shift (k_msm_pick_shift samples 64 scalars).
   const uint64_t h = g_next_handle++;
   g_bases[h] = B;  // msm_join_all walks the registered handles
-  if (n >= SHIFT_MIN_N && !getenv("H2MI_MSM_NO_SHIFT")) {
+  if (n >= SHIFT_MIN_N && !B->small && !ab_env("H2MI_MSM_NO_SHIFT")) {
     fe* ones = nullptr;
     uint8_t* sum = nullptr;
     int rc = H2MI_OK;
@@ -1240,7 +1462,9 @@ static TailDesc tail_desc(const Bases* B, const Slot& S);
 // partition and the accumulation; the latency-bound bucket reduction is deferred to the next join
 // (msm_join_all: h2mi_join / h2mi_sync / h2mi_memcpy_d2h), a full batch, or the reuse of the slot.
 // On a caller-provided stream everything runs in order on that stream.
+static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
+  if (B->small && g_small_path) return msm_small(B, d_scalars, n, d_out, s);
   const uint32_t nb = B->nb, W = B->W;
   // dominant-value shift: only when the MSM covers every registered base (the extra base is their sum)
   const bool shifted = B->has_sum && n == B->n;
@@ -1401,6 +1625,71 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   return H2MI_OK;
 }
 
+// ---- small base sets: host side ---------------------------------------------------------------------------------
+static SmallDesc small_desc(const Bases* B, const Slot& S) {
+  SmallDesc d;
+  d.dig = S.sdig; d.table = B->stable; d.part = S.spart; d.cnt = S.scnt; d.out = (uint8_t*)S.d_out; d.stats = S.stats;
+  d.n = S.small_n; d.n_reg = (uint32_t)B->n; d.W = B->sW; d.c = B->sc; d.S = B->sS; d.P = B->sP; d.canonical = g_canonical ? 1u : 0u;
+  return d;
+}
+
+static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts, uint32_t max_list, hipStream_t t) {
+  static bool attr_set = false;
+  constexpr size_t ACC_LDS_MAX = (size_t)SMALL_THREADS * PART_BYTES + (size_t)SMALL_LIST_MAX * 4;
+  constexpr size_t FIN_LDS = (size_t)(SMALL_PARTS_MAX + SMALL_C_MAX * (1u << (SMALL_C_MAX - 1))) * PART_BYTES;
+  if (!attr_set) {
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_MAX));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS));
+    attr_set = true;
+  }
+  H2_LAUNCH("k_msm_small_accum", k_msm_small_accum, dim3(max_parts, count), SMALL_THREADS, (size_t)SMALL_THREADS * PART_BYTES + (size_t)max_list * 4, t, sb);
+  H2_LAUNCH("k_msm_small_final", k_msm_small_final, count, SMALL_THREADS, FIN_LDS, t, sb);
+  return H2MI_OK;
+}
+
+// One MSM over the first n bases of a small base set.  The digit kernel runs on the caller's stream (it is the only reader of
+// the scalars: work queued on s afterwards may overwrite them); on the library stream the accumulate + final pair is deferred
+// to the next join / flush and batched with the other small MSMs of the phase, on a caller's stream it follows in order.
+static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
+  const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
+  Slot& S = B->slot[B->next_slot];
+  B->last_slot = B->next_slot;
+  B->next_slot = (B->next_slot + 1) % B->nslot;
+  if (S.tail_deferred) {  // every slot of this handle is waiting for its reduction
+    int rc = flush_tails();
+    if (rc) return rc;
+  }
+  // slot reuse: the digit bytes and partial sums are read by the slot's previous accumulate / final pair — and a slot last
+  // used by the general pipeline (h2mi_dbg_msm_small_path) still owes its head / accumulation events
+  if (S.tail_ever && (S.tail_pending || !pipelined || S.last_stream != s)) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+  if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+  if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
+  S.tail_pending = S.accum_pending = S.head_pending = false;
+  S.last_stream = s;
+  S.d_out = d_out;
+  S.small_n = (uint32_t)n;
+  H2_LAUNCH("k_msm_small_digits", k_msm_small_digits, ceil_div_u32(n, 64), 64, 0, s, (const fe*)d_scalars, (uint32_t)n, (uint32_t)B->n, B->sc, B->sW, S.sdig);
+  if (pipelined) {
+    H2_HIP(hipEventRecord(S.accum_done, s));  // "inputs consumed": what the deferred pair waits for
+    S.accum_pending = true;
+    S.accum_ever = true;
+    S.tail_deferred = true;
+    S.small_deferred = true;
+    g_deferred.push_back({B, &S});
+    static const bool eager = ab_env("H2MI_MSM_EAGER_TAIL") != nullptr;
+    if (eager || g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
+    return H2MI_OK;
+  }
+  SmallBatch sb;
+  for (uint32_t j = 0; j < SMALL_BATCH; j++) sb.d[j] = small_desc(B, S);
+  int rc = launch_small(sb, 1, (1u << (B->sc - 1)) * B->sS, B->sP * B->sW, s);
+  if (rc) return rc;
+  H2_HIP(hipEventRecord(S.tail_done, s));
+  S.tail_pending = true;
+  S.tail_ever = true;
+  return H2MI_OK;
+}
+
 // one fold level (<= S1 partials per task: part[0] -> part[1]), then FG lanes per bucket finish into the
 // dense array.  A bucket holding m points leaves ceil(m / (s0 * S1)) partials for the finish kernel: 1 in
 // the uniform case at k = 20, <= ~50 for the hot 0/1 buckets of witness-like columns (7 serial additions
@@ -1463,31 +1752,63 @@ static int flush_tails() {
     int rc0 = use_device(dev);
     if (rc0) return rc0;
     hipStream_t t = ctx().tail_stream;
-    size_t i = 0;
-    while (i < mine.size()) {
-      TailBatch tb;
-      uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0, max_seg = 0;
+    // three kinds of deferred work, each batched with its own kind: the small path's accumulate + final pairs, and the bucket
+    // reductions of narrow and of wide windows (a wide descriptor in a batch used to switch every member to the two-lane
+    // finish: correct, but a silent latency cliff for mixed-size commitment streams — round-3 ADVICE)
+    std::vector<Deferred> group[3];
+    for (const Deferred& d : mine) group[d.S->small_deferred ? 0 : d.B->seg_log ? 2 : 1].push_back(d);
+    for (size_t i = 0; i < group[0].size();) {
+      SmallBatch sb;
+      uint32_t count = 0, max_parts = 0, max_list = 0;
       const size_t first = i;
-      for (; i < mine.size() && count < TAIL_BATCH; i++, count++) {
-        Bases* B = mine[i].B;
-        Slot& S = *mine[i].S;
+      for (; i < group[0].size() && count < SMALL_BATCH; i++, count++) {
+        Bases* B = group[0][i].B;
+        Slot& S = *group[0][i].S;
         H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
-        tb.d[count] = tail_desc(B, S);
-        max_tasks1 = std::max(max_tasks1, S.tasks1);
-        max_nb = std::max(max_nb, B->nb);
-        max_logNh = std::max(max_logNh, B->logNh);
-        max_logNl = std::max(max_logNl, B->logNl);
-        max_seg = std::max(max_seg, B->seg_log);
+        sb.d[count] = small_desc(B, S);
+        max_parts = std::max(max_parts, (1u << (B->sc - 1)) * B->sS);
+        max_list = std::max(max_list, B->sP * B->sW);
       }
-      for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
-      int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, max_seg, t);
+      for (uint32_t j = count; j < SMALL_BATCH; j++) sb.d[j] = sb.d[0];  // never read: blockIdx.y < count
+      int rc = launch_small(sb, count, max_parts, max_list, t);
       if (rc) return rc;
       for (size_t j = first; j < i; j++) {
-        Slot& S = *mine[j].S;
+        Slot& S = *group[0][j].S;
         H2_HIP(hipEventRecord(S.tail_done, t));
         S.tail_pending = true;
         S.tail_ever = true;
         S.tail_deferred = false;
+        S.small_deferred = false;
+      }
+    }
+    for (int gi = 1; gi < 3; gi++) {
+      const std::vector<Deferred>& grp = group[gi];
+      size_t i = 0;
+      while (i < grp.size()) {
+        TailBatch tb;
+        uint32_t count = 0, max_tasks1 = 0, max_nb = 0, max_logNh = 0, max_logNl = 0, max_seg = 0;
+        const size_t first = i;
+        for (; i < grp.size() && count < TAIL_BATCH; i++, count++) {
+          Bases* B = grp[i].B;
+          Slot& S = *grp[i].S;
+          H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
+          tb.d[count] = tail_desc(B, S);
+          max_tasks1 = std::max(max_tasks1, S.tasks1);
+          max_nb = std::max(max_nb, B->nb);
+          max_logNh = std::max(max_logNh, B->logNh);
+          max_logNl = std::max(max_logNl, B->logNl);
+          max_seg = std::max(max_seg, B->seg_log);
+        }
+        for (uint32_t j = count; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];  // never read: blockIdx.y < count
+        int rc = launch_tails(tb, count, max_tasks1, max_nb, max_logNh, max_logNl, max_seg, t);
+        if (rc) return rc;
+        for (size_t j = first; j < i; j++) {
+          Slot& S = *grp[j].S;
+          H2_HIP(hipEventRecord(S.tail_done, t));
+          S.tail_pending = true;
+          S.tail_ever = true;
+          S.tail_deferred = false;
+        }
       }
     }
   }
@@ -1917,6 +2238,15 @@ int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* 
   return H2MI_OK;
 }
 
+int h2mi_dbg_msm_small_path(int on) {
+  H2_REQUIRE_INIT();
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  int rc = flush_tails();  // what is queued keeps the path it was queued on
+  if (rc) return rc;
+  g_small_path = on != 0;
+  return H2MI_OK;
+}
+
 int h2mi_msm_set_canonical(int on) {
   H2_REQUIRE_INIT();
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
@@ -1952,7 +2282,10 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   uint64_t st = 0;
   H2_HIP(hipMemcpy(&st, B->slot[B->last_slot].stats, 8, hipMemcpyDeviceToHost));
   if (bucket_adds) *bucket_adds = st;
-  if (reduce_adds) {
+  if (reduce_adds && B->small && g_small_path) {  // partial sums -> bucket sums, c bit-sliced trees, c (c - 1) / 2 doublings, the last tree
+    const uint64_t NBs = 1ull << (B->sc - 1);
+    *reduce_adds = NBs * B->sS + (uint64_t)B->sc * NBs / 2 + (uint64_t)B->sc * (B->sc - 1) / 2 + B->sc;
+  } else if (reduce_adds) {
     // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))
     uint64_t Nh = 1ull << B->logNh, Nl = 1ull << B->logNl;
     const uint64_t mat = (uint64_t)B->nb >> B->seg_log;  // wide windows: 2 (L - 1) additions per segment of L buckets first

@@ -131,6 +131,11 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
                           h2mi_stream_t stream);
 /* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */
 int h2mi_msm_set_canonical(int on);
+/* Base sets of at most 4096 points take a latency path of their own (narrow windows against a second table, three short
+ * kernels, two of them batched over the MSMs of a prover phase: DESIGN.md 4.1 (ix)) — the sizes of the reference's own
+ * example runs (examples/standard_plonk.rs:26: k = 5).  Test hook: 0 sends them through the general pipeline instead, so
+ * parity tests can run both paths on one handle; 1 (default) restores the small path.  Flushes queued reductions. */
+int h2mi_dbg_msm_small_path(int on);
 /* number of bucket insertions (non-zero signed digits) the last MSM on this handle performed, and the
  * running-sum reduction adds — the numerator of "G1-adds/s" (SURVEY.md 8d).  Synchronises. */
 int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds);

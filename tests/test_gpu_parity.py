@@ -242,6 +242,81 @@ def test_msm_edge_cases(gpu):
     _msm_case(gpu, carry, pts[:6])
 
 
+def _both_msm_paths(gpu, handle, sc, m, want):  # noqa: E302
+    """one registered handle, the same scalars through the small-set path (default below 4097 bases) and, with the test hook,
+    through the general pipeline: both must give the oracle's group element"""
+    out = np.zeros(12, dtype=np.uint64)
+    for small in (1, 0, 1):
+        assert gpu.lib.h2mi_dbg_msm_small_path(small) == 0
+        try:
+            assert gpu.lib.h2mi_msm_bn254_g1(handle, None, sc.ctypes.data, m, out.ctypes.data) == 0
+        finally:
+            gpu.lib.h2mi_dbg_msm_small_path(1)
+        assert o.unpack_jacobian(out) == want, ("small path" if small else "general pipeline", m)
+
+
+@pytest.mark.parametrize("n", [1, 31, 257, 4096])
+def test_msm_small_path_and_general_pipeline_agree_with_oracle(gpu, n):
+    """round 4: base sets of <= 4096 points take a latency path of their own (narrow windows, three short kernels); the forced
+    general pipeline on the same handle, and the C restatement of best_multiexp, must agree with it — uniform scalars, prefixes of
+    the registered set (n < registered n), and the distributions that stress one bucket (a constant column, 0 / 1 columns)."""
+    from oracle import cref
+
+    bases = cref.g1_mul_gen(o.random_field_limbs(n, 700 + n), 4)
+    h = C.c_uint64()
+    assert gpu.lib.h2mi_bases_register(bases.ctypes.data, n, C.byref(h)) == 0
+    cases = [(o.random_field_limbs(n, 31 + n), n), (o.random_field_limbs(n, 32 + n), max(1, n - 3)), (o.random_field_limbs(n, 33), max(1, n // 2 + 1)),
+             (o.witness_like_limbs(n, 5), n), (np.tile(o.random_field_limbs(1, 77)[0], (n, 1)), n), (np.tile(o.pack([o.R - 1], o.R)[0], (n, 1)), n),
+             (np.zeros((n, 4), dtype=np.uint64), n)]
+    for sc, m in cases:
+        sc = np.ascontiguousarray(sc[:m])
+        want = o.unpack_jacobian(cref.msm(sc, bases[:m], 2))
+        _both_msm_paths(gpu, h.value, sc, m, want)
+    # several MSMs queued on the library stream before one join: the deferred accumulate + final pairs run as one batch
+    from halo2_scaffold_amd.device import DevBuf
+
+    scal = [o.random_field_limbs(n, 900 + i) for i in range(11)]
+    d_sc = [DevBuf.from_numpy(x) for x in scal]
+    d_out = DevBuf(96 * len(scal))
+    for i, d in enumerate(d_sc):
+        assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d.ptr, n, d_out.ptr + 96 * i, None) == 0
+    got = d_out.to_numpy(shape=(len(scal), 12))
+    for i, x in enumerate(scal):
+        assert o.unpack_jacobian(got[i]) == o.unpack_jacobian(cref.msm(x, bases, 2)), i
+    ba, ra = C.c_uint64(), C.c_uint64()
+    assert gpu.lib.h2mi_msm_last_stats(h.value, C.byref(ba), C.byref(ra)) == 0 and 0 < ba.value <= n * 128 and ra.value > 0
+    # on a caller's stream everything runs in order on that stream
+    st = C.c_void_p()
+    assert gpu.lib.h2mi_stream_create(C.byref(st)) == 0
+    assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_sc[0].ptr, n, d_out.ptr, st) == 0
+    assert gpu.lib.h2mi_stream_destroy(st) == 0  # synchronises the stream
+    assert o.unpack_jacobian(d_out.to_numpy(shape=(1, 12))[0]) == o.unpack_jacobian(cref.msm(scal[0], bases, 2))
+    for d in d_sc:
+        d.free()
+    d_out.free()
+    assert gpu.lib.h2mi_bases_release(h.value) == 0
+
+
+def test_msm_small_path_edge_points(gpu):
+    """identity bases, duplicated bases (P + P in one bucket: the doubling case of the mixed addition), P and -P with equal scalars
+    (cancellation to the identity inside a bucket), n * G, and digit-carry chains — through the small path, against the oracle."""
+    n = 96
+    pts = _points(n, 5)
+    pts2 = list(pts)
+    pts2[3] = None
+    pts2[5] = pts2[4]
+    pts2[7] = o.g1_neg(pts2[6])
+    s = o.random_field_limbs(n, 99)
+    s[5] = s[4]
+    s[7] = s[6]
+    _msm_case(gpu, s, pts2)
+    ones = np.tile(o.pack([1], o.R)[0], (n, 1))
+    _msm_case(gpu, ones, [o.G1_GEN] * n)
+    _msm_case(gpu, np.tile(o.pack([5], o.R)[0], (2, 1)), [pts[0], o.g1_neg(pts[0])])  # the whole MSM cancels
+    carry = o.pack([(1 << 253) - 1, (1 << 200) - 1, 0x7FFF8000_7FFF8000, 0x8000, 0x8001, 0xFFFF, 3, 4, 0x24, 0x1C], o.R)
+    _msm_case(gpu, carry, pts[:10])
+
+
 def test_empty_msm_is_identity(gpu):
     out = gpu.best_multiexp(np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64))
     assert o.unpack_jacobian(out) is None
