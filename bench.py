@@ -360,7 +360,7 @@ def main(argv=None):
         if world == 1 and n_devices == 1 and args.k == 20:
             try:
                 small = time_small_proofs(h2, ROOT)
-                out["create_proof_k16"], out["create_proof_k8"] = small["k16"], small["k8"]
+                out["create_proof_k16"], out["create_proof_k8"], out["create_proof_k5"] = small["k16"], small["k8"], small["k5"]
                 out["create_proof"]["cpp_host_ms"] = small["k20"].get("cpp_host_ms")
                 out["create_proof_hosts_what"] = small["what"]
             except Exception as e:
@@ -537,7 +537,7 @@ def time_small_proofs(h2, root):
     lib = h2.lib
     out = {}
     exe = os.path.join(root, "examples", "standard_plonk")
-    for k in (16, 8, 20):
+    for k in (16, 8, 5, 20):  # 5: the reference's own example run (examples/standard_plonk.rs:26)
         entry = {}
         if k != 20:  # the k = 20 Python-host figure is the create_proof block itself
             params = ParamsKZG.setup(k, 0x5EC2E7 + 0x48324D49)

@@ -96,7 +96,7 @@ struct Slot {
   bool tail_deferred = false;   // accumulation queued, bucket reduction not yet launched (see flush_tails)
   void* d_out = nullptr;        // where that reduction will write the result
   uint32_t tasks1 = 0;          // its fold grid bound
-  // small base sets (see "small base sets" below): signed digit bytes [Ws][n], per-workgroup partial sums and entry counts
+  // small base sets (see "small base sets" below): signed digit bytes [W][n], per-workgroup partial sums and entry counts
   uint8_t* sdig = nullptr;
   uint8_t* spart = nullptr;
   uint32_t* scnt = nullptr;
@@ -125,10 +125,10 @@ struct Bases {
   int nslot = NSLOT;            // slots in use (allocated) for this handle
   int next_slot = 0, last_slot = 0;
   uint32_t max_tasks0 = 0, max_tasks1 = 0;
-  // small base sets (n <= SMALL_MAX_N): second table with narrow windows, 2^(sc - 1) buckets, sS slices of sP points
+  // small base sets (small_geometry): second table holding every multiple a signed digit can select, no buckets
   bool small = false;
-  uint32_t sc = 0, sW = 0, sS = 0, sP = 0;
-  uint8_t* stable = nullptr;    // [sW][n] affine
+  uint32_t sc = 0, sW = 0, slanes = 0, sr = 0, sG = 0;  // window bits, windows, gathering lanes, cells per lane, workgroups (= partial sums)
+  uint8_t* stable = nullptr;    // [2^(sc-1)][sW][n] affine: j 2^(sc w) P_i
 };
 
 static std::map<uint64_t, Bases*> g_bases;
@@ -1005,33 +1005,66 @@ __global__ void __launch_bounds__(128) k_msm_final(const TailBatch tb) {
 // The pipeline above is built for throughput: nine partition kernels, an accumulation over >= 2^12 buckets and a
 // five-kernel bucket reduction whose chain of ~40 dependent point operations is the same at every size — 217 us for a
 // 256-point MSM (profiles/r03_op_bench.json), six times per proof of the reference's own example (k = 5 .. 8).  A small
-// MSM is pure latency, so it gets a path whose chain is as short as the arithmetic allows:
-//   * narrow signed windows cs = 3 .. 5 against a second table 2^(cs w) P_i (W = 51 .. 85 rows of n points: kilobytes to a few
-//     megabytes): 4 .. 16 buckets instead of 4096 .. 16384 — the weighted bucket sum needs 2 (cs - 1) + 3 levels, not ~35;
+// MSM is pure latency: what it costs is the NUMBER OF DEPENDENT POINT OPERATIONS (~3.3 us each for a quad of lanes, measured),
+// so this path has no buckets at all:
+//   * a second table holds every multiple the signed digits can ask for, M[j][w][i] = j 2^(cs w) P_i, j = 1 .. 2^(cs-1)
+//     (cs = 5: 16 x 51 x n points — 13 MB at n = 256, 214 MB at n = 4096, of 288 GB): the MSM is then the plain sum of the
+//     <= n W table points its digits select — no bucket weights, no doublings, ceil(log2(n W)) tree levels and nothing else;
 //   * k_msm_small_digits (on the caller's stream: the only reader of the scalars): one thread per scalar, Montgomery ->
 //     canonical, W signed digits as bytes;
-//   * k_msm_small_accum, one workgroup per (bucket, slice of points): scans the slice's digit bytes, collects the entries
-//     of its bucket in LDS (no sort: 2^(cs-1) workgroups read the same bytes), every lane sums its share with mixed
-//     additions, then a quad tree in LDS -> one partial sum per workgroup;
-//   * k_msm_small_final, one workgroup per MSM: the <= 256 partial sums -> bucket sums (segmented tree), the bit-sliced
-//     weights A_j = sum over buckets with bit j of (b + 1) set, 2^j A_j by j doublings in parallel, a last tree, Jacobian out.
-// The last two are deferred and batched over the MSMs queued since the last join exactly like the bucket reductions above
-// (blockIdx.y = MSM): a prover phase of four commitments is four digit launches + two launches.
-constexpr size_t SMALL_MAX_N = 4096;
-constexpr uint32_t SMALL_THREADS = 256, SMALL_PARTS_MAX = 256, SMALL_BATCH = 8, SMALL_C_MAX = 7;
-constexpr uint32_t SMALL_LIST_MAX = 16384;  // entries a workgroup's slice can hold (points per slice x windows): 64 KB of LDS
+//   * k_msm_small_accum: one lane per r cells (point i, window w) of the digit array — gather, mixed additions — then a quad tree
+//     over the workgroup's 128 gathered sums in LDS -> one partial sum per workgroup; the workgroup that arrives last sums the
+//     <= 256 partial sums of its MSM the same way and writes the Jacobian result.
+// The second kernel is deferred and batched over the MSMs queued since the last join like the bucket reductions above
+// (blockIdx.y = MSM): a prover phase of four commitments is four digit launches + one launch.  An earlier form of this path
+// (4 .. 16 LDS buckets, per-(bucket, slice) workgroups, bit-sliced weights) needed 21 levels at n = 256 where this one needs 14:
+// 131 us of device time against the general pipeline's 298 (profiles/r04_msm_small_sweep.txt, first block).
+// the widest base set that takes this path.  Measured (profiles/r04_msm_small_sweep.txt; latency / four MSMs + one join / back to
+// back, us, against the general pipeline): 2^8 86 / 138 / 31 vs 229 / 367 / 52; 2^12 132 / 267 / 63 vs 266 / 542 / 83; 2^14 173 / 445 /
+// 106 vs 278 / 582 / 98; 2^15 227 / 633 / 150 vs 327 / 727 / 121; 2^16 366 / 1044 / 263 vs 375 / 823 / 169 — from 2^16 the 2.5x more
+// mixed additions of the narrow windows (43 x n against 17 x n) cost more than the short chain saves.
+constexpr size_t SMALL_MAX_N = (size_t)1 << 14;
+constexpr uint32_t SMALL_THREADS = 256, SMALL_PARTS_MAX = 512, SMALL_BATCH = 8, SMALL_C_MAX = 7;
+// a workgroup's 256 lanes are 64 quads, and a tree level over N values is N / 2 quad operations: 128 values per workgroup keep
+// every level at ONE operation per quad (with 256 the first level ran two in sequence); the upper 128 lanes idle through the
+// gather — free, on a path that is bound by its chain and not by throughput
+constexpr uint32_t SMALL_CELLS = 128;  // beyond 128 x 256 cells every lane gathers (lanes = 256): the madd chains are what counts there
 struct SmallDesc {
   const uint8_t* dig;    // [W][n_reg]: sign << 7 | magnitude (0 = no entry)
-  const uint8_t* table;  // [W][n_reg] affine points 2^(c w) P_i (canonical Montgomery-2^261 words)
-  uint8_t* part;         // [NB][S] XYZZ partial sums
-  uint32_t* cnt;         // [NB * S] entries each workgroup added (statistics)
+  const uint8_t* table;  // [2^(c-1)][W][n_reg] affine points j 2^(c w) P_i (canonical Montgomery-2^261 words)
+  uint8_t* part;         // [G] XYZZ partial sums
+  uint32_t* cnt;         // [G] entries each workgroup added (statistics); cnt[G_max] = arrival counter of the workgroups
+  uint32_t ticket_at;    // index of that counter
   uint8_t* out;
   uint64_t* stats;
-  uint32_t n, n_reg, W, c, S, P, canonical;
+  uint32_t n, n_reg, W, c, r, lanes, G, canonical;  // r cells per gathering lane, G = ceil(n W / (lanes r)) workgroups
 };
 struct SmallBatch {
   SmallDesc d[SMALL_BATCH];
 };
+
+// plane j (multiples j Q of the points Q = 2^(c w) P_i of plane 1), j = 2 .. NB: one thread per point, a chain of mixed
+// additions with one conversion back to affine per multiple
+__global__ void __launch_bounds__(64) k_msm_small_multiples(uint8_t* table, size_t plane /* W * n points */, uint32_t NB) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= plane) return;
+  const affine p = affine_load(table + t * 64);
+  if (affine_is_identity(p)) {
+    for (uint32_t j = 2; j <= NB; j++) affine_store(table + ((size_t)(j - 1) * plane + t) * 64, p);
+    return;
+  }
+  const f29 x = f29_unpack(p.x.v), y = f29_unpack(p.y.v);
+  xyzz29 acc = xyzz29_dbl_affine(x, y);
+  for (uint32_t j = 2; j <= NB; j++) {
+    if (j > 2) xyzz29_madd(acc, x, y);
+    f29 ax, ay;
+    xyzz29_to_affine(acc, ax, ay);
+    affine q;
+    f29_pack(ax, q.x.v);
+    f29_pack(ay, q.y.v);
+    affine_store(table + ((size_t)(j - 1) * plane + t) * 64, q);
+  }
+}
 
 __global__ void __launch_bounds__(64) k_msm_small_digits(const fe* scalars, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W, uint8_t* dig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1074,80 +1107,20 @@ __device__ __forceinline__ void seg_tree_sum(xyzz29* lds, uint32_t nseg, uint32_
   }
 }
 
-__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_accum(const SmallBatch sb) {
-  const SmallDesc& d = sb.d[blockIdx.y];
-  const uint32_t NB = 1u << (d.c - 1);
-  if (blockIdx.x >= NB * d.S) return;  // a batch is launched over its largest member
-  const uint32_t b = blockIdx.x / d.S, sl = blockIdx.x % d.S, tid = threadIdx.x;
-  const uint32_t lo = sl * d.P, hi = min(lo + d.P, d.n);
-  xyzz29* tree = reinterpret_cast<xyzz29*>(h2_msm_smem);                                   // SMALL_THREADS values
-  uint32_t* list = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(h2_msm_smem) + (size_t)SMALL_THREADS * PART_BYTES);
-  __shared__ uint32_t m_sh;
-  if (tid == 0) m_sh = 0;
+// sum of the G partial sums -> Jacobian result (+ statistics); X: LDS for >= SMALL_PARTS_MAX values.  Whole workgroup.
+__device__ __forceinline__ void small_finish(const SmallDesc& d, xyzz29* X) {
+  const uint32_t tid = threadIdx.x, G = d.G;
+  __shared__ uint32_t ins_sh;
+  if (tid == 0) ins_sh = 0;
+  uint32_t T = 1;
+  while (T < G) T <<= 1;
   __syncthreads();
-  if (lo < hi) {
-    const uint32_t np = hi - lo, cells = np * d.W, want = b + 1;
-    for (uint32_t idx = tid; idx < cells; idx += SMALL_THREADS) {
-      const uint32_t w = idx / np, at = w * d.n_reg + lo + (idx - w * np);
-      const uint32_t dg = d.dig[at];
-      if ((dg & 0x7fu) == want) list[atomicAdd(&m_sh, 1u)] = (dg >> 7) << 31 | at;
-    }
+  for (uint32_t t = tid; t < T; t += SMALL_THREADS) {  // G <= SMALL_PARTS_MAX = 512 values, 256 lanes
+    X[t] = t < G ? part_load(d.part + (size_t)t * PART_BYTES) : xyzz29_identity();
+    if (t < G) atomicAdd(&ins_sh, d.cnt[t]);
   }
   __syncthreads();
-  const uint32_t m = m_sh;
-  uint8_t* dst = d.part + (size_t)blockIdx.x * PART_BYTES;
-  if (m == 0) {  // wavefront-uniform
-    if (tid == 0) {
-      part_store(dst, xyzz29_identity());
-      d.cnt[blockIdx.x] = 0;
-    }
-    return;
-  }
-  xyzz29 acc = xyzz29_identity();
-  for (uint32_t k = tid; k < m; k += SMALL_THREADS) {
-    const uint32_t e = list[k];
-    const affine p = affine_load(d.table + (size_t)(e & 0x7fffffffu) * 64);
-    if (affine_is_identity(p)) continue;
-    f29 x2 = f29_unpack(p.x.v), y2 = f29_unpack(p.y.v);
-    if (e >> 31) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
-    xyzz29_madd(acc, x2, y2);
-  }
-  uint32_t T = 1;  // the tree covers the lanes that hold a sum: the next power of two >= min(m, 256)
-  while (T < min(m, SMALL_THREADS)) T <<= 1;
-  if (tid < T) tree[tid] = acc;
-  __syncthreads();
-  seg_tree_sum(tree, 1, T);
-  if (tid == 0) {
-    part_store(dst, tree[0]);
-    d.cnt[blockIdx.x] = m;
-  }
-}
-
-__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_final(const SmallBatch sb) {
-  const SmallDesc& d = sb.d[blockIdx.x];
-  const uint32_t c = d.c, NB = 1u << (c - 1), S = d.S, tid = threadIdx.x, quad = tid >> 2;
-  xyzz29* X = reinterpret_cast<xyzz29*>(h2_msm_smem);  // SMALL_PARTS_MAX values
-  xyzz29* Y = X + SMALL_PARTS_MAX;                      // c * NB <= 7 * 64 values
-  if (tid < NB * S) X[tid] = part_load(d.part + (size_t)tid * PART_BYTES);
-  __syncthreads();
-  seg_tree_sum(X, NB, S);  // bucket sums: X[b * S]
-  // bit-sliced weights: A_j = sum of the buckets whose weight b + 1 has bit j set (weights 1 .. 2^(c-1): bits 0 .. c-1)
-  for (uint32_t t = tid; t < c * NB; t += SMALL_THREADS) {
-    const uint32_t j = t / NB, b = t % NB;
-    Y[t] = (((b + 1) >> j) & 1u) ? X[b * S] : xyzz29_identity();
-  }
-  __syncthreads();
-  seg_tree_sum(Y, c, NB);  // A_j: Y[j * NB]
-  // 2^j A_j: quad j doubles j times; then one tree over the (<= 8) terms
-  xyzz29 v = xyzz29_identity();
-  if (quad < c) {
-    v = Y[quad * NB];
-    for (uint32_t k = 0; k < quad; k++) v = xyzz29_dbl_quad(v);
-  }
-  __syncthreads();
-  if (quad < 8 && (tid & 3u) == 0) X[quad] = v;
-  __syncthreads();
-  seg_tree_sum(X, 1, 8);
+  seg_tree_sum(X, 1, T);
   if (tid == 0) {
     xyzz29 r = X[0];
     jac j;
@@ -1165,12 +1138,62 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_final(const SmallBa
       f29_to_mont256<Fq29>(r.zz, j.z.v);
     }
     jac_store(d.out, j);
-    if (d.stats) {
-      uint64_t ins = 0;
-      for (uint32_t t = 0; t < NB * S; t++) ins += d.cnt[t];
-      d.stats[0] = ins;
+    if (d.stats) d.stats[0] = ins_sh;
+  }
+}
+
+// One launch per batch: every workgroup leaves its partial sum, and the workgroup that ARRIVES LAST (a device-scope counter;
+// nobody waits for anybody, so there is nothing to deadlock) sums the partial sums of its MSM and writes the result — a second
+// launch cost ~8 us of the ~85 (launch + the first touch of the partial sums through a cold L2).  Release / acquire at agent
+// scope (__threadfence = the partial sums are written back before the counter moves, and re-read from memory after it):
+// the workgroups of one launch are spread over the eight XCDs, whose L2s are not coherent for plain accesses.
+__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_accum(const SmallBatch sb) {
+  const SmallDesc& d = sb.d[blockIdx.y];
+  if (blockIdx.x >= d.G) return;  // a batch is launched over its largest member
+  const uint32_t tid = threadIdx.x;
+  const uint32_t cells = d.n * d.W;           // cell = w * n + i (the digit array has row length n_reg)
+  const size_t plane = (size_t)d.W * d.n_reg;  // points per multiple
+  xyzz29* tree = reinterpret_cast<xyzz29*>(h2_msm_smem);  // SMALL_PARTS_MAX values
+  xyzz29 acc = xyzz29_identity();
+  uint32_t mine = 0;
+  const uint32_t lanes = d.lanes;
+  const uint32_t base = blockIdx.x * lanes * d.r;
+  for (uint32_t k = 0; k < d.r && tid < lanes; k++) {
+    const uint32_t cell = base + k * lanes + tid;
+    if (cell >= cells) break;
+    const uint32_t w = cell / d.n, at = w * d.n_reg + (cell - w * d.n);
+    const uint32_t dg = d.dig[at];
+    if (!dg) continue;
+    const affine p = affine_load(d.table + ((size_t)((dg & 0x7fu) - 1) * plane + at) * 64);
+    if (affine_is_identity(p)) continue;
+    mine++;
+    f29 x2 = f29_unpack(p.x.v), y2 = f29_unpack(p.y.v);
+    if (dg >> 7) y2 = f29_sub(f29_zero(), y2, Fq29::K2);  // 2p - y (lazy)
+    xyzz29_madd(acc, x2, y2);
+  }
+  if (tid < lanes) tree[tid] = acc;
+  __shared__ uint32_t cnt_sh, last_sh;
+  if (tid == 0) cnt_sh = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&cnt_sh, mine);
+  uint32_t live = min(cells - base, lanes), T = 1;  // lanes that had a cell at all (k = 0)
+  while (T < live) T <<= 1;
+  seg_tree_sum(tree, 1, T);  // (its first barrier also orders the counter)
+  if (tid == 0) {
+    part_store(d.part + (size_t)blockIdx.x * PART_BYTES, tree[0]);
+    d.cnt[blockIdx.x] = cnt_sh;
+    __threadfence();  // release: this workgroup's partial sum and count are visible device-wide before its arrival is
+    const uint32_t ticket = atomicAdd(&d.cnt[d.ticket_at], 1u);
+    last_sh = ticket == d.G - 1 ? 1u : 0u;
+    if (last_sh) {
+      d.cnt[d.ticket_at] = 0;  // ready for the slot's next MSM (stream order: no workgroup of this MSM touches it again)
+      __threadfence();          // acquire: the other workgroups' partial sums are read from memory, not from a stale line
     }
   }
+  __syncthreads();
+  if (!last_sh) return;  // workgroup-uniform
+  __threadfence();       // every lane that is about to read the partial sums orders its loads behind the counter
+  small_finish(d, tree);
 }
 
 // debug hook for the lane-cooperative point operations (g1_29_quad.cuh): four lanes per element.
@@ -1234,21 +1257,33 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
-// small base sets: window width, slices (see "small base sets").  NB * S <= 256 partial sums (one workgroup of the final
-// kernel holds them in LDS), P * W <= SMALL_LIST_MAX entries per slice.  First guesses by depth count, then measured
-// (tools/msm_small_sweep.py -> profiles/r04_msm_small_sweep.txt).
-static void small_geometry(size_t n, uint32_t* c, uint32_t* S) {
-  uint32_t cc = n <= 256 ? 3 : n <= 1024 ? 4 : 5;
+// small base sets: window width, gathering lanes per workgroup and cells per lane (see "small base sets").  Up to 128 x 256
+// cells: 128 lanes, one cell each; beyond: 256 lanes and r = ceil(n W / (256 x 512)) cells each (<= 512 workgroups = two
+// wavefronts per SIMD: a lone wavefront issues a multiply-add every 8 cycles, two share the unit at ~4.8).  The window is the
+// widest whose table 2^(c-1) x W x n x 64 B stays within SMALL_TABLE_BUDGET.  Returns false when the set does not take the path.
+// First guesses by level count, then measured (tools/msm_small_sweep.sh -> profiles/r04_msm_small_sweep.txt).
+constexpr size_t SMALL_TABLE_BUDGET = (size_t)2 << 30;  // per base set: c = 7 up to 2^13 points (1.2 GB), c = 6 at 2^14 (1.4 GB)
+static bool small_geometry(size_t n, uint32_t* c, uint32_t* lanes, uint32_t* r) {
+  size_t max_n = SMALL_MAX_N;
+  if (const char* ev = ab_env("H2MI_MSM_SMALL_MAX_LOG"))
+    max_n = std::min<size_t>(SMALL_MAX_N, (size_t)1 << std::max(0, atoi(ev)));
+  if (n > max_n) return false;
+  uint32_t cc = SMALL_C_MAX;
+  while (cc > 2 && ((size_t)1 << (cc - 1)) * ((255 + cc - 1) / cc) * n * 64 > SMALL_TABLE_BUDGET) cc--;
   if (const char* ev = ab_env("H2MI_MSM_SMALL_C"))
     if (atoi(ev) >= 2 && atoi(ev) <= (int)SMALL_C_MAX) cc = (uint32_t)atoi(ev);
-  const uint32_t NB = 1u << (cc - 1), W = (255 + cc - 1) / cc;
-  uint32_t SS = SMALL_PARTS_MAX / NB;  // as many slices as the final kernel takes ...
-  while (SS > 1 && (size_t)SS / 2 * 8 >= n) SS >>= 1;  // ... but at least ~8 points per slice
-  if (const char* ev = ab_env("H2MI_MSM_SMALL_S"))
-    if (atoi(ev) >= 1 && (uint32_t)atoi(ev) * NB <= SMALL_PARTS_MAX && (atoi(ev) & (atoi(ev) - 1)) == 0) SS = (uint32_t)atoi(ev);
-  while (((n + SS - 1) / SS) * W > SMALL_LIST_MAX && SS * 2 * NB <= SMALL_PARTS_MAX) SS <<= 1;
+  const size_t cells = n * ((255 + cc - 1) / cc);
+  uint32_t ll = SMALL_CELLS, rr = 1;
+  if (cells > (size_t)SMALL_CELLS * 256) {
+    ll = SMALL_THREADS;
+    rr = (uint32_t)((cells + (size_t)SMALL_THREADS * SMALL_PARTS_MAX - 1) / ((size_t)SMALL_THREADS * SMALL_PARTS_MAX));
+  }
+  if (const char* ev = ab_env("H2MI_MSM_SMALL_R"))
+    if (atoi(ev) >= (int)rr && atoi(ev) <= 256) rr = (uint32_t)atoi(ev), ll = SMALL_THREADS;
   *c = cc;
-  *S = SS;
+  *lanes = ll;
+  *r = rr;
+  return true;
 }
 
 // H2MI_MSM_S0 fixes the chunk length (tuning / tests); 0 = chosen on the device from the entry count
@@ -1365,25 +1400,25 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
                        B->table + (size_t)w * B->stride * 64, n, B->c);
     if (prof_) prof_end(s);
   }
-  if (n <= SMALL_MAX_N) {  // second table with narrow windows for the latency path (see "small base sets")
-    small_geometry(n, &B->sc, &B->sS);
+  if (small_geometry(n, &B->sc, &B->slanes, &B->sr)) {  // second table for the latency path: every multiple a signed digit can select
     B->sW = (255 + B->sc - 1) / B->sc;
-    B->sP = (uint32_t)((n + B->sS - 1) / B->sS);
-    if ((size_t)B->sP * B->sW <= SMALL_LIST_MAX) {
-      const uint32_t NBs = 1u << (B->sc - 1);
-      H2_ALLOC(B->stable, (size_t)B->sW * n * 64);
-      for (int si_ = 0; si_ < B->nslot; si_++) {
-        Slot& S = B->slot[si_];
-        H2_ALLOC(S.sdig, (size_t)B->sW * n);
-        H2_ALLOC(S.spart, (size_t)NBs * B->sS * PART_BYTES);
-        H2_ALLOC(S.scnt, (size_t)NBs * B->sS * 4);
-      }
-      if (hipMemcpyAsync(B->stable, B->table, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
-      for (uint32_t w = 1; w < B->sW; w++)
-        hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 64)), dim3(64), 0, s, (const uint8_t*)(B->stable + (size_t)(w - 1) * n * 64),
-                           B->stable + (size_t)w * n * 64, n, B->sc);
-      B->small = true;
+    B->sG = ceil_div_u32((uint64_t)n * B->sW, (uint64_t)B->slanes * B->sr);
+    const uint32_t NBs = 1u << (B->sc - 1);
+    const size_t plane = (size_t)B->sW * n;
+    H2_ALLOC(B->stable, (size_t)NBs * plane * 64);
+    for (int si_ = 0; si_ < B->nslot; si_++) {
+      Slot& S = B->slot[si_];
+      H2_ALLOC(S.sdig, plane);
+      H2_ALLOC(S.spart, (size_t)B->sG * PART_BYTES);
+      H2_ALLOC(S.scnt, (size_t)(B->sG + 1) * 4);
+      if (hipMemsetAsync(S.scnt, 0, (size_t)(B->sG + 1) * 4, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }  // [sG] = the arrival counter
     }
+    if (hipMemcpyAsync(B->stable, B->table, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
+    for (uint32_t w = 1; w < B->sW; w++)
+      hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 64)), dim3(64), 0, s, (const uint8_t*)(B->stable + (size_t)(w - 1) * n * 64),
+                         B->stable + (size_t)w * n * 64, n, B->sc);
+    hipLaunchKernelGGL(k_msm_small_multiples, dim3(ceil_div_u32(plane, 64)), dim3(64), 0, s, B->stable, plane, NBs);
+    B->small = true;
   }
   // slot n of every window stays the identity until the sum point is known
   for (uint32_t w = 0; w < B->W; w++)
@@ -1628,22 +1663,20 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
 // ---- small base sets: host side ---------------------------------------------------------------------------------
 static SmallDesc small_desc(const Bases* B, const Slot& S) {
   SmallDesc d;
-  d.dig = S.sdig; d.table = B->stable; d.part = S.spart; d.cnt = S.scnt; d.out = (uint8_t*)S.d_out; d.stats = S.stats;
-  d.n = S.small_n; d.n_reg = (uint32_t)B->n; d.W = B->sW; d.c = B->sc; d.S = B->sS; d.P = B->sP; d.canonical = g_canonical ? 1u : 0u;
+  d.dig = S.sdig; d.table = B->stable; d.part = S.spart; d.cnt = S.scnt; d.ticket_at = B->sG; d.out = (uint8_t*)S.d_out; d.stats = S.stats;
+  d.n = S.small_n; d.n_reg = (uint32_t)B->n; d.W = B->sW; d.c = B->sc; d.r = B->sr; d.lanes = B->slanes; d.canonical = g_canonical ? 1u : 0u;
+  d.G = ceil_div_u32((uint64_t)d.n * d.W, (uint64_t)d.lanes * d.r);  // <= B->sG: an MSM over the first n <= n_reg bases
   return d;
 }
 
-static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts, uint32_t max_list, hipStream_t t) {
+static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts, hipStream_t t) {
+  constexpr size_t LDS = (size_t)SMALL_PARTS_MAX * PART_BYTES;  // 72 KB: above the 64 KB a kernel gets without asking
   static bool attr_set = false;
-  constexpr size_t ACC_LDS_MAX = (size_t)SMALL_THREADS * PART_BYTES + (size_t)SMALL_LIST_MAX * 4;
-  constexpr size_t FIN_LDS = (size_t)(SMALL_PARTS_MAX + SMALL_C_MAX * (1u << (SMALL_C_MAX - 1))) * PART_BYTES;
   if (!attr_set) {
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_MAX));
-    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIN_LDS));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_set = true;
   }
-  H2_LAUNCH("k_msm_small_accum", k_msm_small_accum, dim3(max_parts, count), SMALL_THREADS, (size_t)SMALL_THREADS * PART_BYTES + (size_t)max_list * 4, t, sb);
-  H2_LAUNCH("k_msm_small_final", k_msm_small_final, count, SMALL_THREADS, FIN_LDS, t, sb);
+  H2_LAUNCH("k_msm_small_accum", k_msm_small_accum, dim3(max_parts, count), SMALL_THREADS, LDS, t, sb);
   return H2MI_OK;
 }
 
@@ -1682,7 +1715,7 @@ static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hip
   }
   SmallBatch sb;
   for (uint32_t j = 0; j < SMALL_BATCH; j++) sb.d[j] = small_desc(B, S);
-  int rc = launch_small(sb, 1, (1u << (B->sc - 1)) * B->sS, B->sP * B->sW, s);
+  int rc = launch_small(sb, 1, sb.d[0].G, s);
   if (rc) return rc;
   H2_HIP(hipEventRecord(S.tail_done, s));
   S.tail_pending = true;
@@ -1759,22 +1792,24 @@ static int flush_tails() {
     for (const Deferred& d : mine) group[d.S->small_deferred ? 0 : d.B->seg_log ? 2 : 1].push_back(d);
     for (size_t i = 0; i < group[0].size();) {
       SmallBatch sb;
-      uint32_t count = 0, max_parts = 0, max_list = 0;
+      uint32_t count = 0, max_parts = 0;
       const size_t first = i;
+      // the small path's pair runs on the device's LIBRARY stream, behind the digit kernels that were queued there: a
+      // cross-stream hop costs ~10 us each way (event record -> wait -> launch, measured: 26 us of gaps around 81 us of
+      // kernels), more than these kernels could ever gain from running beside the stream's other work
+      hipStream_t ls = ctx().stream;
       for (; i < group[0].size() && count < SMALL_BATCH; i++, count++) {
         Bases* B = group[0][i].B;
         Slot& S = *group[0][i].S;
-        H2_HIP(hipStreamWaitEvent(t, S.accum_done, 0));
         sb.d[count] = small_desc(B, S);
-        max_parts = std::max(max_parts, (1u << (B->sc - 1)) * B->sS);
-        max_list = std::max(max_list, B->sP * B->sW);
+        max_parts = std::max(max_parts, sb.d[count].G);
       }
       for (uint32_t j = count; j < SMALL_BATCH; j++) sb.d[j] = sb.d[0];  // never read: blockIdx.y < count
-      int rc = launch_small(sb, count, max_parts, max_list, t);
+      int rc = launch_small(sb, count, max_parts, ls);
       if (rc) return rc;
       for (size_t j = first; j < i; j++) {
         Slot& S = *group[0][j].S;
-        H2_HIP(hipEventRecord(S.tail_done, t));
+        H2_HIP(hipEventRecord(S.tail_done, ls));
         S.tail_pending = true;
         S.tail_ever = true;
         S.tail_deferred = false;
@@ -2282,9 +2317,8 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   uint64_t st = 0;
   H2_HIP(hipMemcpy(&st, B->slot[B->last_slot].stats, 8, hipMemcpyDeviceToHost));
   if (bucket_adds) *bucket_adds = st;
-  if (reduce_adds && B->small && g_small_path) {  // partial sums -> bucket sums, c bit-sliced trees, c (c - 1) / 2 doublings, the last tree
-    const uint64_t NBs = 1ull << (B->sc - 1);
-    *reduce_adds = NBs * B->sS + (uint64_t)B->sc * NBs / 2 + (uint64_t)B->sc * (B->sc - 1) / 2 + B->sc;
+  if (reduce_adds && B->small && g_small_path) {  // the quad trees: 255 additions per workgroup of 256 lanes, then over the partial sums
+    *reduce_adds = (uint64_t)B->sG * (B->slanes - 1) + B->sG;
   } else if (reduce_adds) {
     // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))
     uint64_t Nh = 1ull << B->logNh, Nl = 1ull << B->logNl;

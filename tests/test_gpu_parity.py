@@ -290,7 +290,7 @@ def test_msm_small_path_and_general_pipeline_agree_with_oracle(gpu, n):
     assert gpu.lib.h2mi_stream_create(C.byref(st)) == 0
     assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_sc[0].ptr, n, d_out.ptr, st) == 0
     assert gpu.lib.h2mi_stream_destroy(st) == 0  # synchronises the stream
-    assert o.unpack_jacobian(d_out.to_numpy(shape=(1, 12))[0]) == o.unpack_jacobian(cref.msm(scal[0], bases, 2))
+    assert o.unpack_jacobian(d_out.to_numpy(shape=(len(scal), 12))[0]) == o.unpack_jacobian(cref.msm(scal[0], bases, 2))
     for d in d_sc:
         d.free()
     d_out.free()

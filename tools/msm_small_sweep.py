@@ -1,7 +1,7 @@
 """Small-set MSM: latency (one call, synchronised), back-to-back throughput and the latency of a prover-phase-like batch (four
 MSMs, one join) for n = 2^5 .. 2^13, through the small path and (test hook) through the general pipeline, with the per-kernel
 device times of one call.  With the -DH2MI_AB library (H2MI_LIBRARY=halo2-scaffold_amd/libh2mi_ab.so) H2MI_MSM_SMALL_C /
-H2MI_MSM_SMALL_S sweep the window width and the slice count.  Usage: msm_small_sweep.py [k ...]"""
+H2MI_MSM_SMALL_R sweep the window width and the cells per lane.  Usage: msm_small_sweep.py [k ...]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch  # noqa: F401
@@ -13,7 +13,7 @@ ks = [int(x) for x in sys.argv[1:]] or [5, 8, 10, 12, 13]
 full = h2.ParamsKZG.setup(max(ks), 0x1234567)
 g = full.get_g()
 full.release()
-tag = f"small_c={os.environ.get('H2MI_MSM_SMALL_C', 'default')} small_s={os.environ.get('H2MI_MSM_SMALL_S', 'default')}"
+tag = f"small_c={os.environ.get('H2MI_MSM_SMALL_C', 'default')} small_r={os.environ.get('H2MI_MSM_SMALL_R', 'default')}"
 for k in ks:
     n = 1 << k
     hreg = C.c_uint64()
@@ -21,7 +21,7 @@ for k in ks:
     assert lib.h2mi_bases_register(bases.ctypes.data, n, C.byref(hreg)) == 0
     sc = [h2.DevBuf.from_numpy(synth.uniform_fr(n, 5 + i)) for i in range(4)]
     out = h2.DevBuf(96 * 4)
-    for small in ((1, 0) if n <= 4096 else (0,)):
+    for small in (1, 0):
         lib.h2mi_dbg_msm_small_path(small)
         run = lambda i=0: lib.h2mi_msm_bn254_g1_dev(hreg.value, sc[i].ptr, n, out.ptr + 96 * i, None)
         for _ in range(5): run()
