@@ -1351,7 +1351,7 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
   // 2^(c-1) >= 1024 entries for every window width pick_window() can return
   if ((B->nbins & 3u) || B->nb < 4 || (B->nb > SCAN_SEG_TASKS && !B->seg_log) || B->nbins > NBINS_MAX || (1u << B->lb) > NQW) { free_bases(B); return H2MI_ERANGE; }
   B->nslot = n > ((size_t)1 << 17) ? 4 : NSLOT;
-  if (const char* ev = getenv("H2MI_MSM_SLOTS"))  // A/B knob
+  if (const char* ev = ab_env("H2MI_MSM_SLOTS"))  // A/B knob
     if (atoi(ev) >= 2 && atoi(ev) <= NSLOT) B->nslot = atoi(ev);
   for (int si_ = 0; si_ < B->nslot; si_++) {
     Slot& S = B->slot[si_];
@@ -1633,7 +1633,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // MSMs (bucket reduction, partition) cannot start until it drains.  An unused dynamic-LDS reservation of
   // 56000 B holds it at two workgroups per CU and leaves half the registers and 48 KB of LDS per CU free:
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
-  static const size_t accum_lds = getenv("H2MI_ACCUM_LDS") ? (size_t)atoi(getenv("H2MI_ACCUM_LDS")) : 56000;
+  static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
             (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;
@@ -1645,7 +1645,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
     S.accum_ever = true;
     S.tail_deferred = true;
     g_deferred.push_back({B, &S});
-    static const bool eager = getenv("H2MI_MSM_EAGER_TAIL") != nullptr;  // A/B: one reduction per MSM, at once
+    static const bool eager = ab_env("H2MI_MSM_EAGER_TAIL") != nullptr;  // A/B: one reduction per MSM, at once
     // half the slots: the reductions of one half run beside the accumulation of the other
     if (eager || g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
     return H2MI_OK;
@@ -1730,7 +1730,7 @@ static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hip
 static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1, uint32_t max_nb, uint32_t max_logNh, uint32_t max_logNl,
                         uint32_t max_seg, hipStream_t t) {
   // fold / finish: quads (4 lanes per point operation) while the grid stays latency-bound, single lanes beyond
-  const bool force_lane = getenv("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
+  const bool force_lane = ab_env("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
   bool all_wide = max_seg != 0;
   for (uint32_t j = 0; j < count; j++) all_wide = all_wide && tb.d[j].seg_log != 0;
   if (all_wide) {

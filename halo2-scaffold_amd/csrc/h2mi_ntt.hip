@@ -84,6 +84,7 @@ struct PassParams {
   const fe* phi;
   uint32_t ph;
   uint32_t tfull, pfull;  // the twiddle / pre-scale table holds every power: fetch instead of hi * lo
+  const fe* wmat;         // non-final pass: the pass's inter-pass twiddles in the order its tiles read them, or null (see k_ntt_wmat_build)
   int has_post;
   f29 post;       // Montgomery-2^261 limbs (converted on the host: every thread of the last pass multiplies by it)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
@@ -274,8 +275,12 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
     f29 x = lds_get(lds, dstride, (c << m) | k);
-    uint32_t ex = ((jl0 + c) * k) << sh;  // < n
-    x = f29_mul<F9>(x, powtab(p.tlo, p.thi, p.h, p.tfull, ex));
+    if (p.wmat) {  // tile-ordered copy of the twiddles: entry o of this tile, whichever segment the tile sits in
+      x = f29_mul<F9>(x, load_unpack(&p.wmat[((size_t)(jl0 >> logC) << (m + logC)) + o]));
+    } else {
+      uint32_t ex = ((jl0 + c) * k) << sh;  // < n
+      x = f29_mul<F9>(x, powtab(p.tlo, p.thi, p.h, p.tfull, ex));
+    }
     // the product is normalized and below 1.2 p (< 2^255): stored as it is, without the canonical reduction — the next pass
     // reads it as a loosely reduced input (its lazy rounds then stay below 34 p of the 169 p capacity; the LAST pass alone
     // returns canonical values)
@@ -322,6 +327,20 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
       fe_store(&p.out[oidx], o_);
     }
   }
+}
+
+// Inter-pass twiddles in TILE ORDER (round 4).  A column-pass tile multiplies its element (column j = jl0 + c, row k) by
+// omega^((j k) << sh).  Fetched from the full power table omega^i that is a gather with stride j * 32 B: every 32-byte entry
+// sits in a 128-byte line of its own, and the pass fetched 130 MB where it needs 32 MB of data and 32 MB of twiddles
+// (profiles/r03_traffic.json: 129.7 MB per k_ntt_pass_col<1024,10> launch; profiles/r04_ntt_traffic.txt has both forms).  The
+// matrix W[tile][o] = omega^((j k) << sh), o = (k << logC) + c, j = tile * C + c, holds the same 2^log_seg values in the order
+// the tiles' threads read them: consecutive lanes read consecutive 32-byte entries.  Built once per plan from the full table.
+__global__ void __launch_bounds__(256) k_ntt_wmat_build(const fe* full, fe* W, uint32_t log_seg, uint32_t m, uint32_t logC, uint32_t sh) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >> log_seg) return;
+  const uint32_t o = (uint32_t)idx & ((1u << (m + logC)) - 1), tile = (uint32_t)(idx >> (m + logC));
+  const uint32_t c = o & ((1u << logC) - 1), k = o >> logC, j = (tile << logC) + c;
+  fe_store(&W[idx], fe_load(&full[(size_t)(j * k) << sh]));
 }
 
 // a[i] = a[i] * base^i (* post)
@@ -731,6 +750,8 @@ struct Plan {
   uint32_t m[3] = {0, 0, 0};
   PowTab tw;
   fe* loc[3] = {nullptr, nullptr, nullptr};
+  fe* wmat[3] = {nullptr, nullptr, nullptr};  // tile-ordered inter-pass twiddles of the non-final passes (k_ntt_wmat_build)
+  uint32_t wlogC[3] = {0, 0, 0};              // the tile geometry each was built for
   Built built;
   uint64_t last_use = 0;
 };
@@ -1090,15 +1111,17 @@ __device__ __forceinline__ void evaluate_h_range_body(const RangeCosets& c, uint
 // two register budgets of the same body (round 3): unconstrained it takes 169 VGPRs (two wavefronts per
 // SIMD); held to 128 (four wavefronts) it spills 40 dwords to scratch.  Measured inside the range proof at DEGREE 22 on one
 // box, alternating: 74.8 / 75.1 ms unconstrained, 75.1 / 75.3 ms at 128 VGPRs — the kernel streams 2^24 rows at ~40 % of HBM and
-// the spills cost what the occupancy buys.  The unconstrained form stays the default; H2MI_EVALH_OCC=4 selects the other.
+// the spills cost what the occupancy buys.  The unconstrained form is the product; the other exists in the -DH2MI_AB library (H2MI_EVALH_OCC=4).
 __global__ void __launch_bounds__(256) k_evaluate_h_range(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h, const fe* xlo,
                                                            const fe* xhi, uint32_t xh, fe* out) {
   evaluate_h_range_body(c, ext_k, k, last_rot, h, xlo, xhi, xh, out);
 }
+#ifdef H2MI_AB  // the measured loser is compiled into the A/B library only (make ab), not into the product
 __global__ void __launch_bounds__(256, 4) k_evaluate_h_range_occ4(RangeCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, HConsts h,
                                                                   const fe* xlo, const fe* xhi, uint32_t xh, fe* out) {
   evaluate_h_range_body(c, ext_k, k, last_rot, h, xlo, xhi, xh, out);
 }
+#endif
 
 // the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
 // as a Montgomery-2^256 value is (32 x) 2^256; its inverse (x^-1 / 32) 2^256 times 2^10 is x^-1 2^261.
@@ -1237,6 +1260,7 @@ static void fill_common(HConsts& h, const fe& beta, const fe& gamma, const fe& d
 // (`g_epoch` counts ABI calls; an entry touched in this epoch is pinned), and only after the whole device is
 // idle, since tables may be in use on any stream.
 constexpr uint32_t FULL_TABLE_MAX_LOG = 22;
+constexpr uint32_t NTT_TILE_LOG = 10;  // elements a pass stages per workgroup (2^10: four tiles of 40 KB per CU)
 constexpr size_t POWTAB_MAX_ENTRIES = 64, POWTAB_KEEP_ENTRIES = 32;
 constexpr size_t POWTAB_MAX_BYTES = (size_t)3 << 30, POWTAB_KEEP_BYTES = (size_t)3 << 29;
 static size_t g_powtab_bytes = 0;
@@ -1253,6 +1277,10 @@ static void free_plan(Plan& pl) {
       if (pl.loc[j] == p) pl.loc[j] = nullptr;
     H2_IGNORE(hipFree(p));
     pl.loc[i] = nullptr;
+  }
+  for (int i = 0; i < 3; i++) {
+    if (pl.wmat[i]) H2_IGNORE(hipFree(pl.wmat[i]));
+    pl.wmat[i] = nullptr;
   }
   pl.built.destroy();
 }
@@ -1290,7 +1318,7 @@ static int evict_tables() {
 }
 
 static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, PowTab* out, bool full = false) {
-  full = full && log_n <= FULL_TABLE_MAX_LOG && !getenv("H2MI_NTT_NO_FULL_TABLES");
+  full = full && log_n <= FULL_TABLE_MAX_LOG && !ab_env("H2MI_NTT_NO_FULL_TABLES");
   Key k;
   memcpy(k.w, base, 32);
   k.log_n = log_n;
@@ -1328,8 +1356,8 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
 }
 
 static void choose_split(uint32_t log_n, Plan* pl) {
-  static const uint32_t MAXM = getenv("H2MI_NTT_MAXM") ? (uint32_t)atoi(getenv("H2MI_NTT_MAXM")) : 10;  // tuning knob (7 .. 10)
-  if (const char* ev = getenv("H2MI_NTT_SPLIT")) {  // tuning knob: "8,8,4" — used for the size whose log_n the parts add up to
+  static const uint32_t MAXM = ab_env("H2MI_NTT_MAXM") ? (uint32_t)atoi(ab_env("H2MI_NTT_MAXM")) : 10;  // tuning knob (7 .. 10)
+  if (const char* ev = ab_env("H2MI_NTT_SPLIT")) {  // tuning knob: "8,8,4" — used for the size whose log_n the parts add up to
     uint32_t a = 0, b = 0, c = 0;
     const int got = sscanf(ev, "%u,%u,%u", &a, &b, &c);
     if (got >= 2 && a + b + c == log_n && a >= 1 && b >= 1 && a <= 10 && b <= 10 && c <= 10) {
@@ -1388,6 +1416,22 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
     }
     // w_loc = omega^(n / 2^m): order 2^m
     H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m, m - 1);
+  }
+  if (pl.tw.full && !ab_env("H2MI_NTT_NO_WMAT")) {  // tile-ordered twiddle matrices of the non-final passes (default tile: 2^10 elements)
+    uint32_t log_seg = log_n;
+    for (int p = 0; p + 1 < pl.P; p++) {
+      const uint32_t m = pl.m[p], logS = log_seg - m;
+      const uint32_t logC = std::min(m >= NTT_TILE_LOG ? 0u : NTT_TILE_LOG - m, logS);
+      if (hipMalloc(&pl.wmat[p], ((size_t)1 << log_seg) * 32) != hipSuccess) {
+        pl.wmat[p] = nullptr;
+        free_plan(pl);
+        return H2MI_ENOMEM;
+      }
+      pl.wlogC[p] = logC;
+      H2_LAUNCH("k_ntt_wmat_build", k_ntt_wmat_build, ceil_div_u32((size_t)1 << log_seg, 256), 256, 0, s, (const fe*)pl.tw.lo, pl.wmat[p], log_seg, m, logC,
+                log_n - log_seg);
+      log_seg -= m;
+    }
   }
   H2_HIP(pl.built.mark(s));
   pl.last_use = g_epoch;
@@ -1459,7 +1503,7 @@ static int release_tmp(hipStream_t s) {
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* v = getenv(name);
+  const char* v = ab_env(name);  // tile geometry experiments: -DH2MI_AB builds only
   return v ? (uint32_t)atoi(v) : dflt;
 }
 
@@ -1485,7 +1529,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     rc = ensure_tmp(n, s);
     if (rc) return rc;
   }
-  const uint32_t tile_elems_log = env_u32("H2MI_NTT_TILE_LOG", 10);  // elements staged per block
+  const uint32_t tile_elems_log = env_u32("H2MI_NTT_TILE_LOG", NTT_TILE_LOG);  // elements staged per block
   const uint32_t remap = env_u32("H2MI_NTT_XCD_REMAP", 1);
   uint32_t nthreads = env_u32("H2MI_NTT_THREADS", 256);
   if (nthreads != 64 && nthreads != 128 && nthreads != 256 && nthreads != 512) nthreads = 256;
@@ -1505,7 +1549,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
 #undef H2_NTT_ATTR
     attr_set = true;
   }
-  static const bool fixed_geometry = !getenv("H2MI_NTT_RUNTIME_GEOMETRY");  // A/B knob: the run-time kernels everywhere
+  static const bool fixed_geometry = !ab_env("H2MI_NTT_RUNTIME_GEOMETRY");  // A/B knob (-DH2MI_AB): the run-time kernels everywhere
 // the compile-time form exists for 1024-element tiles and DFT sizes 2^7 .. 2^10 (every pass of every transform >= 2^14)
 #define H2_NTT_LAUNCH(NAME, KERNEL)                                                                                       \
   do {                                                                                                                    \
@@ -1548,6 +1592,7 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
       uint32_t logS = log_seg - pp.m;
       if (logC > logS) logC = logS;
       pp.logC = logC;
+      pp.wmat = (pl.wmat[p] && pl.wlogC[p] == logC) ? pl.wmat[p] : nullptr;  // (a tile-geometry experiment falls back to the gather)
       uint32_t nblocks = (uint32_t)(n >> (pp.m + logC));
       size_t shmem = ((size_t)1 << (pp.m + logC)) * 36 + std::min<size_t>((size_t)1 << (pp.m - 1), TW_STAGED) * 32;
       H2_NTT_LAUNCH("k_ntt_pass_col", k_ntt_pass_col);
@@ -2020,7 +2065,7 @@ int h2mi_plonk_lookup_product_dev(const void* d_input, const void* d_table, cons
   uint32_t* active = segsum + nseg + 8;
   const fe *in = (const fe*)d_input, *tab = (const fe*)d_table, *pin = (const fe*)d_permuted_input, *ptab = (const fe*)d_permuted_table;
   // the rows whose ratio can differ from one; the count decides between the sparse and the dense form (one 4-byte read)
-  static const bool force_dense = getenv("H2MI_LOOKUP_DENSE") != nullptr;  // A/B
+  static const bool force_dense = ab_env("H2MI_LOOKUP_DENSE") != nullptr;  // A/B (-DH2MI_AB)
   uint32_t n_act = usable_rows;
   if (!force_dense && usable_rows >= 4096) {
     H2_LAUNCH("k_lookup_flag", k_lookup_flag, ceil_div_u32(uu, 256), 256, 0, s, in, tab, pin, ptab, usable_rows, uu, flag);
@@ -2133,14 +2178,16 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
     }
   }
   const uint32_t size = 1u << extended_k;
-  static const bool occ4 = getenv("H2MI_EVALH_OCC") && atoi(getenv("H2MI_EVALH_OCC")) == 4;
-  if (!occ4) {
-    H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
-              (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
-  } else {
+#ifdef H2MI_AB
+  static const bool occ4 = ab_env("H2MI_EVALH_OCC") && atoi(ab_env("H2MI_EVALH_OCC")) == 4;
+  if (occ4) {
     H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range_occ4, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
               (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
+    return H2MI_OK;
   }
+#endif
+  H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
+            (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
   return H2MI_OK;
 }
 

@@ -154,3 +154,45 @@ def test_four_virtual_devices_bytes(gpu, tmp_path):
     env = dict(os.environ, H2MI_VIRTUAL_DEVICES="1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "BIG_MULTIDEV_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+_WORKER8 = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch  # first: one HIP runtime
+import _load_pkg
+h2 = _load_pkg.load()
+lib = h2.lib
+assert lib.h2mi_init_devices(8) == 0 and lib.h2mi_device_count() == 8
+gold = json.load(open(os.path.join({root!r}, "tests", "golden", "big_proofs.json")))
+secret = int(gold["srs_secret"], 16)
+case = {{c["name"]: c for c in gold["cases"]}}["range_k22_bits16"]
+from halo2_scaffold_amd import flex
+import ctypes as C
+params = h2.ParamsKZG.setup(case["k"], secret)          # 2^22 bases: eight slices of 2^19, as on the real node
+c, W, nb, nn = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+assert lib.h2mi_bases_info(params.g_handle, C.byref(c), C.byref(W), C.byref(nb), C.byref(nn)) == 0
+assert nn.value == 1 << 22 and c.value == 16, (nn.value, c.value)   # the slices' own window width (2^19 points), not the 20 bits of 2^22
+cs = flex.FlexGateCS(lookup=True)
+asg = flex.range_closure(cs, int(case["x"], 16), case["lookup_bits"])
+assert asg.instance == [int(v, 16) for v in case["instance"]]
+keys = flex.FlexKeys(params, cs, asg)
+assert keys.vk_bytes().hex() == case["vk_bytes"]
+trace = {{}}
+proof = flex.create_proof(params, keys, asg, case["seed"], trace=trace)
+for ch in ("theta", "beta", "gamma", "y", "x"):
+    assert trace[ch] == int(case["challenges"][ch], 16), ch
+assert proof.hex() == case["proof"], "range_k22_bits16"
+print("BIG_MULTIDEV8_OK")
+"""
+
+
+def test_eight_virtual_devices_range_k22_bytes(gpu, tmp_path):
+    """BASELINE configs[3] at its own size and its own partition: range_check with LOOKUP_BITS = 16 at DEGREE 22, every commitment a
+    sharded MSM over EIGHT slices of 2^19 bases (h2mi_init_devices(8), virtual on a one-GPU box: 8 x 2 window tables of 0.5 GB) —
+    the slices take 16-bit windows where the single-GPU run takes 20 — against the committed golden proof (src/scaffold.rs:434-485)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8.format(root=ROOT))
+    env = dict(os.environ, H2MI_VIRTUAL_DEVICES="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0 and "BIG_MULTIDEV8_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -193,7 +193,10 @@ def test_msm_dominant_value_columns(gpu, k):
     ba, ra = C.c_uint64(), C.c_uint64()
     params.commit_lagrange(np.ascontiguousarray(cols["grand-product-like"]))
     assert h2.lib.h2mi_msm_last_stats(params.g_lagrange_handle, C.byref(ba), C.byref(ra)) == 0
-    assert ba.value < 64 * 20, ba.value
+    if k >= 15:
+        assert ba.value < 64 * 20, ba.value
+    else:  # base sets up to 2^14 take the bucketless small path (round 4): no bucket can run hot there, so nothing is shifted —
+        assert 0 < ba.value <= n * 128, ba.value  # a constant column costs what a uniform one costs, one gather per non-zero digit
     params.release()
 
 
