@@ -119,7 +119,6 @@ struct Bases {
   uint32_t c = 0, W = 0, nb = 0, logNl = 0, logNh = 0;
   uint32_t seg_log = 0;         // wide windows (c >= 18): nb = 2^(MAT_LOG + seg_log); the bucket matrix stays 2^logNh x 2^logNl = 2^16
   uint8_t* table = nullptr;     // [W][n] affine, 64 B each (canonical Montgomery-2^261 words)
-  uint8_t* table72 = nullptr;   // -DH2MI_TABLE72 only: the same entries as 2 x 9 unpacked limbs
   uint8_t* host_stage = nullptr;  // 96 B result + n scalars: staging of the host-pointer entry point (lazy)
   uint32_t lb = 0, nbins = 0;   // partition: nbins bins of 2^lb buckets
   Slot slot[NSLOT];
@@ -691,49 +690,14 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* toff, uint32_t n
   return lo;
 }
 
-// what the accumulation gathers per entry.  Product: the 64-byte table entry (two canonical 8-word values, unpacked to 9 limbs
-// each after the load).  -DH2MI_TABLE72 (measurement build, round 4): a second table with the limbs already unpacked, 72 bytes per
-// entry — ~36 fewer instructions per addition of ~2320 for 12 % more gathered bytes (profiles/r04_accum_ab.txt has the verdict).
-#ifdef H2MI_TABLE72
-constexpr uint32_t TAB_BYTES = 72;
-struct tab_entry { uint32_t w[18]; };
-__device__ __forceinline__ tab_entry tab_load(const uint8_t* table, uint32_t i) {
-  const uint2* q = reinterpret_cast<const uint2*>(table + (size_t)i * 72);
-  tab_entry r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) { uint2 v = q[k]; r.w[2 * k] = v.x; r.w[2 * k + 1] = v.y; }
-  return r;
-}
-__device__ __forceinline__ bool tab_is_identity(const tab_entry& p) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int k = 0; k < 18; k++) o |= p.w[k];
-  return o == 0;
-}
-__device__ __forceinline__ f29 tab_x(const tab_entry& p) { f29 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) r.v[k] = p.w[k];
-  return r; }
-__device__ __forceinline__ f29 tab_y(const tab_entry& p) { f29 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) r.v[k] = p.w[9 + k];
-  return r; }
-__global__ void __launch_bounds__(256) k_msm_table_unpack(const uint8_t* table64, uint8_t* table72, size_t count) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const affine p = affine_load(table64 + i * 64);
-  const f29 x = f29_unpack(p.x.v), y = f29_unpack(p.y.v);
-  uint32_t* o = reinterpret_cast<uint32_t*>(table72 + i * 72);
-#pragma unroll
-  for (int k = 0; k < 9; k++) { o[k] = x.v[k]; o[9 + k] = y.v[k]; }
-}
-#else
+// what the accumulation gathers per entry: the 64-byte table entry (two canonical 8-word values, unpacked to 9 limbs each after
+// the load).  A 72-byte pre-unpacked entry (~36 fewer instructions per addition of ~2320, 12 % more gathered bytes) was built and
+// measured in round 4 (commit 51bbdca, profiles/r04_accum_ab.txt): replay step +1 .. 2 %, not kept.
 typedef affine tab_entry;
 __device__ __forceinline__ tab_entry tab_load(const uint8_t* table, uint32_t i) { return affine_load(table + (size_t)i * 64); }
 __device__ __forceinline__ bool tab_is_identity(const tab_entry& p) { return affine_is_identity(p); }
 __device__ __forceinline__ f29 tab_x(const tab_entry& p) { return f29_unpack(p.x.v); }
 __device__ __forceinline__ f29 tab_y(const tab_entry& p) { return f29_unpack(p.y.v); }
-#endif
 
 // level 0: the bucket-ordered entry array is cut into chunks of exactly s0 entries (any value), one thread per
 // chunk, regardless of bucket boundaries: every lane of a wavefront performs the same number of additions
@@ -1339,7 +1303,6 @@ static uint32_t chunk_override() {
 
 static void free_bases(Bases* B) {
   H2_IGNORE(hipFree(B->table));
-  H2_IGNORE(hipFree(B->table72));
   H2_IGNORE(hipFree(B->stable));
   H2_IGNORE(hipFree(B->host_stage));
   for (Slot& S : B->slot) {
@@ -1498,13 +1461,6 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     }
     B->has_sum = true;
   }
-#ifdef H2MI_TABLE72
-  {
-    if (hipMalloc((void**)&B->table72, nW * 72) != hipSuccess) { H2_IGNORE(hipDeviceSynchronize()); g_bases.erase(h); free_bases(B); return H2MI_ENOMEM; }
-    hipLaunchKernelGGL(k_msm_table_unpack, dim3(ceil_div_u32(nW, 256)), dim3(256), 0, s, (const uint8_t*)B->table, B->table72, nW);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { g_bases.erase(h); free_bases(B); return H2MI_EHIP; }
-  }
-#endif
   *handle_out = h;
   return H2MI_OK;
 }
@@ -1688,7 +1644,7 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
-            (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)(B->table72 ? B->table72 : B->table), S.part[0]);
+            (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;
   S.tasks1 = tasks0 / S1 + nb;
   if (pipelined) {
