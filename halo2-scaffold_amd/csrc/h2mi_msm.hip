@@ -765,6 +765,7 @@ struct TailDesc {
   uint8_t *dense2, *vsum;
   uint32_t seg_log;
   uint32_t hot_min;  // a bucket with more partials than this is finished by a whole workgroup (k_msm_finish_hot)
+  uint32_t no_fold;  // the finish kernels read the accumulation's partials directly (part1 / toff1 / np1 alias part0 / toff0 / np0)
 };
 struct TailBatch {
   TailDesc d[TAIL_BATCH];
@@ -781,7 +782,7 @@ constexpr uint32_t TAIL_THREADS = 512;  // rowcol / weighted: 128 quads reduce u
 template <bool QUAD>
 __global__ void __launch_bounds__(256) k_msm_fold(const TailBatch tb) {
   const TailDesc& d = tb.d[blockIdx.y];
-  if (d.seg_log) return;  // wide windows skip the fold level (tail_desc)
+  if (d.no_fold) return;  // wide windows and mid-size base sets skip the fold level (tail_desc)
   const uint32_t nb = d.nb;
   const uint32_t *toff_out = d.toff1, *toff_in = d.toff0, *np_in = d.np0;
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
@@ -1740,9 +1741,9 @@ static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1
                         uint32_t max_seg, hipStream_t t) {
   // fold / finish: quads (4 lanes per point operation) while the grid stays latency-bound, single lanes beyond
   const bool force_lane = ab_env("H2MI_MSM_TAIL_LANES") != nullptr;  // A/B
-  bool all_wide = max_seg != 0;
-  for (uint32_t j = 0; j < count; j++) all_wide = all_wide && tb.d[j].seg_log != 0;
-  if (all_wide) {
+  bool none_folds = true;
+  for (uint32_t j = 0; j < count; j++) none_folds = none_folds && tb.d[j].no_fold != 0;
+  if (none_folds) {
     // no fold level at all
   } else if (!force_lane && (uint64_t)max_tasks1 * count <= 65536) {
     H2_LAUNCH("k_msm_fold", k_msm_fold<true>, dim3(ceil_div_u32((uint64_t)max_tasks1 * 4, 256), count), 256, 0, t, tb);
@@ -1773,11 +1774,11 @@ static TailDesc tail_desc(const Bases* B, const Slot& S) {
   d.nb = B->nb; d.logNh = B->logNh; d.logNl = B->logNl; d.canonical = g_canonical ? 1u : 0u;
   d.seg_log = B->seg_log; d.dense2 = S.dense2; d.vsum = S.vsum; d.mat = B->seg_log ? S.dense2 : S.dense;
   d.hot_min = B->seg_log ? HOT_MIN_WIDE : HOT_MIN;
-  if (B->seg_log) {
-    // 2^17 .. 2^19 buckets hold a partial or two each: the fold level would copy them (0.08 - 0.18 ms per MSM, measured);
-    // the finish kernels read the accumulation's partials directly
-    d.part1 = S.part[0]; d.toff1 = S.toff[0]; d.np1 = S.np[0];
-  }
+  // wide windows: 2^17 .. 2^19 buckets hold a partial or two each, the fold level would copy them (0.08 - 0.18 ms per MSM, measured);
+  // the finish kernels read the accumulation's partials directly.  (Round 4 tried the same for up to 2^14 / 2^15 buckets, where the
+  // chain is what a join waits for: a lone 2^16 MSM gains ~10 us, a phase of four loses 4 - 7 %: profiles/r04_msm_mid_sweep.txt.)
+  d.no_fold = B->seg_log ? 1u : 0u;
+  if (d.no_fold) { d.part1 = S.part[0]; d.toff1 = S.toff[0]; d.np1 = S.np[0]; }
   return d;
 }
 
