@@ -7,6 +7,7 @@
 // Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]   (poseidon hashes x and x + 1:
 //        examples/poseidon.rs `hash_two`)
 //        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <string>
@@ -72,7 +73,7 @@ int main(int argc, char** argv) {
       proof = transcript.finalize();
     }
     if (const char* np = std::getenv("H2MI_PROOFS")) {  // steady state: N more proofs through the same workspace (bench.py reads the line)
-      const int count = std::atoi(np);
+      const int count = std::max(1, std::atoi(np));  // 0 or a non-number: one proof, never a division by zero
       check(h2mi_sync(), "sync");
       const auto t0 = Clock::now();
       for (int i = 0; i < count; i++) {

@@ -8,6 +8,7 @@
 //
 // Usage: standard_plonk [k [srs_secret_hex [witness_hex [seed]]]]     (the reference hard-codes k = 5 and draws the rest
 //        from OsRng; here they are arguments so that runs are comparable)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <string>
@@ -70,7 +71,7 @@ int main(int argc, char** argv) {
       proof = transcript.finalize();
     }
     if (const char* np = std::getenv("H2MI_PROOFS")) {  // steady state: N more proofs through the same workspace (bench.py reads the line)
-      const int count = std::atoi(np);
+      const int count = std::max(1, std::atoi(np));  // 0 or a non-number: one proof, never a division by zero
       check(h2mi_sync(), "sync");
       const auto t0 = Clock::now();
       for (int i = 0; i < count; i++) {

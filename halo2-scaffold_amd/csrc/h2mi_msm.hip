@@ -1278,6 +1278,7 @@ static bool small_geometry(size_t n, uint32_t* c, uint32_t* lanes, uint32_t* r) 
   if (const char* ev = ab_env("H2MI_MSM_SMALL_MAX_LOG"))
     max_n = std::min<size_t>(SMALL_MAX_N, (size_t)1 << std::max(0, atoi(ev)));
   if (n > max_n) return false;
+  if (getenv("H2MI_MSM_C")) return false;  // a forced window width means the general pipeline with that width (forced-path parity tests)
   uint32_t cc = SMALL_C_MAX;
   while (cc > 2 && ((size_t)1 << (cc - 1)) * ((255 + cc - 1) / cc) * n * 64 > SMALL_TABLE_BUDGET) cc--;
   if (const char* ev = ab_env("H2MI_MSM_SMALL_C"))

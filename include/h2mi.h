@@ -77,8 +77,10 @@ int h2mi_sync(void); /* wait for all work queued on the library's streams */
  * An MSM queued on the library's stream (h2mi_msm_bn254_g1_dev with stream = NULL) only runs its bucket
  * partition and accumulation at once; the latency-bound bucket reduction is deferred and run for all MSMs
  * queued since the last join as one batch, so the 96-byte results are written only by h2mi_join / h2mi_sync /
- * h2mi_memcpy_d2h (or when eight reductions are pending).  A prover calls h2mi_join where the transcript
- * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream. */
+ * h2mi_memcpy_d2h / h2mi_msm_flush — or when half of a handle's workspace slots are pending: two MSMs for base sets
+ * above 2^17 points (four slots), four below (eight slots).  A prover calls h2mi_join where the transcript
+ * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream.
+ * Base sets of at most 2^14 points defer their whole accumulate-and-finish launch the same way (h2mi_dbg_msm_small_path). */
 int h2mi_join(void);
 /* start the deferred bucket reductions of the MSMs queued so far NOW, on the library's reduction stream, without ordering
  * the library's stream behind them (h2mi_join still does that, later): a prover that has queued the commitments of a phase
@@ -191,7 +193,10 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
  * d_out[j] = sum_i weights[i] * (a / (X - roots[i]))[j] for j < n - 1, with weights[i] = 1 / prod_{k != i} (roots[i] - roots[k])
  * computed by the caller (partial fractions; the m quotients are independent, the chain of m dependent divisions is not).
  * roots, roots_inv, weights: m x 4 limbs, Montgomery.  d_out[n - 1] is left untouched; the top m - 1 written coefficients
- * come out as exact zeros. */
+ * come out as exact zeros.
+ * Footprint: the m quotients are materialised side by side in the calling stream's scratch vector before they are summed —
+ * m x (n + n / 512 + 1024) field elements (m = 4, n = 2^22: 0.5 GB; n = 2^25: 4 GB), one such scratch per stream that
+ * issues divisions (SHPLONK's three lanes).  The scratch is grow-only; its first growth synchronises the device. */
 int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t* roots, const uint64_t* roots_inv, const uint64_t* weights,
                                     size_t m, void* d_out, h2mi_stream_t stream);
 /* out[i] = sum_k scalars[k] * polys[k][i], count <= 24 (the challenge-weighted sums of SHPLONK) */

@@ -1036,9 +1036,9 @@ def test_eip196_vectors_hip_path(gpu):
         assert o.unpack_jacobian(got) == pt(v["product"]), v["name"]
 
 
-@pytest.mark.parametrize("c", [19, 20])
+@pytest.mark.parametrize("c", [18, 19, 20])
 def test_msm_wide_windows_forced_at_small_sizes(gpu, c):
-    """the wide-window path (c = 19 / 20: 16-bit in-bin keys, low-bit binning, k_msm_bin_sort_wide, segmented task scans,
+    """the wide-window path (c = 18 .. 20 — 18 is never a default (2-bit top window) but H2MI_MSM_C accepts it: 16-bit in-bin keys, low-bit binning, k_msm_bin_sort_wide, segmented task scans,
     k_msm_seg's segment pre-reduction, the subtraction in k_msm_final) is the default only from 2^22 points (where the
     DEGREE 22 golden proof and the 2^24 linearity test exercise it).  Forced by H2MI_MSM_C in a child process, the same MSM
     edge-case, hot-bucket and randomised-size tests run through it at sizes that take seconds, plus the golden 2^16-row

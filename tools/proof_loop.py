@@ -43,10 +43,21 @@ h2._lib.check(lib.h2mi_sync(), "sync")
 lib.h2mi_profile_reset()
 lib.h2mi_profile_filter(b"")
 times = []
+prof = None
+if os.environ.get("PROOF_LOOP_CPROFILE"):  # where the HOST spends a proof (Python host only): top functions by own time
+    import cProfile
+
+    prof = cProfile.Profile()
+    prof.enable()
 for i in range(proofs):
     t0 = time.perf_counter()
     run(3 + i)
     times.append(time.perf_counter() - t0)
+if prof is not None:
+    import pstats
+
+    prof.disable()
+    pstats.Stats(prof).sort_stats("tottime").print_stats(22)
 h2._lib.check(lib.h2mi_sync(), "sync")
 # launches of one proof, counted by an extra (untimed, event-bracketed) proof at the very end: the trace's last
 # `launches` kernel dispatches belong to it, the `launches` before them to the last timed proof
