@@ -94,6 +94,7 @@ def _load():
         "h2mi_plonk_instance_coset_dev": ([vp, C.c_uint32, C.c_uint32, vp, sz, vp, vp], C.c_int),
         "h2mi_plonk_lookup_product_dev": ([vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_evaluate_h_range_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+        "h2mi_plonk_evaluate_h_flex_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_g1_fixed_base_mul_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_fr_powers_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_profile_enable": ([C.c_int], C.c_int),

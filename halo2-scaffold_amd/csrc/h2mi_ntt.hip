@@ -1123,6 +1123,96 @@ __global__ void __launch_bounds__(256, 4) k_evaluate_h_range_occ4(RangeCosets c,
 }
 #endif
 
+// ---- quotient numerator, GENERAL form (round 4): what halo2-base configures when a circuit overflows one advice column --------
+// `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268) then takes num_advice > 1 gate columns — each with its own
+// vertical gate q_j (a_j + a_j(wX) a_j(w^2 X) - a_j(w^3 X)) — and, for the Range builder, num_lookup_advice lookup-advice
+// columns with one lookup argument each [halo2-base shapes restated from memory].  The specialised kernels above track a stray
+// 2^-5 per multiplication as "levels" so that operands can stay in the memory format; this one does not bother: every operand is
+// brought to the multiplier's radix when it is loaded (one multiplication more per load), all arithmetic is in ONE domain, and h is
+// Horner's rule in y over the terms in evaluate_h's order (gates, permutation, lookups) exactly as the oracle writes them
+// (oracle/flex.py prove: _permutation_terms, _lookup_terms).  About half the speed of k_evaluate_h_range per point — a multi-column
+// circuit is a small one by construction — and, being independent of the level bookkeeping, a cross-check of it: with one gate and
+// the selector form of the lookup input both kernels must produce the same h (tests/test_gpu_flex.py).
+struct FlexCosets {
+  uint32_t n_gates, n_perm, chunk, n_lookups;
+  const fe* gate_a[4];
+  const fe* gate_q[4];
+  const fe* perm_value[8];
+  const fe* perm_sigma[8];
+  const fe* perm_z[8];
+  const fe* lk_in[2];
+  const fe* lk_in_b[2];  // optional second factor of the input expression (selector * advice)
+  const fe* lk_table[2];
+  const fe* lk_pin[2];
+  const fe* lk_ptab[2];
+  const fe* lk_z[2];
+  const fe* l0;
+  const fe* l_last;
+  const fe* l_active;
+};
+struct FlexConsts {
+  fe beta, gamma, y, delta, zeta;  // Montgomery-2^256 words
+  fe tinv[16];
+};
+__global__ void __launch_bounds__(256) k_evaluate_h_flex(FlexCosets c, uint32_t ext_k, uint32_t k, uint32_t last_rot, FlexConsts h, const fe* xlo,
+                                                          const fe* xhi, uint32_t xh, fe* out) {
+  const uint32_t size = 1u << ext_k, rot = 1u << (ext_k - k);
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= size) return;
+  auto at = [&](int r) { return (idx + size + (uint32_t)(r * (int)rot)) & (size - 1); };
+  const uint32_t r_next = at(1), r_prev = at(-1), r_last = at(-(int)last_rot);
+  // one domain (Montgomery-2^261), every value normalized and below ~8 p between operations
+  auto ld = [](const fe* p) { return f29_from_mont256<F9>(fe_load(p).v); };
+  auto cst = [](const fe& v) { return f29_from_mont256<F9>(v.v); };
+  auto mul = [](const f29& a, const f29& b) { return f29_mul<F9>(a, b); };                            // b normalized (every value here is)
+  auto add = [](const f29& a, const f29& b) { return f29_normalize(f29_add(a, b)); };
+  auto sub = [](const f29& a, const f29& b) { return f29_normalize(f29_sub(a, b, F9::K4)); };           // b < 4p - 2^232
+  auto red = [](const f29& a) { return f29_mul<F9>(a, f29_const<F9>(F9::ONE)); };                       // back below 1.1 p (ONE = 2^261 mod p)
+  const f29 one = f29_const<F9>(F9::ONE), beta = cst(h.beta), gamma = cst(h.gamma), y = cst(h.y), delta = cst(h.delta);
+  f29 acc = f29_zero();
+  auto horner = [&](const f29& term) { acc = add(mul(acc, y), term); };
+  for (uint32_t g = 0; g < c.n_gates; g++) {
+    const fe* a = c.gate_a[g];
+    horner(mul(sub(add(ld(&a[idx]), mul(ld(&a[at(1)]), ld(&a[at(2)]))), ld(&a[at(3)])), ld(&c.gate_q[g][idx])));
+  }
+  const f29 l0 = ld(&c.l0[idx]), ll = ld(&c.l_last[idx]), lact = ld(&c.l_active[idx]);
+  if (c.n_perm) {
+    const uint32_t sets = (c.n_perm + c.chunk - 1) / c.chunk;
+    const f29 z_first = ld(&c.perm_z[0][idx]), z_lastset = ld(&c.perm_z[sets - 1][idx]);
+    horner(mul(sub(one, z_first), l0));
+    horner(mul(red(sub(mul(z_lastset, z_lastset), z_lastset)), ll));
+    for (uint32_t s = 1; s < sets; s++) horner(mul(sub(ld(&c.perm_z[s][idx]), ld(&c.perm_z[s - 1][r_last])), l0));
+    f29 cur = mul(mul(pow2tab(xlo, xhi, xh, idx), cst(h.zeta)), beta);  // beta * X, X = zeta * extended_omega^idx
+    for (uint32_t s = 0; s < sets; s++) {
+      f29 left = ld(&c.perm_z[s][r_next]), right = ld(&c.perm_z[s][idx]);
+      const uint32_t j0 = c.chunk * s, j1 = min(c.n_perm, c.chunk * (s + 1));
+      for (uint32_t j = j0; j < j1; j++) {
+        const f29 val = ld(&c.perm_value[j][idx]);
+        left = mul(left, add(add(val, mul(beta, ld(&c.perm_sigma[j][idx]))), gamma));
+        right = mul(right, add(add(val, cur), gamma));
+        cur = mul(cur, delta);
+      }
+      horner(mul(sub(left, right), lact));
+    }
+  }
+  for (uint32_t l = 0; l < c.n_lookups; l++) {
+    f29 a_in = ld(&c.lk_in[l][idx]);
+    if (c.lk_in_b[l]) a_in = mul(a_in, ld(&c.lk_in_b[l][idx]));
+    const f29 t_in = ld(&c.lk_table[l][idx]), ap = ld(&c.lk_pin[l][idx]), ap_prev = ld(&c.lk_pin[l][r_prev]), sp = ld(&c.lk_ptab[l][idx]);
+    const f29 lz = ld(&c.lk_z[l][idx]), lz_next = ld(&c.lk_z[l][r_next]);
+    horner(mul(sub(one, lz), l0));
+    horner(mul(red(sub(mul(lz, lz), lz)), ll));
+    const f29 lhs = mul(mul(lz_next, add(ap, beta)), add(sp, gamma)), rhs = mul(mul(lz, add(a_in, beta)), add(t_in, gamma));
+    horner(mul(sub(lhs, rhs), lact));
+    const f29 d = sub(ap, sp);
+    horner(mul(d, l0));
+    horner(mul(red(mul(d, sub(ap, ap_prev))), lact));
+  }
+  fe o;
+  f29_to_mont256<F9>(mul(acc, cst(h.tinv[idx & (rot - 1)])), o.v);
+  fe_store(&out[idx], o);
+}
+
 // the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
 // as a Montgomery-2^256 value is (32 x) 2^256; its inverse (x^-1 / 32) 2^256 times 2^10 is x^-1 2^261.
 __global__ void k_fr_inv_one(const fe* in, fe* out) {
@@ -2188,6 +2278,53 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* c, uint32_t k, uint
 #endif
   H2_LAUNCH("k_evaluate_h_range", k_evaluate_h_range, ceil_div_u32(size, 256), 256, 0, s, rc_, extended_k, k, blinding_factors + 1, hcst,
             (const fe*)px.lo, (const fe*)px.hi, px.h, (fe*)d_h_out);
+  return H2MI_OK;
+}
+
+int h2mi_plonk_evaluate_h_flex_dev(const h2mi_flex_cosets* c, uint32_t k, uint32_t extended_k, uint32_t blinding_factors, const uint64_t beta[4],
+                                   const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4], const uint64_t zeta[4],
+                                   const uint64_t extended_omega[4], const uint64_t* t_inv, void* d_h_out, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
+  if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
+  if (c->n_gates == 0 || c->n_gates > 4 || c->n_perm > 8 || c->n_lookups > 2) return H2MI_EINVAL;
+  if (c->n_perm && (c->chunk_len == 0 || c->chunk_len > 3)) return H2MI_EINVAL;
+  FlexCosets fc;
+  memset(&fc, 0, sizeof(fc));
+  fc.n_gates = c->n_gates; fc.n_perm = c->n_perm; fc.chunk = c->chunk_len ? c->chunk_len : 1; fc.n_lookups = c->n_lookups;
+  for (uint32_t g = 0; g < c->n_gates; g++) {
+    fc.gate_a[g] = (const fe*)c->gate_a[g]; fc.gate_q[g] = (const fe*)c->gate_q[g];
+    if (!fc.gate_a[g] || !fc.gate_q[g]) return H2MI_EINVAL;
+  }
+  for (uint32_t j = 0; j < c->n_perm; j++) {
+    fc.perm_value[j] = (const fe*)c->perm_value[j]; fc.perm_sigma[j] = (const fe*)c->perm_sigma[j];
+    if (!fc.perm_value[j] || !fc.perm_sigma[j]) return H2MI_EINVAL;
+  }
+  for (uint32_t q = 0; c->n_perm && q < (c->n_perm + fc.chunk - 1) / fc.chunk; q++) {
+    fc.perm_z[q] = (const fe*)c->perm_z[q];
+    if (!fc.perm_z[q]) return H2MI_EINVAL;
+  }
+  for (uint32_t l = 0; l < c->n_lookups; l++) {
+    fc.lk_in[l] = (const fe*)c->lookup_input[l]; fc.lk_in_b[l] = (const fe*)c->lookup_input_b[l]; fc.lk_table[l] = (const fe*)c->lookup_table[l];
+    fc.lk_pin[l] = (const fe*)c->lookup_permuted_input[l]; fc.lk_ptab[l] = (const fe*)c->lookup_permuted_table[l]; fc.lk_z[l] = (const fe*)c->lookup_z[l];
+    if (!fc.lk_in[l] || !fc.lk_table[l] || !fc.lk_pin[l] || !fc.lk_ptab[l] || !fc.lk_z[l]) return H2MI_EINVAL;
+  }
+  fc.l0 = (const fe*)c->l0; fc.l_last = (const fe*)c->l_last; fc.l_active = (const fe*)c->l_active;
+  if (!fc.l0 || !fc.l_last || !fc.l_active) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  PowTab px;
+  int rc = get_powtab(extended_omega, extended_k, s, &px);
+  if (rc) return rc;
+  const uint32_t rot = 1u << (extended_k - k);
+  FlexConsts hc_;
+  memset(&hc_, 0, sizeof(hc_));
+  hc_.beta = host_fe(beta); hc_.gamma = host_fe(gamma); hc_.y = host_fe(y); hc_.delta = host_fe(delta); hc_.zeta = host_fe(zeta);
+  for (uint32_t i = 0; i < rot; i++) hc_.tinv[i] = host_fe(t_inv + 4 * i);
+  const uint32_t size = 1u << extended_k;
+  H2_LAUNCH("k_evaluate_h_flex", k_evaluate_h_flex, ceil_div_u32(size, 256), 256, 0, s, fc, extended_k, k, blinding_factors + 1, hc_, (const fe*)px.lo,
+            (const fe*)px.hi, px.h, (fe*)d_h_out);
   return H2MI_OK;
 }
 

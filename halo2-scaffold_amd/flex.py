@@ -52,8 +52,14 @@ class FlexGateCS:
       Range: fixed 0 table, 1 constants, 2 q_lookup, 3 q_enable     degree 2 + 2 + 1 = 5: sets of three, 4 h pieces
     Queries in creation order (enable_equality queries its column at Rotation::cur)."""
 
-    def __init__(self, lookup: bool):
+    def __init__(self, lookup: bool, num_advice: int = 1, num_lookup_advice: int = 0, k: int = None, minimum_rows: int = 9):
         self.lookup = lookup
+        self.num_advice, self.num_lookup_advice = num_advice, num_lookup_advice
+        self.k, self.minimum_rows = k, minimum_rows  # the multi-column layout needs the row budget 2^k - minimum_rows
+        if num_advice > 1:
+            self._init_multi()
+            return
+        assert num_lookup_advice == 0
         self.n_advice = 1
         if lookup:
             self.col_table, self.col_const, self.col_qlookup, self.col_q = 0, 1, 2, 3
@@ -64,11 +70,51 @@ class FlexGateCS:
             self.col_const, self.col_q = 0, 1
             self.n_fixed = 2
             self.fixed_queries = [(0, 0), (1, 0)]
+        self.col_qs = [self.col_q]
         self.perm_columns = [(FIXED, self.col_const), (ADVICE, 0), (INSTANCE, 0)]
         self.advice_queries = [(0, 0), (0, 1), (0, 2), (0, 3)]
         self.degree = 5 if lookup else 3          # the lookup of a degree-2 input is what raises it
         self.blinding_factors = 6                 # max(3, four queries on the gate column) + 2
         self.chunk = self.degree - 2
+
+    def _init_multi(self):
+        """more than one gate column (round 4): what `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268) configures when
+        the cells overflow 2^k - minimum_rows rows [RECALL halo2-base 0.3]: FlexGateConfig allocates the constants column, then
+        per gate column an advice column (equality-enabled) with its own simple selector and vertical gate; RangeConfig takes the
+        table column first and — there being more than one gate column — no q_lookup but num_lookup_advice lookup-advice columns
+        (advice, equality-enabled, after the gate columns), one lookup argument each with the column itself as input: degree
+        2 + 1 + 1 = 4, permutation sets of two, three h pieces; keygen appends one fixed column per selector (gates of different
+        columns share rows: compress_selectors cannot merge them); the scaffold adds the instance column last."""
+        A, Lc = self.num_advice, self.num_lookup_advice
+        assert 2 <= A <= 4 and Lc <= 2, "the device quotient kernel takes up to four gate columns and two lookup-advice columns"
+        assert (Lc >= 1) == bool(self.lookup), "the Range builder needs a lookup-advice column, the Gate builder has none"
+        assert self.k is not None, "the multi-column layout needs k (rows per column = 2^k - minimum_rows)"
+        self.n_advice = A + Lc
+        self.col_table, self.col_const = (0, 1) if self.lookup else (None, 0)
+        self.col_qlookup = None
+        self.col_qs = [self.col_const + 1 + j for j in range(A)]
+        self.col_q = None
+        self.n_fixed = self.col_const + 1 + A
+        self.fixed_queries = [(self.col_const, 0)] + ([(self.col_table, 0)] if self.lookup else []) + [(c, 0) for c in self.col_qs]
+        self.perm_columns = [(FIXED, self.col_const)] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
+        self.advice_queries = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
+        self.degree = 4 if self.lookup else 3
+        self.blinding_factors = 6
+        self.chunk = self.degree - 2
+
+
+def configure(lookup: bool, k: int, closure, minimum_rows: int = 9) -> FlexGateCS:
+    """GateThreadBuilder::config (src/scaffold.rs:268 `builder.config(k, Some(minimum_rows))`): run the closure once to count its
+    cells and cells to look up, and take ceil(count / (2^k - minimum_rows)) columns of each kind.  `closure(cs) -> Assignment`."""
+    probe = FlexGateCS(lookup)
+    asg = closure(probe)
+    max_rows = (1 << k) - minimum_rows
+    cells = len(asg.advice[0])
+    num_advice = max(1, -(-cells // max_rows))
+    if num_advice == 1:
+        return FlexGateCS(lookup, k=k, minimum_rows=minimum_rows)
+    looked_up = len(asg.fixed[probe.col_qlookup]) if lookup else 0
+    return FlexGateCS(lookup, num_advice, max(1, -(-looked_up // max_rows)) if lookup else 0, k=k, minimum_rows=minimum_rows)
 
 
 class Assignment:
@@ -88,6 +134,7 @@ class Context:
     def __init__(self, asg: Assignment):
         self.asg = asg
         self.cells, self.const_cells, self.lookup_cells = [], [], []
+        self.gates, self.eqs = [], []  # rows (flat cell indices) with the gate enabled; (new cell, source cell) equalities in call order
 
     def load_witness(self, v: int) -> int:
         self.cells.append(v % R)
@@ -99,13 +146,13 @@ class Context:
             row = len(self.cells)
             if kind == "existing":
                 self.cells.append(self.cells[v])
-                self.asg.copies.append(((ADVICE, 0, row), (ADVICE, 0, v)))
+                self.eqs.append((row, v))
             else:
                 self.cells.append(v % R)
                 if kind == "constant":
                     self.const_cells.append((row, v % R))
         for off in gate_offsets:
-            self.asg.fixed[self.asg.cs.col_q][base + off] = 1
+            self.gates.append(base + off)
         return len(self.cells) - 1
 
     # GateInstructions
@@ -137,9 +184,9 @@ class Context:
             self.cells.append((1 << (lookup_bits * i)) % R)
             self.const_cells.append((len(self.cells) - 1, (1 << (lookup_bits * i)) % R))
             self.cells.append(acc % R)
-            self.asg.fixed[self.asg.cs.col_q][base] = 1
+            self.gates.append(base)
             acc_row = len(self.cells) - 1
-        self.asg.copies.append(((ADVICE, 0, a), (ADVICE, 0, acc_row)))  # ctx.constrain_equal(&a, &acc)
+        self.eqs.append((a, acc_row))  # ctx.constrain_equal(&a, &acc)
         self.lookup_cells += rows
         rem = range_bits % lookup_bits
         if rem == 1:  # the top limb is one bit: assert_bit, 0 + x * x - x = 0 on [0, x, x, x]
@@ -151,7 +198,12 @@ class Context:
     def finish(self, public_rows):
         asg = self.asg
         cs = asg.cs
+        if cs.num_advice > 1:
+            return self._finish_multi(public_rows)
         asg.advice[0] = dict(enumerate(self.cells))
+        for g in self.gates:
+            asg.fixed[cs.col_q][g] = 1
+        asg.copies += [((ADVICE, 0, new), (ADVICE, 0, src)) for new, src in self.eqs]
         consts = {}
         for row, v in self.const_cells:  # assign_constants: one fixed cell per distinct value, in order of first use
             if v not in consts:
@@ -163,6 +215,53 @@ class Context:
         for i, row in enumerate(public_rows):  # layouter.constrain_instance(cell, instance, i): src/scaffold.rs:411, 480
             asg.instance.append(self.cells[row])
             asg.copies.append(((ADVICE, 0, row), (INSTANCE, 0, i)))
+
+    def _finish_multi(self, public_rows):
+        """assign_all over several gate columns [RECALL halo2-base 0.3 gates/builder.rs]: the cells run down the current column; a
+        cell that lands on the column's last row (row >= max_rows - 1), or that starts a gate which no longer fits (row + 4 >
+        max_rows), is assigned a second time at row 0 of the next column and tied to its first copy — two gates may overlap at it —
+        and a gate starting there is enabled on the new column.  The cells to look up are copied into the lookup-advice columns.
+        constrain_equal order: break copies as they occur, lookup copies, the closure's equalities, constants, public cells."""
+        asg = self.asg
+        cs = asg.cs
+        A, Lc = cs.num_advice, cs.num_lookup_advice
+        max_rows = (1 << cs.k) - cs.minimum_rows
+        gate_at = set(self.gates)
+        where = []  # flat cell index -> (column, row) of its first copy
+        col, row = 0, 0
+        for i, v in enumerate(self.cells):
+            asg.advice[col][row] = v
+            where.append((col, row))
+            q = i in gate_at
+            if (q and row + 4 > max_rows) or row >= max_rows - 1:
+                if col + 1 >= A:
+                    raise ValueError(f"NOT ENOUGH ADVICE COLUMNS: more than {A} gate columns needed at 2^{cs.k} rows")
+                asg.copies.append(((ADVICE, col + 1, 0), (ADVICE, col, row)))
+                col, row = col + 1, 0
+                asg.advice[col][0] = v
+            if q:
+                asg.fixed[cs.col_qs[col]][row] = 1
+            row += 1
+        cell = lambda i: (ADVICE,) + where[i]
+        lcol, lrow = 0, 0
+        for i in self.lookup_cells:
+            if lrow >= max_rows:
+                lcol, lrow = lcol + 1, 0
+            if lcol >= Lc:
+                raise ValueError("NOT ENOUGH LOOKUP ADVICE COLUMNS")
+            asg.advice[A + lcol][lrow] = self.cells[i]
+            asg.copies.append((cell(i), (ADVICE, A + lcol, lrow)))
+            lrow += 1
+        asg.copies += [(cell(new), cell(src)) for new, src in self.eqs]
+        consts = {}
+        for r, v in self.const_cells:
+            if v not in consts:
+                consts[v] = len(consts)
+                asg.fixed[cs.col_const][consts[v]] = v
+            asg.copies.append((cell(r), (FIXED, cs.col_const, consts[v])))
+        for i, r in enumerate(public_rows):
+            asg.instance.append(self.cells[r])
+            asg.copies.append((cell(r), (INSTANCE, 0, i)))
 
 
 def halo2_lib_closure(cs: FlexGateCS, x: int) -> Assignment:
@@ -197,10 +296,11 @@ def mock(asg: Assignment) -> None:
     host: every enabled row satisfies the vertical gate, every copy constraint joins equal cells, every looked-up cell is
     a table value.  Raises ValueError naming the first violation — what the reference's users run before `prove`."""
     cs = asg.cs
-    a = asg.advice[0]
-    for r in sorted(asg.fixed[cs.col_q]):
-        if (a.get(r, 0) + a.get(r + 1, 0) * a.get(r + 2, 0) - a.get(r + 3, 0)) % R:
-            raise ValueError(f"gate not satisfied at row {r}")
+    for j, cq in enumerate(cs.col_qs):  # gate column j with its own selector
+        a = asg.advice[j]
+        for r in sorted(asg.fixed[cq]):
+            if (a.get(r, 0) + a.get(r + 1, 0) * a.get(r + 2, 0) - a.get(r + 3, 0)) % R:
+                raise ValueError(f"gate not satisfied at row {r}" + (f" of column {j}" if len(cs.col_qs) > 1 else ""))
     value = {ADVICE: lambda c, r: asg.advice[c].get(r, 0), FIXED: lambda c, r: asg.fixed[c].get(r, 0),
              INSTANCE: lambda c, r: asg.instance[r] if r < len(asg.instance) else 0}
     for left, right in asg.copies:
@@ -208,8 +308,12 @@ def mock(asg: Assignment) -> None:
             raise ValueError(f"copy constraint {left} == {right} not satisfied")
     if cs.lookup:
         table = set(v % R for v in asg.table_values) | {0}
-        for r in sorted(asg.fixed[cs.col_qlookup]):
-            if a.get(r, 0) % R not in table:
+        if cs.num_advice == 1:
+            looked_up = [(r, asg.advice[0].get(r, 0)) for r in sorted(asg.fixed[cs.col_qlookup])]
+        else:
+            looked_up = [(r, v) for l in range(cs.num_lookup_advice) for r, v in sorted(asg.advice[cs.num_advice + l].items())]
+        for r, v in looked_up:
+            if v % R not in table:
                 raise ValueError(f"lookup not satisfied at row {r}")
 
 
@@ -450,32 +554,42 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         instance_f = forms(instance, side.handle)
     _write_points(ws, transcript, len(advice))
     theta = sq()
-    # lookup: permuted input / table columns
-    lk = None
+    # lookups: permuted input / table columns.  One advice column: ONE lookup of q_lookup * a (an element-wise product; zero wherever
+    # the selector is off).  Several (round 4): one lookup per lookup-advice column, the column itself as input.
+    A = cs.num_advice
+    single = A == 1
+    lk = []  # per lookup: [input rows, A', S', product]
+    lk_f = []
     if cs.lookup:
-        # the input expression's row values: q_lookup * a (one element-wise product; zero wherever the selector is off)
-        lk_input = dev(n)
-        check(lib.h2mi_fr_mul_dev(pk.fixed_values[cs.col_qlookup].ptr, advice[0].ptr, n, lk_input.ptr, None), "lookup input")
-        a_perm, s_perm = dev(n), dev(n)
-        if gp.lookup_permute(d.k, lk_input, pk.table, a_perm, s_perm):
-            raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
-        lb = synth.uniform_fr(2 * (bf + 1), seed + 4)
-        a_perm.patch(lb[: bf + 1], offset=u * 32)
-        s_perm.patch(lb[bf + 1 :], offset=u * 32)
-        commit(a_perm, True, 0)
-        commit(s_perm, True, 1)
+        if single:
+            lk_input = dev(n)
+            check(lib.h2mi_fr_mul_dev(pk.fixed_values[cs.col_qlookup].ptr, advice[0].ptr, n, lk_input.ptr, None), "lookup input")
+            inputs = [lk_input]
+        else:
+            inputs = [advice[A + l] for l in range(cs.num_lookup_advice)]
+        lb = synth.uniform_fr(2 * (bf + 1) * len(inputs), seed + 4)
+        for l, inp in enumerate(inputs):
+            a_perm, s_perm = dev(n), dev(n)
+            if gp.lookup_permute(d.k, inp, pk.table, a_perm, s_perm):
+                raise ValueError("lookup input not in the table (ConstraintSystemFailure)")
+            o0 = 2 * (bf + 1) * l
+            a_perm.patch(lb[o0 : o0 + bf + 1], offset=u * 32)
+            s_perm.patch(lb[o0 + bf + 1 : o0 + 2 * (bf + 1)], offset=u * 32)
+            commit(a_perm, True, 2 * l)
+            commit(s_perm, True, 2 * l + 1)
+            lk.append([inp, a_perm, s_perm, None])
         check(lib.h2mi_msm_flush(), "flush")
         side.after_library()
-        lk_f = [forms(a_perm, side.handle), forms(s_perm, side.handle)]
-        _write_points(ws, transcript, 2)
-        lk = [a_perm, s_perm, None]
+        for _, a_perm, s_perm, _z in lk:
+            lk_f.append([forms(a_perm, side.handle), forms(s_perm, side.handle)])
+        _write_points(ws, transcript, 2 * len(lk))
     beta, gamma = sq(), sq()
     # vanishing argument's random polynomial: written after the grand products' commitments but dependent on nothing, so
     # its dense MSM is queued first and accumulates beside their latency-bound scans.  Result slot: after the
     # permutation sets and the lookup product, where the transcript expects it.
     random_poly = dev(n)
     check(lib.h2mi_fr_random_dev(random_poly.ptr, n, seed + 3, 0, None), "random_poly")
-    commit(random_poly, False, -(-len(cs.perm_columns) // cs.chunk) + (1 if cs.lookup else 0))
+    commit(random_poly, False, -(-len(cs.perm_columns) // cs.chunk) + len(lk))
     # permutation argument
     col_of = {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: [instance]}
     perm_values = [col_of[kind][c] for kind, c in cs.perm_columns]
@@ -495,13 +609,14 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     for z in zs:
         commit(z, True, slot)
         slot += 1
-    if cs.lookup:
+    lzb = synth.uniform_fr(bf * max(len(lk), 1), seed + 5)
+    for l, entry in enumerate(lk):
         lz = dev(n)
-        gp.lookup_product(d.k, lk_input, pk.fixed_values[cs.col_table], lk[0], lk[1], beta, gamma, u, lz)
-        lz.patch(synth.uniform_fr(bf, seed + 5), offset=(u + 1) * 32)
-        lk[2] = lz
+        gp.lookup_product(d.k, entry[0], pk.fixed_values[cs.col_table], entry[1], entry[2], beta, gamma, u, lz)
+        lz.patch(lzb[bf * l : bf * (l + 1)], offset=(u + 1) * 32)
+        entry[3] = lz
         side.after_library()
-        lk_f.append(forms(lk[2], side.handle))
+        lk_f[l].append(forms(lz, side.handle))
         commit(lz, True, slot)
         slot += 1
     slot += 1  # the random polynomial's commitment, queued before the grand products (RANDOM_SLOT)
@@ -512,11 +627,17 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     # quotient
     h = dev(ext)
     coset_of = {ADVICE: [e for _, e in advice_f], FIXED: list(pk.fixed_cosets), INSTANCE: [instance_f[1]]}
-    gp.evaluate_h_range(d, advice_f[0][1], None, pk.fixed_cosets[cs.col_q], pk.fixed_cosets[cs.col_table] if cs.lookup else None,
-                        [coset_of[kind][c] for kind, c in cs.perm_columns], list(pk.sigma_cosets), [e for _, e in z_f],
-                        lk_f[0][1] if cs.lookup else None, lk_f[1][1] if cs.lookup else None, lk_f[2][1] if cs.lookup else None,
-                        pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf,
-                        lookup_selector=pk.fixed_cosets[cs.col_qlookup] if cs.lookup else None, chunk_len=cs.chunk)
+    if single:
+        gp.evaluate_h_range(d, advice_f[0][1], None, pk.fixed_cosets[cs.col_q], pk.fixed_cosets[cs.col_table] if cs.lookup else None,
+                            [coset_of[kind][c] for kind, c in cs.perm_columns], list(pk.sigma_cosets), [e for _, e in z_f],
+                            lk_f[0][0][1] if cs.lookup else None, lk_f[0][1][1] if cs.lookup else None, lk_f[0][2][1] if cs.lookup else None,
+                            pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf,
+                            lookup_selector=pk.fixed_cosets[cs.col_qlookup] if cs.lookup else None, chunk_len=cs.chunk)
+    else:  # several gate columns: the general quotient kernel (one gate per column, one lookup per lookup-advice column)
+        gp.evaluate_h_flex(d, [(advice_f[j][1], pk.fixed_cosets[cs.col_qs[j]]) for j in range(A)],
+                           [coset_of[kind][c] for kind, c in cs.perm_columns], list(pk.sigma_cosets), [e for _, e in z_f], cs.chunk,
+                           [(advice_f[A + l][1], None, pk.fixed_cosets[cs.col_table], lk_f[l][0][1], lk_f[l][1][1], lk_f[l][2][1]) for l in range(len(lk))],
+                           pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf)
     d.extended_to_coeff_dev(h)
     pieces = d.quotient_poly_degree
     for i in range(pieces):
@@ -538,8 +659,8 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         written += [(zp, x), (zp, x_next)]
         if i + 1 < len(z_p):
             written.append((zp, x_last))
-    if cs.lookup:
-        ap, sp_, lzp = (p for p, _ in lk_f)
+    lk_p = [tuple(p for p, _ in f3) for f3 in lk_f]  # per lookup: (A' poly, S' poly, product poly)
+    for ap, sp_, lzp in lk_p:
         written += [(lzp, x), (lzp, x_next), (ap, x), (ap, x_inv), (sp_, x)]
     todo = written + [(h_poly, x)]
     evals = dev(len(todo) + 8)
@@ -547,11 +668,13 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     for pt in dict.fromkeys(p for _, p in todo):
         group = list(dict.fromkeys(id(poly) for poly, p in todo if p == pt))
         by_id = {id(poly): poly for poly, p in todo if p == pt}
-        gptrs = (C.c_void_p * len(group))(*[by_id[g].ptr for g in group])
         pt_l = _m(pt)
-        check(lib.h2mi_fr_eval_polys_dev(gptrs, len(group), n, pt_l.ctypes.data, evals.ptr + 32 * len(slot_of), None), "eval")
-        for g in group:
-            slot_of[(g, pt)] = len(slot_of)
+        for c0 in range(0, len(group), 24):  # one launch takes up to 24 polynomials (a four-column range circuit opens 32 at x)
+            part = group[c0 : c0 + 24]
+            gptrs = (C.c_void_p * len(part))(*[by_id[g].ptr for g in part])
+            check(lib.h2mi_fr_eval_polys_dev(gptrs, len(part), n, pt_l.ctypes.data, evals.ptr + 32 * len(slot_of), None), "eval")
+            for g in part:
+                slot_of[(g, pt)] = len(slot_of)
     ev = evals.to_numpy(shape=(len(todo) + 8, 4))
     value = {key: F.fr_from_mont_limbs(ev[i]) for key, i in slot_of.items()}
     for poly, pt in written:
@@ -565,7 +688,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         q(zp, x_next)
     for zp in reversed(z_p[:-1]):
         q(zp, x_last)
-    if cs.lookup:
+    for ap, sp_, lzp in lk_p:
         q(lzp, x)
         q(ap, x)
         q(sp_, x)

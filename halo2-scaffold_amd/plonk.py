@@ -195,3 +195,41 @@ def evaluate_h_range(domain: EvaluationDomain, a: DevBuf, lookup_advice: DevBuf,
     args = [mm(beta), mm(gamma), mm(y), mm(FR_DELTA), mm(domain.g_coset), mm(domain.extended_omega)]
     _check(lib.h2mi_plonk_evaluate_h_range_dev(C.byref(cs), domain.k, domain.extended_k, blinding_factors, *[x.ctypes.data for x in args],
                                                t_inv.ctypes.data, out.ptr, None), "evaluate_h_range")
+
+
+class _FlexCosets(C.Structure):
+    """include/h2mi.h h2mi_flex_cosets"""
+    _fields_ = [("n_gates", C.c_uint32), ("gate_a", C.c_void_p * 4), ("gate_q", C.c_void_p * 4), ("n_perm", C.c_uint32), ("chunk_len", C.c_uint32),
+                ("perm_value", C.c_void_p * 8), ("perm_sigma", C.c_void_p * 8), ("perm_z", C.c_void_p * 8), ("n_lookups", C.c_uint32),
+                ("lookup_input", C.c_void_p * 2), ("lookup_input_b", C.c_void_p * 2), ("lookup_table", C.c_void_p * 2),
+                ("lookup_permuted_input", C.c_void_p * 2), ("lookup_permuted_table", C.c_void_p * 2), ("lookup_z", C.c_void_p * 2),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p)]
+
+
+def evaluate_h_flex(domain: EvaluationDomain, gates, perm_values, perm_sigmas, perm_zs, chunk_len: int, lookups, l0: DevBuf, l_last: DevBuf,
+                    l_active: DevBuf, beta: int, gamma: int, y: int, out: DevBuf, blinding_factors: int = BLINDING_FACTORS) -> None:
+    """h(X) on the extended coset for the GENERAL halo2-base shapes (h2mi_plonk_evaluate_h_flex_dev): `gates` = [(advice coset, selector
+    coset)] (<= 4 vertical gates), the permutation argument over <= 8 columns, `lookups` = [(input coset, second input factor or None,
+    table coset, permuted input, permuted table, product)] (<= 2) — what builder.config() configures when one column overflows."""
+    m = len(perm_values)
+    assert 1 <= len(gates) <= 4 and m <= 8 and len(perm_sigmas) == m and len(perm_zs) == (-(-m // chunk_len) if m else 0) and len(lookups) <= 2
+    cs = _FlexCosets()
+    cs.n_gates = len(gates)
+    for g, (a, q) in enumerate(gates):
+        cs.gate_a[g], cs.gate_q[g] = a.ptr, q.ptr
+    cs.n_perm, cs.chunk_len = m, chunk_len
+    for j in range(m):
+        cs.perm_value[j], cs.perm_sigma[j] = perm_values[j].ptr, perm_sigmas[j].ptr
+    for s, z in enumerate(perm_zs):
+        cs.perm_z[s] = z.ptr
+    cs.n_lookups = len(lookups)
+    for l, (a_in, b_in, table, pin, ptab, z) in enumerate(lookups):
+        cs.lookup_input[l], cs.lookup_table[l] = a_in.ptr, table.ptr
+        cs.lookup_input_b[l] = b_in.ptr if b_in is not None else None
+        cs.lookup_permuted_input[l], cs.lookup_permuted_table[l], cs.lookup_z[l] = pin.ptr, ptab.ptr, z.ptr
+    cs.l0, cs.l_last, cs.l_active = l0.ptr, l_last.ptr, l_active.ptr
+    mm = F.fr_to_mont_limbs
+    t_inv = np.ascontiguousarray(vanishing_inverses(domain))
+    args = [mm(beta), mm(gamma), mm(y), mm(FR_DELTA), mm(domain.g_coset), mm(domain.extended_omega)]
+    _check(lib.h2mi_plonk_evaluate_h_flex_dev(C.byref(cs), domain.k, domain.extended_k, blinding_factors, *[x.ctypes.data for x in args],
+                                              t_inv.ctypes.data, out.ptr, None), "evaluate_h_flex")

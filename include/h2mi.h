@@ -327,6 +327,38 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* cosets, uint32_t k,
                                     const uint64_t zeta[4], const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
                                     void* d_h_out, h2mi_stream_t stream);
 
+/* The general form of the halo2-base constraint systems (round 4): what `builder.config(k, Some(minimum_rows))`
+ * (src/scaffold.rs:268) configures when the cells overflow ONE advice column — n_gates <= 4 gate advice columns, each with its
+ * own selector and vertical gate; the permutation argument over n_perm <= 8 columns (constants, the gate columns, the
+ * lookup-advice columns, the instance column) in chunks of chunk_len = cs.degree() - 2; n_lookups <= 2 single-expression lookups
+ * whose input is a lookup-advice column (lookup_input_b NULL) or the product of two columns (the single-column selector form).
+ * Terms in evaluate_h's order: gates, permutation, lookups.  All vectors are extended-coset evaluations; t_inv as above.
+ * Slower per point than the specialised entry above (every operand is converted to the multiplier's radix on load), and written
+ * independently of its level bookkeeping: for a shape both accept the two must agree (tests/test_gpu_flex.py). */
+typedef struct {
+  uint32_t n_gates;
+  const void* gate_a[4];
+  const void* gate_q[4];
+  uint32_t n_perm, chunk_len;
+  const void* perm_value[8];
+  const void* perm_sigma[8];
+  const void* perm_z[8];            /* ceil(n_perm / chunk_len) grand products */
+  uint32_t n_lookups;
+  const void* lookup_input[2];
+  const void* lookup_input_b[2];    /* NULL, or a second factor of the input expression */
+  const void* lookup_table[2];
+  const void* lookup_permuted_input[2];
+  const void* lookup_permuted_table[2];
+  const void* lookup_z[2];
+  const void* l0;
+  const void* l_last;
+  const void* l_active;
+} h2mi_flex_cosets;
+int h2mi_plonk_evaluate_h_flex_dev(const h2mi_flex_cosets* cosets, uint32_t k, uint32_t extended_k, uint32_t blinding_factors,
+                                   const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], const uint64_t delta[4],
+                                   const uint64_t zeta[4], const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
+                                   void* d_h_out, h2mi_stream_t stream);
+
 /* ---- SRS generation helper: ParamsKZG::setup's g[i] = s_i * G   ------------------
  * d_scalars: n Fr (Montgomery).  d_out_affine: n G1Affine.  Fixed-base windowed multiplication of the
  * generator (1, 2) with on-device normalisation. */

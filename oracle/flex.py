@@ -88,6 +88,43 @@ def flex_gate_cs(lookup: bool):
     return cs
 
 
+def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0):
+    """halo2-base's builders when the cells do NOT fit one column: `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268)
+    then configures num_advice = ceil(cells / (2^k - minimum_rows)) gate columns and, for the Range builder, num_lookup_advice =
+    ceil(cells_to_lookup / (2^k - minimum_rows)) lookup-advice columns [RECALL halo2-base 0.3 gates/builder.rs, flex_gate.rs, range.rs]:
+      * FlexGateConfig::configure: the constants column first (enable_equality), then per gate column BasicGateConfig::configure —
+        advice column (enable_equality), its own simple selector, the vertical gate on it;
+      * RangeConfig::configure: the table column before everything; with more than one gate column there is no q_lookup — each
+        lookup-advice column (advice, enable_equality, allocated after the gate columns) gets its own lookup argument
+        (input = the column, degree 1; table = the table column): constraint-system degree 2 + 1 + 1 = 4, permutation chunks of two;
+      * keygen appends one fixed column per simple selector (the gates of different columns are enabled on the same rows, so
+        compress_selectors cannot merge them), after the user's fixed columns;
+      * the scaffold adds the instance column last.
+    num_advice = 1 is flex_gate_cs (the q_lookup form): not built here."""
+    assert num_advice >= 2 and (lookup or num_lookup_advice == 0) and (not lookup or num_lookup_advice >= 1)
+    A, Lc = num_advice, num_lookup_advice
+    TABLE, CONST = (0, 1) if lookup else (None, 0)
+    q0 = CONST + 1
+    gate_of = lambda j: (lambda q: q(FIXED, q0 + j, 0) * (q(ADVICE, j, 0) + q(ADVICE, j, 1) * q(ADVICE, j, 2) - q(ADVICE, j, 3)) % R)
+    gates = [gate_of(j) for j in range(A)]
+    perm = [(FIXED, CONST)] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
+    adv_q = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
+    fix_q = [(CONST, 0)] + ([(TABLE, 0)] if lookup else []) + [(q0 + j, 0) for j in range(A)]
+    lookups = [([(ADVICE, A + l)], (FIXED, TABLE)) for l in range(Lc)]
+    cs = ConstraintSystem(f"{'range' if lookup else 'flex_gate'}_{A}x{Lc}", A + Lc, q0 + A, 1, gates, perm, lookups, adv_q, fix_q, [(0, 0)],
+                          4 if lookup else 3, 6)
+    cs.col_const, cs.col_table, cs.col_qlookup = CONST, TABLE, None
+    cs.col_q = [q0 + j for j in range(A)]
+    cs.num_advice, cs.num_lookup_advice = A, Lc
+    return cs
+
+
+def multi_column_counts(n_cells: int, n_lookup_cells: int, k: int, minimum_rows: int = 9):
+    """GateThreadBuilder::config: columns needed for this many cells at 2^k rows -> (num_advice, num_lookup_advice)"""
+    max_rows = (1 << k) - minimum_rows
+    return -(-n_cells // max_rows), -(-n_lookup_cells // max_rows)
+
+
 class Assignment:
     """what synthesize leaves: sparse cells per column, copy constraints in call order, the public inputs"""
 
@@ -162,6 +199,68 @@ class _Table:
         return asg
 
 
+def multi_column_assignment(t: _Table, cs, public_rows, k: int, minimum_rows: int = 9):
+    """the flat cell list of a closure laid over cs.num_advice gate columns as halo2-base's assign_all does [RECALL builder.rs]:
+    cells go down the current column; after placing a cell at row r the column is full when r >= max_rows - 1, or when the cell
+    STARTS a gate that would not fit (r + 4 > max_rows): the cell is then assigned AGAIN at row 0 of the next column (two gates may
+    overlap at it) and tied to its first copy, and a gate that starts at it is enabled on the new column.  Cells to look up are
+    copied, in order, into the lookup-advice columns (max_rows cells each) and tied to their originals.  constrain_equal calls in
+    the order halo2-base issues them: break copies as they happen, the lookup copies, then the closure's own equalities, the
+    constants, the public cells.
+    This is written differently from the product's flex.Context on purpose: positions come from a precomputed list of break
+    indices (closed form below), not from a running row counter."""
+    A, Lc = cs.num_advice, cs.num_lookup_advice
+    max_rows = (1 << k) - minimum_rows
+    gate_start = set(t.gates)
+    # break indices: cell i ends a column iff its row r_i satisfies r_i >= max_rows - 1 or (i starts a gate and r_i + 4 > max_rows).
+    # r_i = i - (index of the cell at row 0 of i's column); found by one scan over the cells
+    breaks, first = [], 0
+    for i in range(len(t.rows)):
+        r = i - first
+        if (i in gate_start and r + 4 > max_rows) or r >= max_rows - 1:
+            breaks.append(i)
+            first = i  # the copy of cell i sits at row 0 of the next column: cell i + 1 lands on row 1 = (i + 1) - i
+    if len(breaks) + 1 > A:
+        raise ValueError(f"NOT ENOUGH ADVICE COLUMNS: {len(breaks) + 1} needed, {A} configured")
+    col_of = lambda i: sum(1 for b in breaks if b < i)       # column of the FIRST copy of cell i
+    start_of = lambda c: 0 if c == 0 else breaks[c - 1]       # flat index of the cell at row 0 of column c
+    row_of = lambda i: i - start_of(col_of(i))
+    asg = Assignment(cs)
+    copies_break = []
+    for i, (_, v) in enumerate(t.rows):
+        asg.advice[col_of(i)][row_of(i)] = v
+        if i in breaks:
+            c = col_of(i) + 1
+            asg.advice[c][0] = v
+            copies_break.append(((ADVICE, c, 0), (ADVICE, col_of(i), row_of(i))))
+    for g in t.gates:  # a gate that starts at a break cell lives on the NEW column
+        if g in breaks:
+            asg.fixed[cs.col_q[col_of(g) + 1]][0] = 1
+        else:
+            asg.fixed[cs.col_q[col_of(g)]][row_of(g)] = 1
+    where = lambda i: (ADVICE, col_of(i), row_of(i))  # assigned_advices keeps the first copy
+    copies_lookup = []
+    for pos, i in enumerate(t.lookups):
+        lc, lr = divmod(pos, max_rows)
+        if lc >= Lc:
+            raise ValueError("NOT ENOUGH LOOKUP ADVICE COLUMNS")
+        asg.advice[A + lc][lr] = t.value(i)
+        copies_lookup.append((where(i), (ADVICE, A + lc, lr)))
+    first_use = {}
+    for r, (kind, v) in enumerate(t.rows):
+        if kind == K_:
+            first_use.setdefault(v, len(first_use))
+    for v, slot in first_use.items():
+        asg.fixed[cs.col_const][slot] = v
+    asg.copies = copies_break + copies_lookup
+    asg.copies += [(where(new), where(src)) for new, src in t.events]
+    asg.copies += [(where(r), (FIXED, cs.col_const, first_use[v])) for r, (kind, v) in enumerate(t.rows) if kind == K_]
+    for i, r in enumerate(public_rows):
+        asg.instance[0].append(t.value(r))
+        asg.copies.append((where(r), (INSTANCE, 0, i)))
+    return asg
+
+
 def standard_plonk_assignment(cs, x):
     """src/circuits/standard_plonk.rs:83-108 as cells (the same rows oracle/plonk.py::StandardPlonkInstance fills)"""
     asg = Assignment(cs)
@@ -183,6 +282,10 @@ def halo2_lib_assignment(cs, x):
          5 ..  8  x^2, 72, 1, x^2 + 72    gate.add(x_sq, Constant(72))            gate on row 5
          9 .. 12  72, x, x, x^2 + 72      assign_region_last([...], [0])          gate on row 9
         13 .. 16  72, x, x, x^2 + 72      gate.mul_add(x, x, Constant(72))        gate on row 13"""
+    return _halo2_lib_table(x).assignment(cs, [0, 8])
+
+
+def _halo2_lib_table(x):
     x %= R
     t = _Table()
     t.put([(W_, x)])
@@ -191,7 +294,7 @@ def halo2_lib_assignment(cs, x):
     t.put([(K_, 72), (E_, 0), (E_, 0), (W_, x * x + 72)], [0])
     t.put([(K_, 72), (E_, 0), (E_, 0), (W_, x * x + 72)], [0])
     assert len(t.rows) == 17 and t.gates == [1, 5, 9, 13]
-    return t.assignment(cs, [0, 8])
+    return t
 
 
 def range_assignment(cs, x, lookup_bits, n):
@@ -199,7 +302,14 @@ def range_assignment(cs, x, lookup_bits, n):
     0 .. 2^LOOKUP_BITS - 1 (RangeConfig::load_lookup_table), zero elsewhere.  Rows: 0 = x; the inner product occupies rows
     1 .. 3k - 1 (k limbs): limb 0 at row 1, limb i >= 1 at row 3 i - 1, its base 2^(i lb) at row 3 i, the running sum at row
     3 i + 1, gates on rows 1, 4, 7, ...; then the remainder cells, then [x, x, 1, 2x]."""
-    assert 0 <= x < 1 << 64 and n >= 1 << lookup_bits
+    assert n >= 1 << lookup_bits
+    asg = _range_table(x, lookup_bits).assignment(cs, [0])
+    asg.fixed[cs.col_table] = {i: i for i in range(1 << lookup_bits)}
+    return asg
+
+
+def _range_table(x, lookup_bits):
+    assert 0 <= x < 1 << 64
     k = -(-64 // lookup_bits)
     limb = lambda i: (x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1)
     partial = lambda i: x & ((1 << (lookup_bits * (i + 1))) - 1)  # sum of limbs 0 .. i with their bases
@@ -224,7 +334,17 @@ def range_assignment(cs, x, lookup_bits, n):
         r0 = t.put([(K_, 0), (E_, top), (K_, shift), (W_, limb(k - 1) * shift)], [0])
         t.lookups.append(r0 + 3)
     t.put([(E_, 0), (E_, 0), (K_, 1), (W_, 2 * x)], [0])
-    asg = t.assignment(cs, [0])
+    return t
+
+
+def halo2_lib_assignment_multi(cs, x, k, minimum_rows=9):
+    """the halo2_lib closure over cs.num_advice columns (a DEGREE at which its 17 cells overflow one)"""
+    return multi_column_assignment(_halo2_lib_table(x), cs, [0, 8], k, minimum_rows)
+
+
+def range_assignment_multi(cs, x, lookup_bits, k, minimum_rows=9):
+    """the range closure over cs.num_advice gate columns and cs.num_lookup_advice lookup-advice columns"""
+    asg = multi_column_assignment(_range_table(x, lookup_bits), cs, [0], k, minimum_rows)
     asg.fixed[cs.col_table] = {i: i for i in range(1 << lookup_bits)}
     return asg
 

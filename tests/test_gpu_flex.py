@@ -334,3 +334,94 @@ def test_both_hosts_reproduce_the_committed_golden_proofs(gpu):
         assert r.returncode == 0, r.stderr[-1000:]
         out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ")))
         assert out["vk"] == case["vk_bytes"] and out["proof"] == case["proof"], ("C++", shape, bits)
+
+
+# ---- round 4: more than one gate column (builder.config(k, Some(minimum_rows)) on overflow: src/scaffold.rs:268) --------------------
+def test_multi_column_proofs_match_oracle_and_golden(gpu):
+    """the closures at a DEGREE where their cells overflow one advice column: `flex.configure` takes the column counts
+    GateThreadBuilder::config would (range LOOKUP_BITS 4 at DEGREE 5: 3 gate + 1 lookup-advice column; LOOKUP_BITS 3 at DEGREE 6:
+    2 + 1; poseidon at DEGREE 11: 4 gate columns), the product's incremental layout equals the oracle's closed-form one cell for
+    cell and constrain_equal for constrain_equal, keys and proof bytes equal the oracle's (live at DEGREE <= 6) and the committed
+    golden (tests/golden/flex_multi_proofs.json), and the oracle's verifier accepts / rejects as it should.  The quotient runs
+    through the general kernel (h2mi_plonk_evaluate_h_flex_dev): one gate per column, one lookup per lookup-advice column."""
+    import json
+    import os
+
+    from halo2_scaffold_amd import flex, poseidon
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, "tests", "golden", "flex_multi_proofs.json")))
+    secret = int(g["srs_secret"], 16)
+    for case in g["cases"]:
+        shape, k, bits, x, seed = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16), case["seed"]
+        closure = ((lambda cs: flex.range_closure(cs, x, bits)) if shape == "range" else (lambda cs: poseidon.hash_two_closure(cs, x, x + 1)))
+        cs = flex.configure(shape == "range", k, closure)
+        assert (cs.num_advice, cs.num_lookup_advice) == (case["num_advice"], case["num_lookup_advice"]) and cs.num_advice > 1
+        asg = closure(cs)
+        flex.mock(asg)
+        assert asg.instance == [int(v, 16) for v in case["instance"]]
+        params = gpu.ParamsKZG.setup(k, secret)
+        keys = flex.FlexKeys(params, cs, asg)
+        assert keys.vk_bytes().hex() == case["vk_bytes"], (shape, k)
+        trace = {}
+        proof = flex.create_proof(params, keys, asg, seed, trace=trace)
+        assert proof.hex() == case["proof"], (shape, k)
+        ocs = FX.flex_multi_cs(shape == "range", cs.num_advice, cs.num_lookup_advice)
+        if shape == "range":
+            oasg = FX.range_assignment_multi(ocs, x, bits, k)
+            assert asg.advice == oasg.advice and asg.copies == oasg.copies and [asg.instance] == oasg.instance
+            assert [dict(c) for i, c in enumerate(asg.fixed) if i != cs.col_table] == [dict(c) for i, c in enumerate(oasg.fixed) if i != ocs.col_table]
+            okeys = _oracle_keys(ocs, k, oasg)
+            _check_keys(keys, okeys, 1 << k)
+            want = FX.prove(okeys, oasg, seed)
+            for name in ("theta", "beta", "gamma", "y", "x"):
+                assert trace[name] == want[name], name
+            assert proof == want["proof"]
+            assert FX.verify(okeys, proof, [asg.instance]) and not FX.verify(okeys, proof, [[x ^ 1]])
+            # a second proof through a reused workspace, other witness and seed: verified, different bytes
+            ws = flex.FlexWorkspace(params, keys)
+            asg2 = flex.range_closure(cs, x ^ 0xFFFF, bits)
+            p2 = flex.create_proof(params, keys, asg2, seed + 1, ws=ws)
+            assert p2 != proof and FX.verify(okeys, p2, [asg2.instance])
+            assert flex.create_proof(params, keys, asg, seed, ws=ws) == proof
+            ws.release()
+        keys.release()
+        params.release()
+    # the column count the crate's formula gives can be too small (a gate never straddles two columns): same failure as halo2-base
+    cs = flex.configure(False, 4, lambda c: flex.halo2_lib_closure(c, 12))
+    assert cs.num_advice == 3
+    with pytest.raises(ValueError, match="NOT ENOUGH ADVICE COLUMNS"):
+        flex.halo2_lib_closure(cs, 12)
+
+
+def test_general_quotient_kernel_agrees_with_the_specialised_one(gpu):
+    """k_evaluate_h_flex (every operand converted to the multiplier's radix, Horner in y as the oracle writes it) and
+    k_evaluate_h_range (level bookkeeping, shared reductions) are two independent implementations of the same function of their
+    inputs: on RANDOM cosets — single gate, three permutation columns, the selector form of the lookup input and the lookup-advice
+    form, and the Gate shape without a lookup — they must produce the same h, element for element."""
+    from halo2_scaffold_amd import plonk as gp
+    from halo2_scaffold_amd import synth
+    from halo2_scaffold_amd.device import DevBuf
+
+    k = 9
+    for lookup, selector_form in ((False, False), (True, True), (True, False)):
+        degree = 5 if selector_form else 4 if lookup else 3
+        d = gpu.EvaluationDomain(degree, k)
+        ext = d.extended_len()
+        rnd = lambda i: DevBuf.from_numpy(synth.uniform_fr(ext, 4000 + i))
+        a, q, table, la, ql = rnd(0), rnd(1), rnd(2), rnd(3), rnd(4)
+        chunk = degree - 2
+        perm_v, perm_s = [rnd(10 + j) for j in range(3)], [rnd(20 + j) for j in range(3)]
+        zs = [rnd(30 + j) for j in range(-(-3 // chunk))]
+        pin, ptab, lz = rnd(40), rnd(41), rnd(42)
+        l0, ll, lact = rnd(50), rnd(51), rnd(52)
+        beta, gamma, y = 0x1234567 ^ k, 0xABCDEF01, 0x777 + degree
+        h1, h2 = DevBuf(ext * 32), DevBuf(ext * 32)
+        gp.evaluate_h_range(d, a, (la if lookup and not selector_form else None), q, table if lookup else None, perm_v, perm_s, zs,
+                            pin if lookup else None, ptab if lookup else None, lz if lookup else None, l0, ll, lact, beta, gamma, y, h1,
+                            blinding_factors=6, lookup_selector=ql if selector_form else None, chunk_len=chunk)
+        lookups = [((ql if selector_form else la), (a if selector_form else None), table, pin, ptab, lz)] if lookup else []
+        gp.evaluate_h_flex(d, [(a, q)], perm_v, perm_s, zs, chunk, lookups, l0, ll, lact, beta, gamma, y, h2, blinding_factors=6)
+        assert np.array_equal(h1.to_numpy(shape=(ext, 4)), h2.to_numpy(shape=(ext, 4))), (lookup, selector_form)
+        for b in [a, q, table, la, ql, pin, ptab, lz, l0, ll, lact, h1, h2] + perm_v + perm_s + zs:
+            b.free()

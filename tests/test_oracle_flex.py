@@ -11,6 +11,9 @@ import pytest
 from oracle import flex as FX
 from oracle import formats as fm
 
+R = FX.R
+SECRET = 0x5EC2E7 + 0x48324D49
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "standard_plonk_proofs.json")
 
 
@@ -109,3 +112,73 @@ def test_committed_flex_golden_proofs_are_what_the_oracle_produces():
         assert FX.prove(keys, asg, case["seed"])["proof"].hex() == case["proof"]
         assert [int(v, 16) for v in case["instance"]] == asg.instance[0]
         assert FX.verify(keys, bytes.fromhex(case["proof"]), asg.instance)
+
+
+# ---- round 4: more than one gate column (what builder.config(k, Some(minimum_rows)) configures on overflow: src/scaffold.rs:268) ----
+def test_multi_column_layout_and_proofs():
+    """range_check(x, 64) with LOOKUP_BITS 4 at DEGREE 5: 51 cells over columns of 2^5 - 9 = 23 rows -> three gate columns and one
+    lookup-advice column (oracle/flex.py flex_multi_cs / multi_column_assignment [RECALL halo2-base]).  The layout's own invariants
+    (every gate holds on its column, every equality joins equal cells — break copies included —, every looked-up cell is in the
+    table), the oracle prover / verifier on it, a tampered proof, a wrong public input, and the committed golden bytes."""
+    import json
+    import os
+
+    x, bits, k = 0xDEADBEEFCAFE1234, 4, 5
+    t = FX._range_table(x, bits)
+    assert FX.multi_column_counts(len(t.rows), len(t.lookups), k) == (3, 1) and (len(t.rows), len(t.lookups)) == (51, 16)
+    cs = FX.flex_multi_cs(True, 3, 1)
+    asg = FX.range_assignment_multi(cs, x, bits, k)
+    assert [len(c) for c in asg.advice] == [23, 22, 8, 16]  # two break copies: 51 + 2 cells over the gate columns
+    assert cs.degree == 4 and cs.chunk == 2 and len(cs.perm_columns) == 6 and len(cs.lookups) == 1
+    # the layout is a satisfying assignment
+    for j in range(3):
+        a = asg.advice[j]
+        for r in asg.fixed[cs.col_q[j]]:
+            assert r + 3 < 23 and (a[r] + a[r + 1] * a[r + 2] - a[r + 3]) % R == 0, (j, r)
+    val = {FX.ADVICE: lambda c, r: asg.advice[c][r], FX.FIXED: lambda c, r: asg.fixed[c][r], FX.INSTANCE: lambda c, r: asg.instance[c][r]}
+    for left, right in asg.copies:
+        assert val[left[0]](left[1], left[2]) == val[right[0]](right[1], right[2]), (left, right)
+    assert [(l[1], l[2], r[1]) for l, r in asg.copies[:2]] == [(1, 0, 0), (2, 0, 1)]  # the two break copies come first: row 0 of the next column
+    assert all(v < 16 for v in asg.advice[3].values())
+    keys = FX.Keys(cs, k, SECRET, asg.fixed, asg.copies)
+    r = FX.prove(keys, asg, 99)
+    assert FX.verify(keys, r["proof"], asg.instance)
+    assert FX.verify(FX.VerifierKeys(cs, k, SECRET, asg.fixed, asg.copies), r["proof"], asg.instance)  # closed-form verifying key
+    bad = bytearray(r["proof"])
+    bad[100] ^= 1
+    assert not FX.verify(keys, bytes(bad), asg.instance)
+    assert not FX.verify(keys, r["proof"], [[x ^ 1]])
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flex_multi_proofs.json")))
+    case = next(c for c in g["cases"] if c["shape"] == "range" and c["k"] == 5)
+    assert int(g["srs_secret"], 16) == SECRET and r["proof"].hex() == case["proof"] and keys.vk_bytes().hex() == case["vk_bytes"]
+    # a witness that breaks a gate on the SECOND column is not provable
+    asg.advice[1][5] = (asg.advice[1][5] + 1) % R
+    assert not FX.verify(keys, FX.prove(keys, asg, 99)["proof"], asg.instance)
+
+
+def test_multi_column_counts_can_be_too_few_as_in_the_crate():
+    """GateThreadBuilder::config takes ceil(cells / rows) columns, but a break wastes rows (a gate never straddles two columns): the
+    17 cells of x^2 + 72 at DEGREE 4 (7-row columns) are configured with three columns and need four — halo2-base panics with
+    'NOT ENOUGH ADVICE COLUMNS' there, and so does the layout here."""
+    t = FX._halo2_lib_table(12)
+    assert FX.multi_column_counts(len(t.rows), 0, 4) == (3, 0)
+    with pytest.raises(ValueError, match="NOT ENOUGH ADVICE COLUMNS"):
+        FX.halo2_lib_assignment_multi(FX.flex_multi_cs(False, 3, 0), 12, 4)
+    asg = FX.halo2_lib_assignment_multi(FX.flex_multi_cs(False, 4, 0), 12, 4)  # with the fourth column it fits
+    assert sum(len(c) for c in asg.advice) == 17 + 3
+
+
+def test_fast_prover_matches_on_multi_column_shapes():
+    """oracle/fastflex.py (the vector form that makes the poseidon DEGREE 11 golden) against the Python-integer engine on the
+    three-column range circuit: byte-identical proofs"""
+    from oracle import fastflex as FF
+
+    x, bits, k = 0x0123456789ABCDEF, 3, 6
+    t = FX._range_table(x, bits)
+    A, Lc = FX.multi_column_counts(len(t.rows), len(t.lookups), k)
+    assert (A, Lc) == (2, 1)
+    cs = FX.flex_multi_cs(True, A, Lc)
+    asg = FX.range_assignment_multi(cs, x, bits, k)
+    slow = FX.prove(FX.Keys(cs, k, SECRET, asg.fixed, asg.copies), asg, 5)["proof"]
+    fast = FF.prove(FF.Keys(cs, k, SECRET, asg.fixed, asg.copies), asg, 5)["proof"]
+    assert slow == fast
