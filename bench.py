@@ -259,7 +259,7 @@ def main(argv=None):
     # HBM traffic of the kernel comes from rocprofv3 PMC counters, which cannot be collected from inside this
     # process: the field carries the figure of the latest committed counter run of this same workload and says so
     traffic, traffic_source = None, None
-    for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and world == 1 and args.k == 20 and args.shape == "standard_plonk":
             try:
@@ -363,6 +363,10 @@ def main(argv=None):
                 out["create_proof_k16"], out["create_proof_k8"], out["create_proof_k5"] = small["k16"], small["k8"], small["k5"]
                 out["create_proof"]["cpp_host_ms"] = small["k20"].get("cpp_host_ms")
                 out["create_proof_hosts_what"] = small["what"]
+                if small["k20"].get("cpp_host_ms"):  # the compiled host is the mirror of the reference's (compiled) example: the headline wall clock
+                    out["pipeline_ms_per_step"] = small["k20"]["cpp_host_ms"]
+                    out["pipeline_ms_per_step_what"] = ("create_proof() wall clock per 2^20-row proof on the C++ host (examples/standard_plonk.cpp, a child process); "
+                                                        "create_proof.ms_per_proof is the same prover driven from Python")
             except Exception as e:
                 out["create_proof_k16"] = {"error": repr(e)}
             # BASELINE configs[2], [4], [3] data-true on this GPU: create_proof through the halo2-lib builders
