@@ -335,12 +335,22 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
 // (profiles/r03_traffic.json: 129.7 MB per k_ntt_pass_col<1024,10> launch; profiles/r04_ntt_traffic.txt has both forms).  The
 // matrix W[tile][o] = omega^((j k) << sh), o = (k << logC) + c, j = tile * C + c, holds the same 2^log_seg values in the order
 // the tiles' threads read them: consecutive lanes read consecutive 32-byte entries.  Built once per plan from the full table.
-__global__ void __launch_bounds__(256) k_ntt_wmat_build(const fe* full, fe* W, uint32_t log_seg, uint32_t m, uint32_t logC, uint32_t sh) {
+// `lo` / `hi` / `h`: the plan's power table — the full table (h = log_n: one entry per power, copied) or, above 2^22, the two-level
+// table (an entry = the product of two: the multiplication the pass kernel then no longer does per element and pass).
+__global__ void __launch_bounds__(256) k_ntt_wmat_build(const fe* lo, const fe* hi, uint32_t h, uint32_t full, fe* W, uint32_t log_seg, uint32_t m,
+                                                         uint32_t logC, uint32_t sh) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >> log_seg) return;
   const uint32_t o = (uint32_t)idx & ((1u << (m + logC)) - 1), tile = (uint32_t)(idx >> (m + logC));
   const uint32_t c = o & ((1u << logC) - 1), k = o >> logC, j = (tile << logC) + c;
-  fe_store(&W[idx], fe_load(&full[(size_t)(j * k) << sh]));
+  const uint32_t e = (j * k) << sh;  // < n
+  if (full) {
+    fe_store(&W[idx], fe_load(&lo[e]));
+  } else {
+    fe v;
+    f29_pack(f29_reduce_canonical<F9>(pow2tab(lo, hi, h, e)), v.v);
+    fe_store(&W[idx], v);
+  }
 }
 
 // a[i] = a[i] * base^i (* post)
@@ -1351,6 +1361,7 @@ static void fill_common(HConsts& h, const fe& beta, const fe& gamma, const fe& d
 // idle, since tables may be in use on any stream.
 constexpr uint32_t FULL_TABLE_MAX_LOG = 22;
 constexpr uint32_t NTT_TILE_LOG = 10;  // elements a pass stages per workgroup (2^10: four tiles of 40 KB per CU)
+constexpr uint32_t WMAT_MAX_LOG = 24;  // largest transform whose inter-pass twiddles are kept as tile-ordered matrices
 constexpr size_t POWTAB_MAX_ENTRIES = 64, POWTAB_KEEP_ENTRIES = 32;
 constexpr size_t POWTAB_MAX_BYTES = (size_t)3 << 30, POWTAB_KEEP_BYTES = (size_t)3 << 29;
 static size_t g_powtab_bytes = 0;
@@ -1507,7 +1518,10 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
     // w_loc = omega^(n / 2^m): order 2^m
     H2_LAUNCH("k_pow_table", k_pow_table, ceil_div_u32(cnt, 256), 256, 0, s, pl.loc[p], cnt, w, log_n - m, m - 1);
   }
-  if (pl.tw.full && !ab_env("H2MI_NTT_NO_WMAT")) {  // tile-ordered twiddle matrices of the non-final passes (default tile: 2^10 elements)
+  // tile-ordered twiddle matrices of the non-final passes (default tile: 2^10 elements): from the full table up to 2^22, from the
+  // two-level table up to 2^24 (512 MB per 2^24 plan of 288 GB: the pass kernels then fetch the inter-pass twiddle instead of
+  // multiplying two table entries per element — 11.75 -> 9.75 multiplications per element of a 2^24 transform)
+  if (pl.P > 1 && log_n <= WMAT_MAX_LOG && !ab_env("H2MI_NTT_NO_WMAT")) {
     uint32_t log_seg = log_n;
     for (int p = 0; p + 1 < pl.P; p++) {
       const uint32_t m = pl.m[p], logS = log_seg - m;
@@ -1518,8 +1532,8 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
         return H2MI_ENOMEM;
       }
       pl.wlogC[p] = logC;
-      H2_LAUNCH("k_ntt_wmat_build", k_ntt_wmat_build, ceil_div_u32((size_t)1 << log_seg, 256), 256, 0, s, (const fe*)pl.tw.lo, pl.wmat[p], log_seg, m, logC,
-                log_n - log_seg);
+      H2_LAUNCH("k_ntt_wmat_build", k_ntt_wmat_build, ceil_div_u32((size_t)1 << log_seg, 256), 256, 0, s, (const fe*)pl.tw.lo, (const fe*)pl.tw.hi, pl.tw.h,
+                pl.tw.full ? 1u : 0u, pl.wmat[p], log_seg, m, logC, log_n - log_seg);
       log_seg -= m;
     }
   }

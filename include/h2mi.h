@@ -38,7 +38,7 @@ extern "C" {
 #define H2MI_EHANDLE (-5)  /* unknown or released bases handle                                          */
 #define H2MI_ERANGE (-6)   /* n larger than the registered base count / unsupported size                */
 
-#define H2MI_MAX_LOG_N 27  /* largest NTT the device path accepts (2^27 x 32 B = 4 GiB per buffer)       */
+#define H2MI_MAX_LOG_N 28  /* largest NTT the device path accepts: the field's two-adicity (2^28 x 32 B = 8 GiB per buffer) */
 
 typedef void* h2mi_stream_t; /* a hipStream_t, or NULL for the library's own stream */
 

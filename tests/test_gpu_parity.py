@@ -201,6 +201,39 @@ def test_domain_matches_oracle(gpu):
     assert o.unpack(back, o.R)[: d.n] == vals
 
 
+def test_ntt_at_the_two_adicity_limit(gpu):
+    """log_n = 28 = Fr's two-adicity (`log_n 1..=28`; omega = ROOT_OF_UNITY itself): 8 GiB per vector, three passes
+    (2^10 x 2^9 x 2^9), two-level twiddle tables.  Size-independent properties on device-resident data, sampled against the
+    host's integer arithmetic: NTT(delta_1)[i] = omega^i, NTT(delta_0 + delta_3)[i] = 1 + omega^(3 i) (linearity on the same
+    kernel path), and the inverse transform with the fused n^-1 returns the input exactly."""
+    from halo2_scaffold_amd import field as F
+    from halo2_scaffold_amd.device import DevBuf
+
+    log_n = 28
+    n = 1 << log_n
+    lib = gpu.lib
+    w = F.omega_for(log_n)
+    assert w == F.FR_ROOT_OF_UNITY and pow(w, n // 2, o.R) == o.R - 1
+    wl, wil, ninv = F.fr_to_mont_limbs(w), F.fr_to_mont_limbs(F.fr_inv(w)), F.fr_to_mont_limbs(F.fr_inv(n))
+    buf = DevBuf(n * 32)
+    assert lib.h2mi_ntt_bn254_fr_dev(buf.ptr, 29, wl.ctypes.data, None, None, None) != 0  # beyond the two-adicity: refused (H2MI_ERANGE)
+    one = F.fr_to_mont_limbs(1)
+    samples = [0, 1, 2, 3, 1023, 1024, (1 << 18) + 5, (1 << 27) - 1, 1 << 27, n - 1, 0x0ABCDEF, 0xFEDCBA9]
+    for support in ([1], [0, 3]):
+        assert lib.h2mi_memset_zero(buf.ptr, n * 32) == 0
+        for j in support:
+            buf.upload(one, offset=j * 32)
+        assert lib.h2mi_ntt_bn254_fr_dev(buf.ptr, log_n, wl.ctypes.data, None, None, None) == 0
+        for i in samples:
+            got = F.fr_from_mont_limbs(buf.to_numpy(shape=(4,), nbytes=32, offset=i * 32))
+            assert got == sum(pow(w, j * i, o.R) for j in support) % o.R, (support, i)
+        assert lib.h2mi_ntt_bn254_fr_dev(buf.ptr, log_n, wil.ctypes.data, None, ninv.ctypes.data, None) == 0
+        for i in samples + [4, 5, 1 << 20]:
+            got = F.fr_from_mont_limbs(buf.to_numpy(shape=(4,), nbytes=32, offset=i * 32))
+            assert got == (1 if i in support else 0), (support, i)
+    buf.free()
+
+
 def _msm_case(gpu, scalars_limbs, points):
     got = gpu.best_multiexp(scalars_limbs, o.pack_points(points))
     want = o.msm_naive(o.unpack(scalars_limbs, o.R), points)
