@@ -264,8 +264,13 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), e = o >> logC;
     size_t idx = base + ((size_t)e << logS) + jl0 + c;
-    f29 x = idx < p.in_len ? load_unpack(&p.in[idx]) : f29_zero();
-    if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+    // zero-extended input (coeff_to_extended: three quarters of a 4n coset transform's input are padding): a padded element needs
+    // neither its load nor its coset power (two table loads and two multiplications above 2^22) — round 4: coset 2^24 from 2^22
+    f29 x = f29_zero();
+    if (idx < p.in_len) {
+      x = load_unpack(&p.in[idx]);
+      if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+    }
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
   stage_twiddles(tw, p.loc, m);
@@ -306,8 +311,13 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
     uint32_t c = o >> m, e = o & ((1u << m) - 1);
     size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
     size_t idx = (rho << m) + e;
-    f29 x = idx < p.in_len ? load_unpack(&p.in[idx]) : f29_zero();
-    if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+    // zero-extended input (coeff_to_extended: three quarters of a 4n coset transform's input are padding): a padded element needs
+    // neither its load nor its coset power (two table loads and two multiplications above 2^22) — round 4: coset 2^24 from 2^22
+    f29 x = f29_zero();
+    if (idx < p.in_len) {
+      x = load_unpack(&p.in[idx]);
+      if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+    }
     lds_put(lds, dstride, (c << m) | bitrev(e, m), x);
   }
   stage_twiddles(tw, p.loc, m);
