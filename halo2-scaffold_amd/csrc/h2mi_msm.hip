@@ -1335,7 +1335,7 @@ static void free_bases(Bases* B) {
 
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
 
-static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s) {
+static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s, bool allow_small = true) {
   if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
   Bases* B = new Bases();
   B->n = n;
@@ -1411,7 +1411,9 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
                        B->table + (size_t)w * B->stride * 64, n, B->c);
     if (prof_) prof_end(s);
   }
-  if (small_geometry(n, &B->sc, &B->slanes, &B->sr)) {  // second table for the latency path: every multiple a signed digit can select
+  // (an ad-hoc base set — handle = 0: used once or a few times — keeps the general pipeline: the multiples table costs ~10 ms of
+  // dependent conversions to build, which pays for a registered SRS and not for a one-off slice)
+  if (allow_small && small_geometry(n, &B->sc, &B->slanes, &B->sr)) {  // second table for the latency path: every multiple a signed digit can select
     B->sW = (255 + B->sc - 1) / B->sc;
     B->sG = ceil_div_u32((uint64_t)n * B->sW, (uint64_t)B->slanes * B->sr);
     const uint32_t NBs = 1u << (B->sc - 1);
@@ -2181,7 +2183,7 @@ static int adhoc_handle(const uint64_t* bases, size_t n, uint64_t* handle_out) {
     g_adhoc.erase(g_adhoc.begin() + victim);
   }
   uint64_t nh = 0;
-  int rc = register_dev(d.p, n, &nh, s);
+  int rc = register_dev(d.p, n, &nh, s, /*allow_small=*/false);
   if (rc) return rc;
   g_adhoc_builds++;
   g_adhoc.push_back({n, {h[0], h[1]}, nh, g_adhoc_clock});

@@ -331,8 +331,18 @@ def test_msm_small_path_and_general_pipeline_agree_with_oracle(gpu, n):
 
 
 def test_msm_small_path_edge_points(gpu):
-    """identity bases, duplicated bases (P + P in one bucket: the doubling case of the mixed addition), P and -P with equal scalars
-    (cancellation to the identity inside a bucket), n * G, and digit-carry chains — through the small path, against the oracle."""
+    """identity bases, duplicated bases (P + P in one lane's chain and in the tree: the doubling cases), P and -P with equal scalars
+    (cancellation to the identity), n * G, and digit-carry chains — through the small path (REGISTERED base sets: an ad-hoc slice,
+    handle = 0, keeps the general pipeline) and through the general pipeline on the same handle, against the oracle."""
+
+    def case(scalars, points):
+        bases = o.pack_points(points)
+        h = C.c_uint64()
+        assert gpu.lib.h2mi_bases_register(bases.ctypes.data, len(points), C.byref(h)) == 0
+        sc = np.ascontiguousarray(scalars)
+        _both_msm_paths(gpu, h.value, sc, len(points), o.msm_naive(o.unpack(sc, o.R), points))
+        assert gpu.lib.h2mi_bases_release(h.value) == 0
+
     n = 96
     pts = _points(n, 5)
     pts2 = list(pts)
@@ -342,12 +352,12 @@ def test_msm_small_path_edge_points(gpu):
     s = o.random_field_limbs(n, 99)
     s[5] = s[4]
     s[7] = s[6]
-    _msm_case(gpu, s, pts2)
+    case(s, pts2)
     ones = np.tile(o.pack([1], o.R)[0], (n, 1))
-    _msm_case(gpu, ones, [o.G1_GEN] * n)
-    _msm_case(gpu, np.tile(o.pack([5], o.R)[0], (2, 1)), [pts[0], o.g1_neg(pts[0])])  # the whole MSM cancels
+    case(ones, [o.G1_GEN] * n)
+    case(np.tile(o.pack([5], o.R)[0], (2, 1)), [pts[0], o.g1_neg(pts[0])])  # the whole MSM cancels
     carry = o.pack([(1 << 253) - 1, (1 << 200) - 1, 0x7FFF8000_7FFF8000, 0x8000, 0x8001, 0xFFFF, 3, 4, 0x24, 0x1C], o.R)
-    _msm_case(gpu, carry, pts[:10])
+    case(carry, pts[:10])
 
 
 def test_empty_msm_is_identity(gpu):
