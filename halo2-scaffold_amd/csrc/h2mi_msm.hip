@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(256) k_msm_fill_one(fe* out, size_t n) {
 // pairs, 67 MB of sorted payloads: 0.3 GB against 0.7 GB + 0.1 GB for key/value radix sorting.
 // The order of the points inside a bucket follows LDS-atomic arrival, so it is not reproducible: see
 // k_msm_final for what that means for the result.
-constexpr uint32_t P1_TS = 768;       // scalars per partition tile = threads per workgroup
+constexpr uint32_t P1_TS = 768;       // scalars per partition tile = threads per workgroup (512, whose 48-KB scatter stage fits beside two
+                                      // accumulation workgroups on a CU, measured again in round 4: no difference — profiles/r04_accum_ab.txt)
 constexpr uint32_t NBINS_MAX = 512;
 // Wide windows (c = 18 .. 20: 2^17 .. 2^19 buckets; round 3, measured in profiles/r03_msm_sweep.txt).  The first partition
 // level keeps its 512 bins, so a bin holds up to 1024 buckets: 16-bit in-bin keys and a 1024-entry second-level histogram
