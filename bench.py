@@ -489,9 +489,10 @@ def time_ntt_roofline(h2):
         elif log_n <= 20:
             ms = [(log_n + 1) // 2, log_n - (log_n + 1) // 2]
         else:
-            m0 = (log_n + 2) // 3
-            m1 = (log_n - m0 + 1) // 2
-            ms = [m0, m1, log_n - m0 - m1]
+            m0 = max(8, (log_n + 2) // 3)
+            rem = log_n - m0
+            m1 = max(min(8, rem - 4), (rem + 1) // 2)
+            ms = [m0, m1, rem - m1]
         per = sum((m // 2 - 1) + 0.25 + (0.5 if m & 1 else 0) for m in ms)
         return per + (len(ms) - 1) + (1 if coset else 0), ms
 

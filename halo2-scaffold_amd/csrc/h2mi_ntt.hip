@@ -1485,10 +1485,14 @@ static void choose_split(uint32_t log_n, Plan* pl) {
     pl->m[0] = (log_n + 1) / 2;
     pl->m[1] = log_n - pl->m[0];
   } else {
+    // three passes: 2^8-point DFTs first where the size allows (round 4, re-swept with the tile-ordered twiddles,
+    // profiles/r04_ntt_sweep.txt: 2^21 (8,8,5) 269 / 264 us plain / coset against 277 / 270 for (7,7,7); 2^22 (8,8,6) 520 / 498 against
+    // 524 / 502 for (8,7,7); 2^24 (8,8,8) as before; every split within +- 3 %); the last pass keeps at least 2^4 points
     pl->P = 3;
-    pl->m[0] = (log_n + 2) / 3;
-    pl->m[1] = (log_n - pl->m[0] + 1) / 2;
-    pl->m[2] = log_n - pl->m[0] - pl->m[1];
+    pl->m[0] = std::max<uint32_t>(8, (log_n + 2) / 3);
+    const uint32_t rem = log_n - pl->m[0];
+    pl->m[1] = std::max<uint32_t>(std::min<uint32_t>(8, rem - 4), (rem + 1) / 2);
+    pl->m[2] = rem - pl->m[1];
   }
 }
 
