@@ -1373,6 +1373,7 @@ constexpr uint32_t FULL_TABLE_MAX_LOG = 22;
 constexpr uint32_t NTT_TILE_LOG = 10;  // elements a pass stages per workgroup (2^10: four tiles of 40 KB per CU)
 constexpr uint32_t WMAT_MAX_LOG = 24;  // largest transform whose inter-pass twiddles are kept as tile-ordered matrices
 constexpr size_t POWTAB_MAX_ENTRIES = 64, POWTAB_KEEP_ENTRIES = 32;
+constexpr size_t PLAN_KEEP = 24;  // transform plans (one per (omega, size): a prover uses four to six) kept through an eviction
 constexpr size_t POWTAB_MAX_BYTES = (size_t)3 << 30, POWTAB_KEEP_BYTES = (size_t)3 << 29;
 static size_t g_powtab_bytes = 0;
 static uint64_t g_epoch = 1, g_evictions = 0;
@@ -1398,31 +1399,44 @@ static void free_plan(Plan& pl) {
 
 static int evict_tables() {
   H2_HIP(hipDeviceSynchronize());  // every stream: a table may be read by kernels the caller queued elsewhere
-  // plans first (they hold raw copies of their twiddle table's pointers), then unreferenced tables, oldest first
-  for (auto it = g_plans.begin(); it != g_plans.end();) {
-    if (it->second.last_use < g_epoch) {
-      free_plan(it->second);
-      it = g_plans.erase(it);
-    } else {
-      ++it;
+  // What fills the cache in a prover loop are the per-challenge tables (evaluation points, their inverses: a dozen per proof, used
+  // once); the per-domain plans and the omega / coset tables they reference are hit by every proof.  So: unreferenced tables go
+  // first, oldest first, and plans are dropped only when that was not enough.  (Until round 4 every plan not used by the running
+  // call was freed on every eviction — harmless while a plan was two small twiddle tables, but a plan now owns its tile-ordered
+  // twiddle matrices, 32 - 512 MB: a proof loop rebuilt them every five or six proofs, k_ntt_wmat_build inside the steady state.)
+  auto drop_unreferenced = [&]() {
+    std::vector<std::pair<uint64_t, Key>> order;
+    for (auto& kv : g_powtabs) {
+      if (kv.second.last_use >= g_epoch) continue;  // handed out during this call
+      bool referenced = false;
+      for (auto& pk : g_plans) referenced = referenced || pk.second.tw.lo == kv.second.lo;
+      if (!referenced) order.push_back({kv.second.last_use, kv.first});
     }
-  }
-  std::vector<std::pair<uint64_t, Key>> order;
-  for (auto& kv : g_powtabs) {
-    if (kv.second.last_use >= g_epoch) continue;  // handed out during this call
-    bool referenced = false;
-    for (auto& pk : g_plans) referenced = referenced || pk.second.tw.lo == kv.second.lo;
-    if (!referenced) order.push_back({kv.second.last_use, kv.first});
-  }
-  std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, Key>& a, const std::pair<uint64_t, Key>& b) { return a.first < b.first; });
-  for (auto& e : order) {
-    if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES) break;
-    auto it = g_powtabs.find(e.second);
-    H2_IGNORE(hipFree(it->second.lo));
-    H2_IGNORE(hipFree(it->second.hi));
-    it->second.built.destroy();
-    g_powtab_bytes -= it->second.bytes;
-    g_powtabs.erase(it);
+    std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, Key>& a, const std::pair<uint64_t, Key>& b) { return a.first < b.first; });
+    for (auto& e : order) {
+      if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES) break;
+      auto it = g_powtabs.find(e.second);
+      H2_IGNORE(hipFree(it->second.lo));
+      H2_IGNORE(hipFree(it->second.hi));
+      it->second.built.destroy();
+      g_powtab_bytes -= it->second.bytes;
+      g_powtabs.erase(it);
+    }
+  };
+  drop_unreferenced();
+  if (g_powtabs.size() > POWTAB_KEEP_ENTRIES || g_powtab_bytes > POWTAB_KEEP_BYTES || g_plans.size() > PLAN_KEEP) {
+    // still over: the plans of domains no longer in use (oldest first), then the tables they held
+    std::vector<std::pair<uint64_t, Key>> plans;
+    for (auto& kv : g_plans)
+      if (kv.second.last_use < g_epoch) plans.push_back({kv.second.last_use, kv.first});
+    std::sort(plans.begin(), plans.end(), [](const std::pair<uint64_t, Key>& a, const std::pair<uint64_t, Key>& b) { return a.first < b.first; });
+    for (auto& e : plans) {
+      auto it = g_plans.find(e.second);
+      free_plan(it->second);
+      g_plans.erase(it);
+      drop_unreferenced();
+      if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES && g_plans.size() <= PLAN_KEEP) break;
+    }
   }
   g_evictions++;
   return H2MI_OK;
