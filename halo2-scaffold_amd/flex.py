@@ -621,9 +621,11 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         slot += 1
     slot += 1  # the random polynomial's commitment, queued before the grand products (RANDOM_SLOT)
     check(lib.h2mi_msm_flush(), "flush")
-    side.join_library()  # evaluate_h and the openings read the side stream's forms
     _write_points(ws, transcript, slot)
     y = sq()
+    # evaluate_h and the openings read the side stream's forms.  Joined AFTER the read-back of the phase's points: the copy runs on
+    # the library stream, and a join in front of it made the transcript wait for every transform instead of the bucket reductions only
+    side.join_library()
     # quotient
     h = dev(ext)
     coset_of = {ADVICE: [e for _, e in advice_f], FIXED: list(pk.fixed_cosets), INSTANCE: [instance_f[1]]}

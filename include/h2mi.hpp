@@ -56,12 +56,142 @@ struct G1 {
 };
 
 // ---- host-side scalar-field helpers (a few scalars per domain; never bulk data) --------------------
+namespace detail {
+// x with a x = 1 (mod p) for an odd modulus p < 2^255 and 0 < a < p, plain integers (4 x 64-bit limbs), by Bernstein - Yang division
+// steps ("Fast constant-time gcd computation and modular inversion", 2019) in batches of 62: a batch looks at the low words of f and g
+// only and yields a 2 x 2 transition matrix that is then applied to the full f, g (exactly divisible by 2^62) and to the cofactors d, e
+// (modulo p).  ~1.5 us against ~18 us for the Fermat exponentiation a^(p-2): the provers' hosts invert a dozen single elements per
+// proof on the transcript's critical path (batch_normalize of a phase's points, the rotation sets' Lagrange denominators) — at 2^16
+// rows and below that was ~0.2 ms of a proof.  Returns false if the steps did not converge (they always do for gcd(a, p) = 1).
+inline bool inv_mod_odd(const uint64_t a[4], const uint64_t p[4], uint64_t out[4]) {
+  typedef unsigned __int128 u128;
+  typedef __int128 i128;
+  constexpr int64_t M62 = (int64_t)((1ULL << 62) - 1);
+  auto to62 = [&](const uint64_t x[4], int64_t y[5]) {
+    y[0] = (int64_t)(x[0] & (uint64_t)M62);
+    y[1] = (int64_t)(((x[0] >> 62) | (x[1] << 2)) & (uint64_t)M62);
+    y[2] = (int64_t)(((x[1] >> 60) | (x[2] << 4)) & (uint64_t)M62);
+    y[3] = (int64_t)(((x[2] >> 58) | (x[3] << 6)) & (uint64_t)M62);
+    y[4] = (int64_t)(x[3] >> 56);
+  };
+  uint64_t pinv = p[0];  // p^-1 mod 2^64 by Newton's iteration (p odd: correct to 3 bits, doubling each round)
+  for (int i = 0; i < 6; i++) pinv *= 2 - p[0] * pinv;
+  int64_t f[5], g[5];
+  to62(p, f);
+  to62(a, g);
+  uint64_t d[4] = {0, 0, 0, 0}, e[4] = {1, 0, 0, 0};  // f = d a, g = e a (mod p), both kept in [0, p)
+  int64_t eta = -1;                                    // eta = -delta
+  auto mul_add_shift = [&](int64_t cu, const uint64_t* x, int64_t cv, const uint64_t* y, uint64_t* o) {
+    // o = (cu x + cv y) / 2^62 mod p for |cu|, |cv| <= 2^62 and x, y in [0, p): a negative coefficient takes p - operand, the sum
+    // S < 2^63 p gets the multiple m p that clears its low 62 bits (one Montgomery step), (S + m p) / 2^62 < 3 p
+    uint64_t xx[4], yy[4];
+    auto cond_neg = [&](bool neg, const uint64_t* s, uint64_t* t) {
+      if (!neg || (s[0] | s[1] | s[2] | s[3]) == 0) { std::memcpy(t, s, 32); return; }
+      u128 bo = 0;
+      for (int i = 0; i < 4; i++) {
+        u128 df = (u128)p[i] - s[i] - (uint64_t)bo;
+        t[i] = (uint64_t)df;
+        bo = (df >> 64) & 1;
+      }
+    };
+    cond_neg(cu < 0, x, xx);
+    cond_neg(cv < 0, y, yy);
+    const uint64_t mu = (uint64_t)(cu < 0 ? -cu : cu), mv = (uint64_t)(cv < 0 ? -cv : cv);
+    uint64_t S[5];
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 lo = (u128)mu * xx[i], hi = (u128)mv * yy[i];
+      c += (uint64_t)lo;
+      c += (uint64_t)hi;
+      S[i] = (uint64_t)c;
+      c = (c >> 64) + (lo >> 64) + (hi >> 64);
+    }
+    S[4] = (uint64_t)c;
+    const uint64_t m = (0 - S[0] * pinv) & (uint64_t)M62;
+    c = 0;
+    uint64_t T[5];
+    for (int i = 0; i < 4; i++) {
+      u128 pr = (u128)m * p[i];
+      c += (u128)S[i] + (uint64_t)pr;
+      T[i] = (uint64_t)c;
+      c = (c >> 64) + (pr >> 64);
+    }
+    c += S[4];
+    T[4] = (uint64_t)c;
+    uint64_t r[4];
+    for (int i = 0; i < 4; i++) r[i] = (T[i] >> 62) | (T[i + 1] << 2);  // / 2^62 (the value is below 3 p < 2^256)
+    for (int round = 0; round < 2; round++) {
+      bool ge = true;
+      for (int i = 3; i >= 0; i--) {
+        if (r[i] > p[i]) break;
+        if (r[i] < p[i]) { ge = false; break; }
+      }
+      if (!ge) break;
+      u128 bo = 0;
+      for (int i = 0; i < 4; i++) {
+        u128 df = (u128)r[i] - p[i] - (uint64_t)bo;
+        r[i] = (uint64_t)df;
+        bo = (df >> 64) & 1;
+      }
+    }
+    std::memcpy(o, r, 32);
+  };
+  for (int batch = 0; batch < 13; batch++) {
+    if ((g[0] | g[1] | g[2] | g[3] | g[4]) == 0) break;
+    // 62 division steps on the low words; (u, v; q, r) scaled by 2^62
+    uint64_t u = 1, v = 0, q = 0, r = 1, fl = (uint64_t)f[0] | ((uint64_t)f[1] << 62), gl = (uint64_t)g[0] | ((uint64_t)g[1] << 62);
+    for (int i = 0; i < 62; i++) {
+      uint64_t c1 = (uint64_t)(eta >> 63), c2 = 0 - (gl & 1);
+      const uint64_t x = (fl ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+      gl += x & c2; q += y & c2; r += z & c2;
+      c1 &= c2;
+      eta = (int64_t)(((uint64_t)eta ^ c1) - (c1 + 1));
+      fl += gl & c1; u += q & c1; v += r & c1;
+      gl >>= 1; u <<= 1; v <<= 1;
+    }
+    const int64_t su = (int64_t)u, sv = (int64_t)v, sq = (int64_t)q, sr = (int64_t)r;
+    // f, g <- (u f + v g, q f + r g) / 2^62 over signed 62-bit limbs
+    i128 cf = (i128)su * f[0] + (i128)sv * g[0], cg = (i128)sq * f[0] + (i128)sr * g[0];
+    cf >>= 62; cg >>= 62;
+    for (int i = 1; i < 5; i++) {
+      cf += (i128)su * f[i] + (i128)sv * g[i];
+      cg += (i128)sq * f[i] + (i128)sr * g[i];
+      f[i - 1] = (int64_t)cf & M62; cf >>= 62;
+      g[i - 1] = (int64_t)cg & M62; cg >>= 62;
+    }
+    f[4] = (int64_t)cf;
+    g[4] = (int64_t)cg;
+    uint64_t nd[4], ne[4];
+    mul_add_shift(su, d, sv, e, nd);
+    mul_add_shift(sq, d, sr, e, ne);
+    std::memcpy(d, nd, 32);
+    std::memcpy(e, ne, 32);
+  }
+  if ((g[0] | g[1] | g[2] | g[3] | g[4]) != 0) return false;
+  // f = +1 or -1 (gcd 1): the inverse is d or p - d
+  const bool plus = f[0] == 1 && (f[1] | f[2] | f[3] | f[4]) == 0;
+  const bool minus = f[0] == M62 && f[1] == M62 && f[2] == M62 && f[3] == M62 && f[4] == -1;
+  if (!plus && !minus) return false;
+  if (plus) {
+    std::memcpy(out, d, 32);
+  } else {
+    u128 bo = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 df = (u128)p[i] - d[i] - (uint64_t)bo;
+      out[i] = (uint64_t)df;
+      bo = (df >> 64) & 1;
+    }
+  }
+  return true;
+}
+}  // namespace detail
 namespace fr {
 typedef unsigned __int128 u128;
 constexpr uint64_t MODULUS[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
 constexpr uint64_t INV = 0xc2e1f593efffffffULL;
 constexpr Fr ONE = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}};
 constexpr Fr R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+constexpr Fr R3 = {{0x5e94d8e1b4bf0040ULL, 0x2a489cbe1cfbb6b8ULL, 0x893cc664a19fcfedULL, 0x0cf8594b7fcc657cULL}};  // 2^768 mod r
 constexpr uint32_t S = 28;
 
 inline Fr mul(const Fr& a, const Fr& b) {
@@ -172,9 +302,15 @@ inline Fr pow_u64(const Fr& a, uint64_t e) {
   uint64_t ee[4] = {e, 0, 0, 0};
   return pow(a, ee);
 }
-inline Fr invert(const Fr& a) {  // a^(r-2); the crate returns CtOption, callers here never pass zero
+inline Fr invert_fermat(const Fr& a) {  // a^(r-2): the definition, kept as the cross-check of invert()
   uint64_t e[4] = {MODULUS[0] - 2, MODULUS[1], MODULUS[2], MODULUS[3]};
   return pow(a, e);
+}
+inline Fr invert(const Fr& a) {  // the crate returns CtOption, callers here never pass zero (0 -> 0, as a^(r-2) gives)
+  if ((a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0) return a;
+  Fr t;  // a = A R: the integer inverse is A^-1 R^-1, and (A^-1 R^-1)(R^3) R^-1 = A^-1 R
+  if (!detail::inv_mod_odd(a.l, MODULUS, t.l)) return invert_fermat(a);
+  return mul(t, R3);
 }
 inline std::vector<Fr> batch_invert(const std::vector<Fr>& v) {
   std::vector<Fr> out(v.size());

@@ -626,9 +626,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   }
   slot++;  // the random polynomial's slot
   check(h2mi_msm_flush(), "flush");
-  check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");
   write_points(slot);
   const Fr y = tr.squeeze_challenge();
+  // joined AFTER the read-back: the copy runs on the library stream, and a join in front of it made the transcript wait for every
+  // transform of the side stream instead of the bucket reductions only
+  check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");
   // quotient
   DeviceVec& h = ws.take(ext);
   {

@@ -108,7 +108,8 @@ inline E mul(const E& a, const E& b) {
   std::memcpy(r.l, t, 32);
   return r;
 }
-inline E invert(const E& a) {  // a^(q-2)
+constexpr E R3 = {{0xb1cd6dafda1530dfULL, 0x62f210e6a7283db6ULL, 0xef7f0b0c0ada0afbULL, 0x20fd6e902d592544ULL}};  // 2^768 mod q
+inline E invert_fermat(const E& a) {  // a^(q-2): the definition, kept as the cross-check of invert()
   const uint64_t e[4] = {MODULUS[0] - 2, MODULUS[1], MODULUS[2], MODULUS[3]};
   E r = ONE;
   for (int i = 255; i >= 0; i--) {
@@ -116,6 +117,12 @@ inline E invert(const E& a) {  // a^(q-2)
     if ((e[i >> 6] >> (i & 63)) & 1) r = mul(r, a);
   }
   return r;
+}
+inline E invert(const E& a) {  // division steps on the integer behind the Montgomery form (h2mi.hpp detail::inv_mod_odd), then back: ~1.5 us, not ~18
+  if ((a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0) return a;
+  E t;
+  if (!h2mi::detail::inv_mod_odd(a.l, MODULUS, t.l)) return invert_fermat(a);
+  return mul(t, R3);
 }
 }  // namespace fq
 inline G1Affine normalize_host(const G1& p) {
@@ -765,7 +772,9 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");
   for (uint32_t m = 0; m < na; m++) commit(params.g_lagrange_handle(), z[m]->p, m);
   check(h2mi_msm_flush(), "flush");
-  // coefficient / extended forms of z, queued behind the commitments
+  // coefficient / extended forms of z, queued behind the commitments on the library stream.  (Round 4 tried the side stream, so that the
+  // read-back of the phase's points would not queue behind them: at 2^16 rows the proof got 0.2 ms SLOWER — the transforms then run beside
+  // the commitments' partition and bucket-reduction chain, whose latency is what the phase waits for, and slow it: DESIGN 4.5)
   for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *z[j], *z_polys[j], *z_cosets[j]);
   check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");  // evaluate_h and the openings read the advice forms
   write_phase_points(na + 1);

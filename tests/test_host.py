@@ -301,3 +301,39 @@ def test_bench_honours_a_preset_world_size_and_rejects_mismatch():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in r.stderr and "starting" not in r.stderr
+
+
+def test_cpp_host_single_element_inversion_matches_pow():
+    """include/h2mi.hpp detail::inv_mod_odd (division steps in batches of 62: what fr::invert / fq::invert of the C++ host use on the
+    transcript's critical path) against Python's pow(x, -1, p), edge values and random ones, both fields, plain and Montgomery forms."""
+    import ctypes as C
+
+    src = os.path.join(ROOT, "tests", "host", "inv_host.cpp")
+    so = os.path.join(ROOT, "tests", "host", "libinvhost.so")
+    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "include", "h2mi_plonk.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.h2t_inv_plain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.h2t_inv_mont.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(0x1217)
+    for field, mod in ((0, o.Q), (1, o.R)):
+        vals = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, 1 << 62, (1 << 62) - 1, 1 << 124, 1 << 253, (1 << 253) + 1,
+                (1 << 64) - 1, 1 << 64, (1 << 128) - 1, (1 << 192) + 1, pow(2, -1, mod), pow(3, -1, mod), pow(2, -62, mod), pow(2, -124, mod)]
+        vals += [int.from_bytes(rng.bytes(32), "little") % (mod - 1) + 1 for _ in range(20000)]
+        vals += [int(v) for v in rng.integers(1, 1 << 20, size=2000)]  # small values: f and g of very different sizes
+        n = len(vals)
+        A = np.array([[(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)] for v in vals], dtype=np.uint64)
+        out = np.zeros_like(A)
+        ok = np.zeros(n, dtype=np.uint8)
+        L.h2t_inv_plain(field, A.ctypes.data, out.ctypes.data, ok.ctypes.data, n)
+        assert ok.all()  # the fast path itself, not the Fermat fallback behind it
+        got = [sum(int(out[j, i]) << (64 * i) for i in range(4)) for j in range(n)]
+        assert got == [pow(v, -1, mod) for v in vals]
+        # Montgomery forms through fr::invert / fq::invert, against the exponentiation they replace; zero stays zero
+        M = o.pack([0] + vals[:3000], mod)
+        fast, fermat = np.zeros_like(M), np.zeros_like(M)
+        L.h2t_inv_mont(field, 0, M.ctypes.data, fast.ctypes.data, len(M))
+        L.h2t_inv_mont(field, 1, M.ctypes.data, fermat.ctypes.data, len(M))
+        assert np.array_equal(fast, fermat)
+        assert o.unpack(fast, mod) == [0] + [pow(v, -1, mod) for v in vals[:3000]]
