@@ -283,7 +283,7 @@ __device__ __forceinline__ void for_each_digit(const fe& s, uint32_t c_rt, uint3
 // so subtracting the majority value v turns the column into a sparse one (zero digits are never materialised) plus
 // one more scalar.  k_msm_pick_shift samples 64 evenly spaced scalars and takes v = the value held by >= 40 of them,
 // else 0 (uniform data: nothing changes).  Only for MSMs over all registered bases (B is their sum).
-__global__ void __launch_bounds__(64) k_msm_pick_shift(const fe* scalars, size_t n, fe* shift_out) {
+__device__ __forceinline__ void msm_pick_shift_body(const fe* scalars, size_t n, fe* shift_out) {
   __shared__ fe smp[64];
   const uint32_t lane = threadIdx.x;
   size_t idx = (n / 64) * lane + n / 128;
@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(64) k_msm_pick_shift(const fe* scalars, size_t
   const uint64_t winners = __ballot(same >= 40);
   if (lane == 0) fe_store(shift_out, winners ? smp[__ffsll((unsigned long long)winners) - 1] : fe_zero());
 }
+__global__ void __launch_bounds__(64) k_msm_pick_shift(const fe* scalars, size_t n, fe* shift_out) { msm_pick_shift_body(scalars, n, shift_out); }
 // scalar i of an MSM over n (+ 1) points as canonical integer: s_i - shift for the caller's scalars, shift itself for
 // the sum point
 // A zero scalar (an unassigned row; every row of a constant column after the shift) skips the Montgomery conversion: real
@@ -322,8 +323,8 @@ __device__ __forceinline__ fe msm_scalar(const fe* scalars, size_t i, size_t n, 
 }
 
 template <uint32_t CT>
-__global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb,
-                                                         uint32_t nbins, uint32_t ntiles, uint32_t* cnt_out, uint32_t* tile_live) {
+__device__ __forceinline__ void msm_bin_count_body(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb, uint32_t nbins,
+                                                   uint32_t ntiles, uint32_t* cnt_out, uint32_t* tile_live) {
   __shared__ uint32_t cnt[NBINS_MAX];
   __shared__ uint32_t any_live;
   const uint32_t tid = threadIdx.x;
@@ -345,13 +346,18 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size
   if (tid < nbins) cnt_out[(size_t)tid * ntiles + blockIdx.x] = cnt[tid];
   if (blockIdx.x == 0 && tid == 0) cnt_out[(size_t)nbins * ntiles] = 0;  // the scan leaves the total there
 }
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_count(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb,
+                                                         uint32_t nbins, uint32_t ntiles, uint32_t* cnt_out, uint32_t* tile_live) {
+  msm_bin_count_body<CT>(scalars, n, shift, c, W, lb, nbins, ntiles, cnt_out, tile_live);
+}
 
 extern __shared__ uint4 h2_msm_smem[];
 
 template <uint32_t CT>
-__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W,
-                                                           uint32_t lb, uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
-                                                           void* keys_out_, const uint32_t* tile_live) {
+__device__ __forceinline__ void msm_bin_scatter_body(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
+                                                     uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out, void* keys_out_,
+                                                     const uint32_t* tile_live) {
   constexpr bool WIDE = CT >= WIDE_MIN_C;  // in-bin keys of up to 10 bits: staged and written as 16-bit values
   if (!tile_live[blockIdx.x]) return;  // no non-zero scalar in this tile (k_msm_bin_count): block-uniform, before any barrier
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
@@ -451,11 +457,17 @@ __global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, si
     }
   }
 }
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W,
+                                                           uint32_t lb, uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out,
+                                                           void* keys_out_, const uint32_t* tile_live) {
+  msm_bin_scatter_body<CT>(scalars, n, shift, n_reg, c, W, lb, nbins, ntiles, base, vals_out, keys_out_, tile_live);
+}
 
 constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 512 bins)
-__global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
-                                                             uint32_t nbins, uint32_t lb, uint32_t s0_fixed, uint32_t nb, uint32_t* vals_out,
-                                                             uint32_t* off, uint32_t* np0, uint32_t* np1, uint32_t* s0_out) {
+__device__ __forceinline__ void msm_bin_sort_body(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles, uint32_t nbins,
+                                                  uint32_t lb, uint32_t s0_fixed, uint32_t nb, uint32_t* vals_out, uint32_t* off, uint32_t* np0,
+                                                  uint32_t* np1, uint32_t* s0_out) {
   __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
   __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
   __shared__ uint32_t stage[P2_CH];
@@ -551,6 +563,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys
     }
     __syncthreads();
   }
+}
+__global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles,
+                                                             uint32_t nbins, uint32_t lb, uint32_t s0_fixed, uint32_t nb, uint32_t* vals_out,
+                                                             uint32_t* off, uint32_t* np0, uint32_t* np1, uint32_t* s0_out) {
+  msm_bin_sort_body(keys_in, vals_in, base, ntiles, nbins, lb, s0_fixed, nb, vals_out, off, np0, np1, s0_out);
 }
 
 // k_msm_bin_sort for wide windows: up to NQW = 1024 buckets per bin, 16-bit keys, one shared histogram (1024 counters
@@ -707,8 +724,8 @@ __device__ __forceinline__ f29 tab_y(const tab_entry& p) { return f29_unpack(p.y
 // partial sums are numbered in array order, so bucket b owns np0[b] = 1 + (#chunk starts strictly inside
 // its run) consecutive partials starting at toff[b] (the exclusive scan of np0) — the layout the fold
 // expects.  Gathers table points (64 B), mixed additions in the lazy 29-bit-limb representation.
-__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb,
-                                                    const uint32_t* s0_dev, const uint8_t* table, uint8_t* part) {
+__device__ __forceinline__ void msm_accum_body(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb, const uint32_t* s0_dev,
+                                               const uint8_t* table, uint8_t* part) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = off[nb];
   const uint32_t s0 = *s0_dev;
@@ -746,6 +763,66 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
     xyzz29_madd(acc, x2, y2);
   }
   part_store(part + (size_t)pidx * PART_BYTES, acc);
+}
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb,
+                                                    const uint32_t* s0_dev, const uint8_t* table, uint8_t* part) {
+  msm_accum_body(entries, off, toff, nb, s0_dev, table, part);
+}
+
+// ---- batched head: the partition and the accumulation of up to HEAD_BATCH MSMs of one length over ONE base set as ONE set of launches
+// (blockIdx.y = MSM; round 4).  At 2^16 rows and below a prover phase's three or four commitments were issued at the HOST's pace: eight
+// launches and six event operations per MSM, ~77 us each on the compiled host, while the kernels themselves run 4 - 13 us (proof
+// timeline at 2^16: the three z commitments' partitions occupy 270 us of the phase one after the other).  The kernels are the
+// single-MSM bodies behind a descriptor; h2mi_msm_bn254_g1_batch_dev chooses this form up to HEAD_BATCH_MAX_N points — beyond, the
+// stage-by-stage pipelining of consecutive MSMs (partition of one beside the accumulation of another) is worth more than the launches.
+constexpr uint32_t HEAD_BATCH = 4;
+struct HeadDesc {
+  const fe* scalars;
+  fe* shift;  // nullptr: no dominant-value shift
+  uint32_t *bincnt, *tile_live, *binseg, *binbase, *vals0, *vals1, *off, *np0, *np1, *toff0, *toff1, *s0_dev;
+  void* bkeys;
+  uint8_t* part0;
+};
+struct HeadBatch {
+  HeadDesc d[HEAD_BATCH];
+};
+__global__ void __launch_bounds__(64) k_msm_pick_shift_b(const HeadBatch hb, size_t n) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  msm_pick_shift_body(d.scalars, n, d.shift);
+}
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_count_b(const HeadBatch hb, size_t n, uint32_t c, uint32_t W, uint32_t lb, uint32_t nbins,
+                                                           uint32_t ntiles) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  msm_bin_count_body<CT>(d.scalars, n, d.shift, c, W, lb, nbins, ntiles, d.bincnt, d.tile_live);
+}
+template <uint32_t CT>
+__global__ void __launch_bounds__(P1_TS) k_msm_bin_scatter_b(const HeadBatch hb, size_t n, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
+                                                             uint32_t nbins, uint32_t ntiles) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  msm_bin_scatter_body<CT>(d.scalars, n, d.shift, n_reg, c, W, lb, nbins, ntiles, d.binbase, d.vals0, d.bkeys, d.tile_live);
+}
+__global__ void __launch_bounds__(P2_THREADS) k_msm_bin_sort_b(const HeadBatch hb, uint32_t ntiles, uint32_t nbins, uint32_t lb, uint32_t s0_fixed,
+                                                               uint32_t nb) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  msm_bin_sort_body((const uint8_t*)d.bkeys, d.vals0, d.binbase, ntiles, nbins, lb, s0_fixed, nb, d.vals1, d.off, d.np0, d.np1, d.s0_dev);
+}
+__global__ void __launch_bounds__(256) k_msm_accum_b(const HeadBatch hb, uint32_t nb, const uint8_t* table) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  msm_accum_body(d.vals1, d.off, d.toff0, nb, d.s0_dev, table, d.part0);
+}
+// the scans of scan.cuh over the batch's arrays: blockIdx.y = MSM (bins), blockIdx.y = array and blockIdx.z = MSM (task counts)
+__global__ void __launch_bounds__(1024) k_scan_segsum_bins_b(const HeadBatch hb, uint32_t m) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  scan_segsum_body<SCAN_SEG_BINS>(d.bincnt, m, d.binseg);
+}
+__global__ void __launch_bounds__(1024) k_scan_seg_bins_b(const HeadBatch hb, uint32_t m) {
+  const HeadDesc& d = hb.d[blockIdx.y];
+  scan_seg_body<SCAN_SEG_BINS>(d.bincnt, d.binbase, m, d.binseg);
+}
+__global__ void __launch_bounds__(1024) k_scan_seg_tasks_b(const HeadBatch hb, uint32_t m) {
+  const HeadDesc& d = hb.d[blockIdx.z];
+  scan_seg_body<SCAN_SEG_TASKS>(blockIdx.y ? d.np1 : d.np0, blockIdx.y ? d.toff1 : d.toff0, m, nullptr);
 }
 
 // ---- bucket reduction ("tail"), batched --------------------------------------------------------------
@@ -1077,7 +1154,7 @@ __global__ void __launch_bounds__(64) k_msm_small_multiples(uint8_t* table, size
   }
 }
 
-__global__ void __launch_bounds__(64) k_msm_small_digits(const fe* scalars, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W, uint8_t* dig) {
+__device__ __forceinline__ void msm_small_digits_body(const fe* scalars, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W, uint8_t* dig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const fe s = msm_scalar(scalars, i, n, nullptr);
@@ -1101,6 +1178,16 @@ __global__ void __launch_bounds__(64) k_msm_small_digits(const fe* scalars, uint
     }
     dig[(size_t)w * n_reg + i] = (uint8_t)(mag ? (neg << 7 | mag) : 0u);
   }
+}
+__global__ void __launch_bounds__(64) k_msm_small_digits(const fe* scalars, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W, uint8_t* dig) {
+  msm_small_digits_body(scalars, n, n_reg, c, W, dig);
+}
+struct SmallHeadBatch {  // the digit kernels of up to HEAD_BATCH MSMs over one small base set as one launch (blockIdx.y = MSM)
+  const fe* scalars[HEAD_BATCH];
+  uint8_t* dig[HEAD_BATCH];
+};
+__global__ void __launch_bounds__(64) k_msm_small_digits_b(const SmallHeadBatch hb, uint32_t n, uint32_t n_reg, uint32_t c, uint32_t W) {
+  msm_small_digits_body(hb.scalars[blockIdx.y], n, n_reg, c, W, hb.dig[blockIdx.y]);
 }
 
 // segmented tree sums in LDS: nseg segments of len (a power of two) consecutive XYZZ values each; segment k's sum ends
@@ -1512,6 +1599,154 @@ static TailDesc tail_desc(const Bases* B, const Slot& S);
 // (msm_join_all: h2mi_join / h2mi_sync / h2mi_memcpy_d2h), a full batch, or the reuse of the slot.
 // On a caller-provided stream everything runs in order on that stream.
 static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
+static bool g_head_batch = true;  // h2mi_dbg_msm_batch(0): h2mi_msm_bn254_g1_batch_dev issues its MSMs one by one (parity tests, A/B)
+constexpr size_t HEAD_BATCH_MAX_N = (size_t)1 << 17;  // largest base set whose MSMs are partitioned and accumulated as a batch
+
+// `m` <= HEAD_BATCH MSMs of n scalars each over B, results to d_out + 96 j: what m calls of msm_dev would compute, with the partition
+// and the accumulation of all m as ONE set of launches (narrow windows, library stream).  Slots, events and the deferred bucket
+// reductions are those of m single calls.
+static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s) {
+  const uint32_t nb = B->nb, W = B->W;
+  const bool shifted = B->has_sum && n == B->n;
+  const size_t n_eff = n + (shifted ? 1 : 0);
+  const uint32_t total = (uint32_t)(n_eff * W);
+  hipStream_t hs = ctx().head_stream, as = ctx().accum_stream;
+  uint32_t s0_fixed = chunk_override();
+  while (s0_fixed && s0_fixed < S0_MAX && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) s0_fixed++;
+  if (s0_fixed && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) return H2MI_ERANGE;
+  if ((size_t)P1_TS * W * 6 > 150 * 1024) return H2MI_ERANGE;
+  Slot* slots[HEAD_BATCH];
+  HeadBatch hb;
+  memset(&hb, 0, sizeof(hb));
+  for (size_t j = 0; j < m; j++) {
+    Slot& S = B->slot[B->next_slot];
+    B->last_slot = B->next_slot;
+    B->next_slot = (B->next_slot + 1) % B->nslot;
+    if (S.tail_deferred) {  // this slot still waits for its reduction (never one of this batch: m <= nslot)
+      int rc = flush_tails();
+      if (rc) return rc;
+    }
+    if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+    if (S.tail_pending && S.last_stream != s) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+    S.last_stream = s;
+    slots[j] = &S;
+    HeadDesc& d = hb.d[j];
+    d.scalars = (const fe*)d_scalars[j];
+    d.shift = shifted ? S.shift : nullptr;
+    d.bincnt = S.bincnt; d.tile_live = S.tile_live; d.binseg = S.binseg; d.binbase = S.binbase;
+    d.vals0 = S.vals[0]; d.vals1 = S.vals[1]; d.bkeys = S.bkeys;
+    d.off = S.off; d.np0 = S.np[0]; d.np1 = S.np[1]; d.toff0 = S.toff[0]; d.toff1 = S.toff[1]; d.s0_dev = S.s0_dev;
+    d.part0 = S.part[0];
+  }
+  for (size_t j = m; j < HEAD_BATCH; j++) hb.d[j] = hb.d[0];  // never launched (gridDim.y = m)
+  const uint32_t ntiles = ceil_div_u32(n_eff, P1_TS), mm = (uint32_t)m;
+  static bool attr_set = false;
+  if (!attr_set) {
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+#define H2_BIN_COUNT_B(CT) H2_LAUNCH("k_msm_bin_count", k_msm_bin_count_b<CT>, dim3(ntiles, mm), P1_TS, 0, s, hb, n, B->c, W, B->lb, B->nbins, ntiles)
+#define H2_BIN_SCATTER_B(CT) \
+  H2_LAUNCH("k_msm_bin_scatter", k_msm_bin_scatter_b<CT>, dim3(ntiles, mm), P1_TS, (size_t)P1_TS * W * 6, s, hb, n, B->stride, B->c, W, B->lb, B->nbins, ntiles)
+  if (shifted) H2_LAUNCH("k_msm_pick_shift", k_msm_pick_shift_b, dim3(1, mm), 64, 0, s, hb, n);
+  switch (B->c) {
+    case 13: H2_BIN_COUNT_B(13); break;
+    case 15: H2_BIN_COUNT_B(15); break;
+    case 16: H2_BIN_COUNT_B(16); break;
+    case 17: H2_BIN_COUNT_B(17); break;
+    default: H2_BIN_COUNT_B(0); break;
+  }
+  const uint32_t cells = B->nbins * ntiles;
+  const uint32_t nseg = ceil_div_u32(cells, SCAN_SEG_BINS);
+  if (nseg > 1) H2_LAUNCH("k_scan_segsum", k_scan_segsum_bins_b, dim3(nseg, mm), 1024, 0, s, hb, cells);
+  H2_LAUNCH("k_scan_seg_bins", k_scan_seg_bins_b, dim3(nseg, mm), 1024, 0, s, hb, cells);
+  switch (B->c) {
+    case 13: H2_BIN_SCATTER_B(13); break;
+    case 15: H2_BIN_SCATTER_B(15); break;
+    case 16: H2_BIN_SCATTER_B(16); break;
+    case 17: H2_BIN_SCATTER_B(17); break;
+    default: H2_BIN_SCATTER_B(0); break;
+  }
+#undef H2_BIN_COUNT_B
+#undef H2_BIN_SCATTER_B
+  // one event for the batch's inputs; the slots' own events for what later calls wait on per slot
+  H2_HIP(hipEventRecord(slots[0]->input_ready, s));
+  H2_HIP(hipStreamWaitEvent(hs, slots[0]->input_ready, 0));
+  for (size_t j = 0; j < m; j++) {
+    Slot& S = *slots[j];
+    if (S.accum_pending) H2_HIP(hipStreamWaitEvent(hs, S.accum_done, 0));
+    if (S.tail_pending) H2_HIP(hipStreamWaitEvent(hs, S.tail_done, 0));
+    S.tail_pending = S.accum_pending = S.head_pending = false;
+  }
+  H2_LAUNCH("k_msm_bin_sort", k_msm_bin_sort_b, dim3(B->nbins, mm), P2_THREADS, 0, hs, hb, ntiles, B->nbins, B->lb, s0_fixed, nb);
+  H2_LAUNCH("k_scan_seg_tasks", k_scan_seg_tasks_b, dim3(1, 2, mm), 1024, 0, hs, hb, nb);
+  const uint32_t chunks0 = s0_fixed ? (uint32_t)(((uint64_t)total + s0_fixed - 1) / s0_fixed) : std::min(accum_rounds(total) * ACCUM_RESIDENT_CHUNKS, total);
+  const uint32_t tasks0 = chunks0 + nb;
+  for (size_t j = 0; j < m; j++) {
+    H2_HIP(hipEventRecord(slots[j]->head_done, hs));
+    slots[j]->head_pending = true;
+    slots[j]->head_ever = true;
+  }
+  H2_HIP(hipStreamWaitEvent(as, slots[m - 1]->head_done, 0));
+  static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
+  H2_LAUNCH("k_msm_accum", k_msm_accum_b, dim3(ceil_div_u32(chunks0, 256), mm), 256, accum_lds, as, hb, nb, (const uint8_t*)B->table);
+  for (size_t j = 0; j < m; j++) {
+    Slot& S = *slots[j];
+    S.d_out = (char*)d_out + 96 * j;
+    S.tasks1 = tasks0 / S1 + nb;
+    H2_HIP(hipEventRecord(S.accum_done, as));
+    S.accum_pending = true;
+    S.accum_ever = true;
+    S.tail_deferred = true;
+    g_deferred.push_back({B, &S});
+  }
+  if (g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
+  return H2MI_OK;
+}
+
+// the small path's batch: one digit launch for the m MSMs; their accumulate / final pair is deferred and batched as ever
+static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s) {
+  SmallHeadBatch hb;
+  memset(&hb, 0, sizeof(hb));
+  Slot* slots[HEAD_BATCH];
+  for (size_t j = 0; j < m; j++) {
+    Slot& S = B->slot[B->next_slot];
+    B->last_slot = B->next_slot;
+    B->next_slot = (B->next_slot + 1) % B->nslot;
+    if (S.tail_deferred) {
+      int rc = flush_tails();
+      if (rc) return rc;
+    }
+    if (S.tail_ever && (S.tail_pending || S.last_stream != s)) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
+    if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
+    if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
+    S.tail_pending = S.accum_pending = S.head_pending = false;
+    S.last_stream = s;
+    S.d_out = (char*)d_out + 96 * j;
+    S.small_n = (uint32_t)n;
+    hb.scalars[j] = (const fe*)d_scalars[j];
+    hb.dig[j] = S.sdig;
+    slots[j] = &S;
+  }
+  for (size_t j = m; j < HEAD_BATCH; j++) { hb.scalars[j] = hb.scalars[0]; hb.dig[j] = hb.dig[0]; }
+  H2_LAUNCH("k_msm_small_digits", k_msm_small_digits_b, dim3(ceil_div_u32(n, 64), (uint32_t)m), 64, 0, s, hb, (uint32_t)n, (uint32_t)B->n, B->sc, B->sW);
+  for (size_t j = 0; j < m; j++) {
+    Slot& S = *slots[j];
+    H2_HIP(hipEventRecord(S.accum_done, s));  // "inputs consumed": what the deferred pair waits for
+    S.accum_pending = true;
+    S.accum_ever = true;
+    S.tail_deferred = true;
+    S.small_deferred = true;
+    g_deferred.push_back({B, &S});
+  }
+  if (g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
+  return H2MI_OK;
+}
+
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
   if (B->small && g_small_path) return msm_small(B, d_scalars, n, d_out, s);
   const uint32_t nb = B->nb, W = B->W;
@@ -2214,6 +2449,39 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
   return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream));
 }
 
+int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_out_jacobian || !d_scalars || count == 0) return H2MI_EINVAL;
+  for (size_t j = 0; j < count; j++)
+    if (!d_scalars[j] && n != 0) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  auto it = g_bases.find(handle);
+  hipStream_t s = pick_stream(stream);
+  const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
+  static const bool eager = ab_env("H2MI_MSM_EAGER_TAIL") != nullptr;
+  // batched launches: a plain (unsharded) handle on the library stream, narrow windows or the small path, small enough that launch
+  // pace and not stage overlap is what the phase waits for; everything else is the loop the caller would have written
+  if (n != 0 && count > 1 && g_head_batch && pipelined && !eager && it != g_bases.end() && n <= it->second->n && it->second->n <= HEAD_BATCH_MAX_N) {
+    Bases* B = it->second;
+    const bool small = B->small && g_small_path;
+    if (small || B->seg_log == 0) {
+      for (size_t j0 = 0; j0 < count;) {
+        const size_t m = std::min({count - j0, (size_t)HEAD_BATCH, (size_t)B->nslot});
+        int rc = small ? msm_small_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s)
+                       : msm_dev_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s);
+        if (rc) return rc;
+        j0 += m;
+      }
+      return H2MI_OK;
+    }
+  }
+  for (size_t j = 0; j < count; j++) {
+    int rc = h2mi_msm_bn254_g1_dev(handle, d_scalars[j], n, (char*)d_out_jacobian + 96 * j, stream);
+    if (rc) return rc;
+  }
+  return H2MI_OK;
+}
+
 int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out[12]) {
   H2_REQUIRE_INIT();
   if (!out) return H2MI_EINVAL;
@@ -2287,6 +2555,11 @@ int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* 
   return H2MI_OK;
 }
 
+int h2mi_dbg_msm_batch(int on) {
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  g_head_batch = on != 0;
+  return H2MI_OK;
+}
 int h2mi_dbg_msm_small_path(int on) {
   H2_REQUIRE_INIT();
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);

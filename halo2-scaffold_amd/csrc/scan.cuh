@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t block_sum_1024(uint32_t v, uint32_t* wsum /*
   return t;
 }
 template <uint32_t SEG>
-__global__ void __launch_bounds__(1024) k_scan_segsum(const uint32_t* in, uint32_t m, uint32_t* segsum) {
+__device__ __forceinline__ void scan_segsum_body(const uint32_t* in, uint32_t m, uint32_t* segsum) {
   __shared__ uint32_t wsum[16];
   const uint32_t seg0 = blockIdx.x * SEG, len = min(SEG, m - seg0);
   uint32_t sum = 0;
@@ -46,13 +46,17 @@ __global__ void __launch_bounds__(1024) k_scan_segsum(const uint32_t* in, uint32
   if (threadIdx.x == 0) segsum[blockIdx.x] = t;
 }
 template <uint32_t SEG>
-__global__ void __launch_bounds__(1024) k_scan_seg(const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1, uint32_t m,
-                                                   const uint32_t* segsum) {
+__global__ void __launch_bounds__(1024) k_scan_segsum(const uint32_t* in, uint32_t m, uint32_t* segsum) {
+  scan_segsum_body<SEG>(in, m, segsum);
+}
+// one array: segment blockIdx.x of `in_` -> `out_`
+template <uint32_t SEG>
+__device__ __forceinline__ void scan_seg_body(const uint32_t* in_, uint32_t* out_, uint32_t m, const uint32_t* segsum) {
   __shared__ uint32_t wsum[16], wsum2[16];
   constexpr uint32_t NV = SEG / 4096;  // 16-byte vectors per thread
   const uint32_t seg = blockIdx.x, seg0 = seg * SEG, len = min(SEG, m - seg0);
-  const uint32_t* in = (blockIdx.y ? in1 : in0) + seg0;
-  uint32_t* out = (blockIdx.y ? out1 : out0) + seg0;
+  const uint32_t* in = in_ + seg0;
+  uint32_t* out = out_ + seg0;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t before = 0;  // sum of the earlier segments
   if (seg) {
@@ -95,6 +99,11 @@ __global__ void __launch_bounds__(1024) k_scan_seg(const uint32_t* in0, uint32_t
     for (uint32_t w = 0; w < 16; w++) t += wsum[w];
     out[len] = t;
   }
+}
+template <uint32_t SEG>
+__global__ void __launch_bounds__(1024) k_scan_seg(const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1, uint32_t m,
+                                                   const uint32_t* segsum) {
+  scan_seg_body<SEG>(blockIdx.y ? in1 : in0, blockIdx.y ? out1 : out0, m, segsum);
 }
 
 

@@ -95,9 +95,17 @@ def _write_phase_points(ws: ProverWorkspace, transcript, k: int):
 def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, lagrange: bool):
     """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join) and write the
     points to the transcript"""
-    for i, (buf, offset_elems) in enumerate(columns):
-        _commit(params, ws, buf, offset_elems, lagrange, i)
+    _commit_columns(params, ws, columns, lagrange)
     _write_phase_points(ws, transcript, len(columns))
+
+
+def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool):
+    """queue the commitments of one phase into result slots 0 .. len - 1 with ONE call (h2mi_msm_bn254_g1_batch_dev): below 2^17 rows
+    their partition and accumulation kernels are launched once for the whole phase"""
+    h = params.g_lagrange_handle if lagrange else params.g_handle
+    out = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
+    ptrs = (C.c_void_p * len(columns))(*[buf.ptr + (offset_elems + params.lo) * 32 for buf, offset_elems in columns])
+    check(lib.h2mi_msm_bn254_g1_batch_dev(h, ptrs, len(columns), params.n, out, None), "commit")
 
 
 def _commit(params: ParamsKZG, ws: ProverWorkspace, buf: DevBuf, offset_elems: int, lagrange: bool, slot: int):
@@ -140,8 +148,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
                 cells[r - lo] = _m(syn.advice[j][r])
             col.patch(cells, offset=lo * 32)
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
-    for i, c in enumerate(ws.advice):
-        _commit(params, ws, c, 0, True, i)
+    _commit_columns(params, ws, [(c, 0) for c in ws.advice], True)
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join below
     # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
     # y): on a side stream they run beside the commitments' bucket reductions, the transcript round trip and the
@@ -167,8 +174,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
                             active=pk.active_rows)
     for m, z in enumerate(ws.z):
         z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
-    for i, z in enumerate(ws.z):
-        _commit(params, ws, z, 0, True, i)
+    _commit_columns(params, ws, [(z, 0) for z in ws.z], True)
     check(lib.h2mi_msm_flush(), "flush")
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
     # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products

@@ -131,6 +131,17 @@ int h2mi_msm_adhoc_builds(uint64_t* builds_out);
 /* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
                           h2mi_stream_t stream);
+/* `count` MSMs of n scalars each over ONE registered base set — the commitments of a prover phase (create_proof commits a phase's
+ * advice columns, then its grand products, then the quotient's pieces, each group before one challenge: reference
+ * examples/standard_plonk.rs:41-49 through halo2_proofs' create_proof).  Result j goes to d_out_jacobian + 96 j; the results are the
+ * ones `count` calls of h2mi_msm_bn254_g1_dev in the same order would produce.  For base sets of up to 2^17 points on the library
+ * stream the partition and the accumulation of up to four MSMs run as ONE set of launches (the host could not issue a small MSM's eight
+ * launches as fast as the device ran them: DESIGN.md 4.1 (x)); larger base sets, caller streams and sharded handles take the loop.
+ * The scalars must stay untouched until work queued on `stream` after this call would run (as for the single form). */
+int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
+                                h2mi_stream_t stream);
+/* test hook: 0 makes h2mi_msm_bn254_g1_batch_dev issue its MSMs one by one (parity tests, A/B); 1 (default) batches. */
+int h2mi_dbg_msm_batch(int on);
 /* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */
 int h2mi_msm_set_canonical(int on);
 /* Base sets of at most 4096 points take a latency path of their own (narrow windows against a second table, three short

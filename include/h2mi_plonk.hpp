@@ -724,6 +724,10 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     for (const G1Affine& a : normalize_host_batch(jac)) tr.write_point(a);
   };
   auto commit = [&](uint64_t handle, const void* col, size_t slot) { check(h2mi_msm_bn254_g1_dev(handle, col, n, (char*)points.p + 96 * slot, nullptr), "commit"); };
+  // the commitments of one phase (results in slots 0 .. k-1): one call, so that small circuits get one set of launches for all of them
+  auto commit_phase = [&](uint64_t handle, const std::vector<const void*>& cols) {
+    check(h2mi_msm_bn254_g1_batch_dev(handle, cols.data(), cols.size(), n, points.p, nullptr), "commit");
+  };
 
   tr.common_scalar(pk.vk.transcript_repr);  // vk.hash_into
 
@@ -738,7 +742,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     for (const auto& kv : syn.advice[j]) patch(col, kv.first, kv.second);
     check(h2mi_memcpy_h2d_async((char*)col.p + (size_t)u * 32, &blind[(size_t)j * (bf + 1)], (bf + 1) * 32), "blinding rows");
   }
-  for (uint32_t j = 0; j < na; j++) commit(params.g_lagrange_handle(), advice[j]->p, j);
+  {
+    std::vector<const void*> cols;
+    for (uint32_t j = 0; j < na; j++) cols.push_back(advice[j]->p);
+    commit_phase(params.g_lagrange_handle(), cols);
+  }
   check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // the advice columns' coefficient / extended forms wait for no challenge: on the side stream they run beside the
   // transcript round trip and the permutation argument's latency-bound scans
@@ -770,7 +778,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)na * bf);
   for (uint32_t m = 0; m < na; m++)
     check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");
-  for (uint32_t m = 0; m < na; m++) commit(params.g_lagrange_handle(), z[m]->p, m);
+  {
+    std::vector<const void*> cols;
+    for (uint32_t m = 0; m < na; m++) cols.push_back(z[m]->p);
+    commit_phase(params.g_lagrange_handle(), cols);
+  }
   check(h2mi_msm_flush(), "flush");
   // coefficient / extended forms of z, queued behind the commitments on the library stream.  (Round 4 tried the side stream, so that the
   // read-back of the phase's points would not queue behind them: at 2^16 rows the proof got 0.2 ms SLOWER — the transforms then run beside
@@ -801,7 +813,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     check(h2mi_fr_scale_powers_dev(h.p, ext, d.get_g_coset_inv().l, d.get_extended_ifft_divisor().l, nullptr), "distribute_powers_zeta");
   }
   const uint32_t pieces = StandardPlonk::CS_DEGREE - 1;
-  for (uint32_t i = 0; i < pieces; i++) commit(params.g_handle(), (char*)h.p + (size_t)i * n * 32, i);
+  {
+    std::vector<const void*> cols;
+    for (uint32_t i = 0; i < pieces; i++) cols.push_back((char*)h.p + (size_t)i * n * 32);
+    commit_phase(params.g_handle(), cols);
+  }
   write_phase_points(pieces);
   const Fr x = tr.squeeze_challenge();
   const Fr xn = fr::pow_u64(x, n);

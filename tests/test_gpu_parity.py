@@ -1099,3 +1099,65 @@ def test_msm_wide_windows_forced_at_small_sizes(gpu, c):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_big_golden.py", "-x", "-q", "-m", "gpu", "-k", "standard_plonk_k16 and python_host",
                         "-p", "no:cacheprovider"], cwd=root, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,small", [(300, 1), (300, 0), (4096, 1), (5000, 0), (1 << 15, 0), (1 << 17, 0), (1 << 18, 0)])
+def test_msm_batch_entry_matches_single_calls_and_oracle(gpu, n, small):
+    """round 4: h2mi_msm_bn254_g1_batch_dev — the commitments of a prover phase as ONE set of partition / accumulation launches (up to
+    four MSMs, base sets up to 2^17 points; 2^18 takes the loop).  Every result must be the group element the C restatement of
+    best_multiexp gives and the one a single call gives: uniform, sparse, constant (the dominant-value shift) and zero columns in one
+    batch, counts below / at / above the batch and slot limits, a prefix of the base set (no shift), and batches queued back to back
+    before one join (slot reuse across batches)."""
+    from oracle import cref
+    from halo2_scaffold_amd.device import DevBuf
+
+    bases = cref.g1_mul_gen(o.random_field_limbs(n, 4100 + n % 97), 8)
+    h = C.c_uint64()
+    assert gpu.lib.h2mi_bases_register(bases.ctypes.data, n, C.byref(h)) == 0
+    const = np.tile(o.random_field_limbs(1, 78)[0], (n, 1))
+    const[n // 3] = o.random_field_limbs(1, 79)[0]  # a grand product: one value except at a few rows
+    cols = [o.random_field_limbs(n, 5000), o.witness_like_limbs(n, 6), const, np.zeros((n, 4), dtype=np.uint64), o.random_field_limbs(n, 5001),
+            np.tile(o.pack([o.R - 1], o.R)[0], (n, 1)), o.witness_like_limbs(n, 7), o.random_field_limbs(n, 5002), const.copy()]
+    want = [o.unpack_jacobian(cref.msm(np.ascontiguousarray(c), bases, 8)) for c in cols]
+    d_cols = [DevBuf.from_numpy(np.ascontiguousarray(c)) for c in cols]
+    d_out = DevBuf(96 * 2 * len(cols))
+    assert gpu.lib.h2mi_dbg_msm_small_path(small) == 0
+    try:
+        for count in (1, 2, 3, 4, 5, 9):
+            for batch in (1, 0):
+                assert gpu.lib.h2mi_dbg_msm_batch(batch) == 0
+                ptrs = (C.c_void_p * count)(*[d.ptr for d in d_cols[:count]])
+                assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, ptrs, count, n, d_out.ptr, None) == 0
+                got = d_out.to_numpy(shape=(2 * len(cols), 12))
+                for j in range(count):
+                    assert o.unpack_jacobian(got[j]) == want[j], (count, batch, j)
+        assert gpu.lib.h2mi_dbg_msm_batch(1) == 0
+        # two batches and a single call before one join: slots are reused across them, reductions deferred together
+        p3 = (C.c_void_p * 3)(*[d.ptr for d in d_cols[:3]])
+        q4 = (C.c_void_p * 4)(*[d.ptr for d in d_cols[3:7]])
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, p3, 3, n, d_out.ptr, None) == 0
+        assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_cols[7].ptr, n, d_out.ptr + 96 * 7, None) == 0
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, q4, 4, n, d_out.ptr + 96 * 3, None) == 0
+        got = d_out.to_numpy(shape=(2 * len(cols), 12))
+        for j in range(8):
+            assert o.unpack_jacobian(got[j]) == want[j], ("mixed", j)
+        # a prefix of the base set: no sum point, no shift
+        m = n - 5
+        wantp = [o.unpack_jacobian(cref.msm(np.ascontiguousarray(c[:m]), bases[:m], 8)) for c in cols[:3]]
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, p3, 3, m, d_out.ptr, None) == 0
+        got = d_out.to_numpy(shape=(2 * len(cols), 12))
+        for j in range(3):
+            assert o.unpack_jacobian(got[j]) == wantp[j], ("prefix", j)
+        # argument checks: a null column, no columns
+        bad = (C.c_void_p * 2)(d_cols[0].ptr, None)
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, bad, 2, n, d_out.ptr, None) != 0
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value, p3, 0, n, d_out.ptr, None) != 0
+        assert gpu.lib.h2mi_msm_bn254_g1_batch_dev(h.value + 12345, p3, 3, n, d_out.ptr, None) != 0
+    finally:
+        gpu.lib.h2mi_dbg_msm_small_path(1)
+        gpu.lib.h2mi_dbg_msm_batch(1)
+    for d in d_cols:
+        d.free()
+    d_out.free()
+    assert gpu.lib.h2mi_bases_release(h.value) == 0
