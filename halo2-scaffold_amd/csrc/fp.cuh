@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "inv_divsteps.cuh"
+
 namespace h2 {
 
 struct alignas(16) fe {
@@ -320,6 +322,21 @@ __device__ __noinline__ fe fe_inv_gcd(const fe& a_mont) {
   fe r = is_one(u) ? x1 : x2;  // (a R)^-1 as a plain integer: a^-1 R^-1
   const fe r2 = fe_const<F>(F::R2);
   return fe_mul<F>(fe_mul<F>(r, r2), r2);  // * R^2 -> a^-1 R
+}
+
+// The same inverse by division steps (inv_divsteps.cuh): a third of the instructions, no data-dependent branches inside a batch.
+// For the single inversions a prover's critical path waits for (the grand products' denominators); fe_inv_gcd stays as its
+// fallback and cross-check (h2mi_dbg_field_op: op 4 = Fermat, op 9 = this, op 10 = fe_inv_gcd).
+template <class F>
+__device__ __noinline__ fe fe_inv_ds(const fe& a_mont) {
+  if (fe_is_zero(a_mont)) return a_mont;
+  uint32_t mod[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) mod[i] = F::MOD[i];
+  fe r;
+  if (!inv_divsteps_256(a_mont.v, mod, F::INV, r.v)) return fe_inv_gcd<F>(a_mont);
+  const fe r2 = fe_const<F>(F::R2);
+  return fe_mul<F>(fe_mul<F>(r, r2), r2);  // (a R)^-1 = a^-1 R^-1 as a plain integer; * R^2 twice -> a^-1 R
 }
 
 }  // namespace h2

@@ -79,6 +79,8 @@ __global__ void __launch_bounds__(256) k_dbg_field(int op, const fe* a, const fe
     case 5: r = fe_from_mont<F>(x); break;
     case 6: r = fe_to_mont<F>(x); break;
     case 7: r = fe_neg<F>(x); break;
+    case 9: r = fe_inv_ds<F>(x); break;
+    case 10: r = fe_inv_gcd<F>(x); break;
     default: r = fe_dbl<F>(x); break;
   }
   fe_store(&out[i], r);

@@ -1233,18 +1233,19 @@ __global__ void __launch_bounds__(256) k_evaluate_h_flex(FlexCosets c, uint32_t 
   fe_store(&out[idx], o);
 }
 
-// the one inversion on the critical path, by the binary extended Euclid of the 32-bit-limb layer.  in = x 2^261 read
+// the one inversion on the critical path, by division steps on the 32-bit-limb layer (fe_inv_ds; round 4: the shift / subtract
+// Euclid it replaces took 110 us for a lone wavefront).  in = x 2^261 read
 // as a Montgomery-2^256 value is (32 x) 2^256; its inverse (x^-1 / 32) 2^256 times 2^10 is x^-1 2^261.
 __global__ void k_fr_inv_one(const fe* in, fe* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  fe r = fe_inv_gcd<Fr>(fe_load(in));
+  fe r = fe_inv_ds<Fr>(fe_load(in));
   for (int i = 0; i < 10; i++) r = fe_dbl<Fr>(r);
   fe_store(out, r);
 }
 // A handful of constrained cells (the reference's StandardPlonk: 8 positions, x^2 + 72: ~30): the whole sparse grand
 // product in ONE workgroup.  R_i = prod_{j<=i} num_j / den_j = PN_i * S_(i+1) / S_0 with PN the prefix products of the
 // numerators and S the suffix products of the denominators: the two scans run together (Hillis-Steele), and the ONE
-// inversion (binary Euclid, see k_fr_inv_one) is of S_0 — every lane of the first wavefront runs it on the same value, so
+// inversion (division steps, see k_fr_inv_one) is of S_0 — every lane of the first wavefront runs it on the same value, so
 // its data-dependent branches are wavefront-uniform.  (Round 2 inverted each lane's own denominator: 64 different branch
 // histories in one wavefront, 0.22 ms for 8 cells.)  The result is already in the columns' Montgomery-2^256 form for
 // k_perm_write_sets.
@@ -1279,7 +1280,7 @@ __global__ void __launch_bounds__(PERM_SMALL_MAX) k_perm_sparse_small(PermArgs a
     __syncthreads();
   }
   if (tid < 64) {  // (S_0 2^261) read as Montgomery-2^256 is (32 S_0) 2^256; its inverse times 2^10 is S_0^-1 2^261
-    fe inv = fe_inv_gcd<Fr>(shd[0]);
+    fe inv = fe_inv_ds<Fr>(shd[0]);
     for (int q = 0; q < 10; q++) inv = fe_dbl<Fr>(inv);
     if (tid == 0) sh_inv = inv;
   }

@@ -406,7 +406,7 @@ int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches)
 int h2mi_profile_dump(char* buf, size_t cap, size_t* needed_out);
 
 /* ---- test hooks (elementwise device arithmetic, used by the parity tests only) ------------------- */
-int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,4=inv,5=from_mont,6=to_mont,7=neg,8=dbl*/,
+int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,4=inv (Fermat),5=from_mont,6=to_mont,7=neg,8=dbl,9=inv by division steps,10=inv by binary Euclid*/,
                       const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op 0: out = P + Q (affine inputs, via XYZZ mixed add); 1: 2P; 2: P + Q via XYZZ full add; output Jacobian (12 limbs each) */
 int h2mi_dbg_g1_op(int op, const uint64_t* p_affine, const uint64_t* q_affine, uint64_t* out_jac, size_t n);

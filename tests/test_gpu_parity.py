@@ -42,6 +42,9 @@ def test_field_ops_bit_exact(gpu, field, mod):
     assert o.unpack(run(7, False), mod) == [(-x) % mod for x in a]
     assert o.unpack(run(8, False), mod) == [2 * x % mod for x in a]
     assert o.unpack(run(4, False), mod) == [pow(x, -1, mod) if x else 0 for x in a]
+    # the two Euclid-style inversions: division steps (what the grand products' one inversion runs) and the shift / subtract form
+    assert o.unpack(run(9, False), mod) == [pow(x, -1, mod) if x else 0 for x in a]
+    assert o.unpack(run(10, False), mod) == [pow(x, -1, mod) if x else 0 for x in a]
     # from_mont: Montgomery limbs -> canonical limbs ; to_mont is its inverse
     assert o.unpack(run(5, False)) == a
     can = o.pack(a)

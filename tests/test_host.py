@@ -310,11 +310,13 @@ def test_cpp_host_single_element_inversion_matches_pow():
 
     src = os.path.join(ROOT, "tests", "host", "inv_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libinvhost.so")
-    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "include", "h2mi_plonk.hpp")]
+    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "include", "h2mi_plonk.hpp"),
+            os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "inv_divsteps.cuh")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     L = C.CDLL(so)
     L.h2t_inv_plain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.h2t_inv_plain32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.h2t_inv_mont.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     rng = np.random.default_rng(0x1217)
     for field, mod in ((0, o.Q), (1, o.R)):
@@ -330,6 +332,11 @@ def test_cpp_host_single_element_inversion_matches_pow():
         assert ok.all()  # the fast path itself, not the Fermat fallback behind it
         got = [sum(int(out[j, i]) << (64 * i) for i in range(4)) for j in range(n)]
         assert got == [pow(v, -1, mod) for v in vals]
+        # the device's 32-bit form of the same steps (csrc/inv_divsteps.cuh: what the grand products' one inversion runs), on the host
+        out32 = np.zeros_like(A)
+        ok32 = np.zeros(n, dtype=np.uint8)
+        L.h2t_inv_plain32(field, A.ctypes.data, out32.ctypes.data, ok32.ctypes.data, n)
+        assert ok32.all() and np.array_equal(out32, out)
         # Montgomery forms through fr::invert / fq::invert, against the exponentiation they replace; zero stays zero
         M = o.pack([0] + vals[:3000], mod)
         fast, fermat = np.zeros_like(M), np.zeros_like(M)
