@@ -26,6 +26,7 @@
 #include <optional>
 #include <utility>
 
+#include <chrono>
 #include "h2mi.hpp"
 #include "h2mi_transcript.hpp"
 
@@ -682,6 +683,11 @@ struct ProverWorkspace {
   Dev random_poly, h, h_poly, points, evals, nx, tmp, h_x, l_x, h2_x;
   std::unique_ptr<ShplonkLanes> lanes;
   h2mi_stream_t side = nullptr;  // transforms of the advice columns run here, beside the permutation argument's chain
+  // optional host-side phase clock (untraced: a kernel tracer distorts exactly the host-paced stretches one wants to see): when
+  // time_phases is set, create_proof adds the wall clock between its transcript joins to phase_us[0 .. 5] = advice committed,
+  // z + random committed, h pieces committed, evaluations written, SHPLONK's first and second commitment written
+  bool time_phases = false;
+  double phase_us[6] = {0, 0, 0, 0, 0, 0};
   ProverWorkspace(const ProverWorkspace&) = delete;
   ProverWorkspace& operator=(const ProverWorkspace&) = delete;
   ~ProverWorkspace() {
@@ -729,6 +735,13 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     check(h2mi_msm_bn254_g1_batch_dev(handle, cols.data(), cols.size(), n, points.p, nullptr), "commit");
   };
 
+  auto phase_t0 = std::chrono::steady_clock::now();
+  auto mark = [&](int phase) {
+    if (!ws.time_phases) return;
+    const auto t = std::chrono::steady_clock::now();
+    ws.phase_us[phase] += std::chrono::duration<double, std::micro>(t - phase_t0).count();
+    phase_t0 = t;
+  };
   tr.common_scalar(pk.vk.transcript_repr);  // vk.hash_into
 
   // advice columns: witness cells + blinding rows, committed in the Lagrange basis
@@ -753,6 +766,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
   for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *advice[j], *advice_polys[j], *advice_cosets[j], ws.side);
   write_phase_points(na);
+  mark(0);
   (void)tr.squeeze_challenge();  // theta: drawn even without lookups
   const Fr beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
   // vanishing argument's random polynomial: written after the z commitments, dependent on nothing — its dense MSM is
@@ -790,6 +804,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   for (uint32_t j = 0; j < na; j++) to_poly_and_coset_into(d, *z[j], *z_polys[j], *z_cosets[j]);
   check(h2mi_stream_wait(nullptr, ws.side), "stream_wait");  // evaluate_h and the openings read the advice forms
   write_phase_points(na + 1);
+  mark(1);
   const Fr y = tr.squeeze_challenge();
 
   // quotient: evaluate_h on the extended coset (divided by X^n - 1), back to coefficients, commit the pieces
@@ -819,6 +834,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
     commit_phase(params.g_handle(), cols);
   }
   write_phase_points(pieces);
+  mark(2);
   const Fr x = tr.squeeze_challenge();
   const Fr xn = fr::pow_u64(x, n);
 
@@ -866,6 +882,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   std::vector<Fr> ev(todo.size());
   check(h2mi_memcpy_d2h(ev.data(), evals.p, todo.size() * 32), "d2h");
   for (size_t i = 0; i < written.size(); i++) tr.write_scalar(ev[slot[i]]);
+  mark(3);
   auto value_of = [&](const DeviceVec* poly, const Fr& pt) {
     for (size_t i = 0; i < todo.size(); i++)
       if (todo[i].poly == poly && todo[i].point == pt) return ev[slot[i]];
@@ -886,9 +903,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   q(&h_poly, x);
   q(&random_poly, x);
   ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, &ws.shplonk_s, ws.lanes->lanes()};
+  int shplonk_commit = 0;
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
     commit(params.g_handle(), poly.p, 0);
     write_phase_points(1);
+    mark(4 + shplonk_commit++);
   }, scratch);
 }
 
