@@ -89,6 +89,7 @@ struct PassParams {
   f29 post;       // Montgomery-2^261 limbs (converted on the host: every thread of the last pass multiplies by it)
   uint32_t logN1, logN2;  // last pass: digit-reversal geometry
   uint32_t remap;         // XCD-aware block remap on/off
+  uint32_t nofuse;        // A/B (-DH2MI_AB, H2MI_NTT_NO_FUSE): the first / last round through LDS like the others
   size_t in_len;          // elements of `in` that exist; indices beyond read as zero (first pass of a
                           // zero-extending transform: coeff_to_extended without materialising the padding)
 };
@@ -232,6 +233,84 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
   }
 }
 
+// ---- fused ends (round 4) -------------------------------------------------------------------------------------------------
+// With one quad per thread (T = tile / 4) the four elements a thread LOADS — e0 + k 2^(m-2), k < 4, of one DFT — are exactly the
+// quad of the first radix-4 round (bit reversal puts them at four consecutive LDS positions), and the four outputs of the LAST
+// round — positions pos + j 2^(m-2) — are exactly what a thread of the store loop writes.  So the first round runs on the loaded
+// registers and the last round's results go straight to the store: two of a 2^10 tile's six LDS round trips (initial put, five
+// get / put rounds, final get) and one barrier disappear; the arithmetic, and with it every result bit, is that of local_ntt.
+// Even m >= 4 with compile-time geometry only (every pass of the default splits but 2^5 / 2^7 / 2^9-point ones).
+// one radix-4 round on registers: inputs x0..x3 from positions i, i+h, i+2h, i+3h; outputs for the same positions
+template <bool FIRST>
+__device__ __forceinline__ void ntt_r4(const f29& x0, const f29& x1, const f29& x2, const f29& x3, const f29& wa, const f29& w2, const f29& w3,
+                                       f29& r0, f29& r1, f29& r2, f29& r3) {
+  f29 t1 = x1, t3 = x3;
+  if (!FIRST) {
+    t1 = f29_mul<F9>(x1, wa);
+    t3 = f29_mul<F9>(x3, wa);
+  }
+  const f29 a0 = f29_add(x0, t1), a1 = f29_sub(x0, t1, F9::K2);
+  const f29 a2 = f29_add(x2, t3), a3 = f29_sub(x2, t3, F9::K2);
+  const f29 u3 = f29_mul<F9>(a3, w3);
+  if (FIRST) {  // the twiddle of (a0, a2) is omega^0
+    r0 = f29_normalize(f29_add(a0, a2));
+    r2 = f29_normalize(f29_sub(a0, a2, F9::KW4));
+  } else {
+    const f29 u2 = f29_mul<F9>(a2, w2);
+    r0 = f29_normalize(f29_add(a0, u2));
+    r2 = f29_normalize(f29_sub(a0, u2, F9::K2));
+  }
+  r1 = f29_normalize(f29_add(a1, u3));
+  r3 = f29_normalize(f29_sub(a1, u3, F9::K2));
+}
+// first round (stages 0, 1) on the loaded elements e_k = element e0 + k 2^(m-2) of DFT c, results to their LDS positions
+// (named values, not an array: an f29[4] passed by reference stayed in scratch memory — 304 B per thread, passes 8 - 20 % slower)
+__device__ __forceinline__ void ntt_first_round_put(uint32_t* lds, uint32_t dstride, const fe* loc, uint32_t m, uint32_t c, uint32_t e0, const f29& e_0,
+                                                    const f29& e_1, const f29& e_2, const f29& e_3) {
+  const uint32_t i = (c << m) | (bitrev(e0, m - 2) << 2);
+  // bit reversal: element k sits at position i + bitrev2(k): (x0, x1, x2, x3) of the round = elements 0, 2, 1, 3
+  const f29 w3 = load_unpack(&loc[1u << (m - 2)]);  // staged entry 1 = loc[bitrev(1, m - 1)]
+  f29 r0, r1, r2, r3;
+  ntt_r4<true>(e_0, e_2, e_1, e_3, w3, w3, w3, r0, r1, r2, r3);
+  lds_put(lds, dstride, i, r0);
+  lds_put(lds, dstride, i + 1, r1);
+  lds_put(lds, dstride, i + 2, r2);
+  lds_put(lds, dstride, i + 3, r3);
+}
+// rounds s = 2 .. m - 4 through LDS, as local_ntt runs them; ends with a workgroup barrier (the last round regroups the threads)
+__device__ __forceinline__ void ntt_middle_rounds(uint32_t* lds, uint32_t dstride, const uint32_t* tw, const fe* loc, uint32_t m, uint32_t logC) {
+  const uint32_t tid = threadIdx.x, tcnt = tw_staged_count(m);
+  for (uint32_t s = 2; s + 2 < m; s += 2) {
+    const uint32_t h = 1u << s;
+    const uint32_t c = tid >> (m - 2), r = tid & ((1u << (m - 2)) - 1);
+    const uint32_t pos = r & (h - 1), grp = r >> s;
+    const uint32_t i = (c << m) | (grp << (s + 2)) | pos;
+    const f29 x0 = lds_get(lds, dstride, i), x1 = lds_get(lds, dstride, i + h), x2 = lds_get(lds, dstride, i + 2 * h), x3 = lds_get(lds, dstride, i + 3 * h);
+    const uint32_t pb = bitrev(pos, s);
+    f29 r0, r1, r2, r3;
+    ntt_r4<false>(x0, x1, x2, x3, tw_fetch(tw, tcnt, loc, m, s, pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb + 1), r0, r1,
+                  r2, r3);
+    lds_put(lds, dstride, i, r0);
+    lds_put(lds, dstride, i + h, r1);
+    lds_put(lds, dstride, i + 2 * h, r2);
+    lds_put(lds, dstride, i + 3 * h, r3);
+    // wave-local while the next round's quads stay inside a wavefront's own 256 elements — and the next round is not the last
+    if (s + 4 < m && s + 4 <= 8) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+  }
+}
+// last round (stages m-2, m-1) for the quad (c, pos): y[j] = the DFT's output k = pos + j 2^(m-2)
+__device__ __forceinline__ void ntt_last_round_get(const uint32_t* lds, uint32_t dstride, const uint32_t* tw, const fe* loc, uint32_t m, uint32_t c,
+                                                   uint32_t pos, f29& y0, f29& y1, f29& y2, f29& y3) {
+  const uint32_t s = m - 2, h = 1u << s, tcnt = tw_staged_count(m);
+  const uint32_t i = (c << m) | pos;
+  const f29 x0 = lds_get(lds, dstride, i), x1 = lds_get(lds, dstride, i + h), x2 = lds_get(lds, dstride, i + 2 * h), x3 = lds_get(lds, dstride, i + 3 * h);
+  const uint32_t pb = bitrev(pos, s);
+  ntt_r4<false>(x0, x1, x2, x3, tw_fetch(tw, tcnt, loc, m, s, pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb + 1), y0, y1, y2,
+                y3);
+}
+constexpr bool ntt_fused_geometry(uint32_t DS, uint32_t M) { return DS != 0 && M >= 4 && (M & 1u) == 0; }
+
 __device__ __forceinline__ f29 pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {  // Mont261
   return f29_mul<F9>(load_unpack(&hi[e >> h]), load_unpack(&lo[e & ((1u << h) - 1)]));
 }
@@ -260,6 +339,46 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   const uint32_t seg = tile >> tiles_per_seg_log;
   const uint32_t jl0 = (tile & ((1u << tiles_per_seg_log) - 1)) << logC;
   const size_t base = (size_t)seg << p.log_seg;
+  const uint32_t sh = p.log_n - p.log_seg;
+
+  if (ntt_fused_geometry(DS, M) && T * 4 == DS && !p.nofuse) {  // one quad per thread: first round on the loaded registers, last round into the store
+    const uint32_t c = tid & (C - 1), e0 = tid >> logC, Q = 1u << (m - 2);
+    auto ld = [&](uint32_t k) {
+      const size_t idx = base + ((size_t)(e0 + k * Q) << logS) + jl0 + c;
+      f29 x = f29_zero();
+      if (idx < p.in_len) {
+        x = load_unpack(&p.in[idx]);
+        if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+      }
+      return x;
+    };
+    {
+      const f29 x0 = ld(0), x1 = ld(1), x2 = ld(2), x3 = ld(3);
+      ntt_first_round_put(lds, dstride, p.loc, m, c, e0, x0, x1, x2, x3);
+    }
+    stage_twiddles(tw, p.loc, m);
+    __syncthreads();
+    ntt_middle_rounds(lds, dstride, tw, p.loc, m, logC);
+    f29 y0, y1, y2, y3;
+    ntt_last_round_get(lds, dstride, tw, p.loc, m, c, e0, y0, y1, y2, y3);  // pos = e0: this thread's outputs k = e0 + j Q of DFT c
+    auto st = [&](uint32_t j, const f29& y) {
+      const uint32_t k = e0 + j * Q, o = (k << logC) | c;
+      f29 v;
+      if (p.wmat) {
+        v = f29_mul<F9>(y, load_unpack(&p.wmat[((size_t)(jl0 >> logC) << (m + logC)) + o]));
+      } else {
+        v = f29_mul<F9>(y, powtab(p.tlo, p.thi, p.h, p.tfull, ((jl0 + c) * k) << sh));
+      }
+      fe o_;
+      f29_pack(v, o_.v);
+      fe_store(&p.out[base + ((size_t)k << logS) + jl0 + c], o_);
+    };
+    st(0, y0);
+    st(1, y1);
+    st(2, y2);
+    st(3, y3);
+    return;
+  }
 
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), e = o >> logC;
@@ -276,7 +395,6 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   stage_twiddles(tw, p.loc, m);
   __syncthreads();
   local_ntt(lds, dstride, tw, p.loc, m, logC);
-  const uint32_t sh = p.log_n - p.log_seg;
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o & (C - 1), k = o >> logC;
     f29 x = lds_get(lds, dstride, (c << m) | k);
@@ -306,6 +424,48 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x, p.remap);
   const uint32_t k2 = tile & ((1u << p.logN2) - 1);
   const uint32_t k1_0 = (tile >> p.logN2) << logC;
+
+  if (ntt_fused_geometry(DS, M) && T * 4 == DS && !p.nofuse) {  // see k_ntt_pass_col
+    const uint32_t Q = 1u << (m - 2);
+    {
+      const uint32_t c = tid >> (m - 2), e0 = tid & (Q - 1);  // loads: a wavefront reads 64 consecutive elements of one row
+      const size_t rho = ((size_t)(k1_0 + c) << p.logN2) + k2;
+      auto ld = [&](uint32_t k) {
+        const size_t idx = (rho << m) + e0 + k * Q;
+        f29 x = f29_zero();
+        if (idx < p.in_len) {
+          x = load_unpack(&p.in[idx]);
+          if (p.plo) x = f29_mul<F9>(x, powtab(p.plo, p.phi, p.ph, p.pfull, (uint32_t)idx));
+        }
+        return x;
+      };
+      const f29 x0 = ld(0), x1 = ld(1), x2 = ld(2), x3 = ld(3);
+      ntt_first_round_put(lds, dstride, p.loc, m, c, e0, x0, x1, x2, x3);
+    }
+    stage_twiddles(tw, p.loc, m);
+    __syncthreads();
+    ntt_middle_rounds(lds, dstride, tw, p.loc, m, logC);
+    const uint32_t c = tid & (C - 1), pos = tid >> logC;  // stores: the C rows' outputs k are adjacent in memory
+    f29 y0, y1, y2, y3;
+    ntt_last_round_get(lds, dstride, tw, p.loc, m, c, pos, y0, y1, y2, y3);
+    const f29 fin = p.post;
+    auto st = [&](uint32_t j, const f29& y) {
+      const uint32_t k = pos + j * Q;
+      const size_t oidx = (size_t)(k1_0 + c) + ((size_t)k2 << p.logN1) + ((size_t)k << (p.logN1 + p.logN2));
+      if (p.has_post) {
+        pack_store(&p.out[oidx], f29_mul<F9>(y, fin));
+      } else {
+        fe o_;
+        f29_pack(f29_reduce_loose<F9>(y), o_.v);
+        fe_store(&p.out[oidx], o_);
+      }
+    };
+    st(0, y0);
+    st(1, y1);
+    st(2, y2);
+    st(3, y3);
+    return;
+  }
 
   for (uint32_t o = tid; o < (C << m); o += T) {
     uint32_t c = o >> m, e = o & ((1u << m) - 1);
@@ -1714,6 +1874,9 @@ static int ntt_dev(fe* d_a, uint32_t log_n, const uint64_t omega[4], const uint6
     pp.h = pl.tw.h;
     pp.tfull = pl.tw.full;
     pp.remap = remap;
+    // below 2^18 a pass is a few dozen tiles and the regrouping barrier before the last round costs more than the LDS round trips
+    // it saves (2^16: 36.0 -> 36.8 us fused; 2^20: 134.7 -> 129.5, 2^24: 2000 -> 1958: profiles/r04_ntt_fused_rounds.txt)
+    pp.nofuse = (log_n < 18 || ab_env("H2MI_NTT_NO_FUSE")) ? 1 : 0;
     if (p == 0 && pre) {
       pp.plo = pt.lo;
       pp.phi = pt.hi;
