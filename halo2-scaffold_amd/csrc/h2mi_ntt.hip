@@ -239,7 +239,7 @@ __device__ __forceinline__ void local_ntt(uint32_t* lds, uint32_t dstride, const
 // round — positions pos + j 2^(m-2) — are exactly what a thread of the store loop writes.  So the first round runs on the loaded
 // registers and the last round's results go straight to the store: two of a 2^10 tile's six LDS round trips (initial put, five
 // get / put rounds, final get) and one barrier disappear; the arithmetic, and with it every result bit, is that of local_ntt.
-// Even m >= 4 with compile-time geometry only (every pass of the default splits but 2^5 / 2^7 / 2^9-point ones).
+// m >= 4 with compile-time geometry only (every pass of the default splits); an odd m ends with the closing radix-2 stage instead.
 // one radix-4 round on registers: inputs x0..x3 from positions i, i+h, i+2h, i+3h; outputs for the same positions
 template <bool FIRST>
 __device__ __forceinline__ void ntt_r4(const f29& x0, const f29& x1, const f29& x2, const f29& x3, const f29& wa, const f29& w2, const f29& w3,
@@ -309,7 +309,28 @@ __device__ __forceinline__ void ntt_last_round_get(const uint32_t* lds, uint32_t
   ntt_r4<false>(x0, x1, x2, x3, tw_fetch(tw, tcnt, loc, m, s, pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb), tw_fetch(tw, tcnt, loc, m, s, 2 * pb + 1), y0, y1, y2,
                 y3);
 }
-constexpr bool ntt_fused_geometry(uint32_t DS, uint32_t M) { return DS != 0 && M >= 4 && (M & 1u) == 0; }
+// odd m: the closing radix-2 stage s = m - 1 for the thread's two butterflies (pos, pos + 2Q) and (pos + Q, pos + 3Q), Q = 2^(m-2):
+// the same four outputs k = pos + j Q
+__device__ __forceinline__ void ntt_last_stage_get_odd(const uint32_t* lds, uint32_t dstride, const uint32_t* tw, const fe* loc, uint32_t m, uint32_t c,
+                                                       uint32_t pos, f29& y0, f29& y1, f29& y2, f29& y3) {
+  const uint32_t s = m - 1, half = 1u << s, Q = 1u << (m - 2), tcnt = tw_staged_count(m);
+  const uint32_t i = (c << m) | pos;
+  const f29 u0 = lds_get(lds, dstride, i), v0 = lds_get(lds, dstride, i + half);
+  const f29 u1 = lds_get(lds, dstride, i + Q), v1 = lds_get(lds, dstride, i + Q + half);
+  const f29 t0 = f29_mul<F9>(v0, tw_fetch(tw, tcnt, loc, m, s - 1, bitrev(pos, s)));
+  const f29 t1 = f29_mul<F9>(v1, tw_fetch(tw, tcnt, loc, m, s - 1, bitrev(pos + Q, s)));
+  y0 = f29_normalize(f29_add(u0, t0));
+  y2 = f29_normalize(f29_sub(u0, t0, F9::K2));
+  y1 = f29_normalize(f29_add(u1, t1));
+  y3 = f29_normalize(f29_sub(u1, t1, F9::K2));
+}
+template <uint32_t M>
+__device__ __forceinline__ void ntt_last_get(const uint32_t* lds, uint32_t dstride, const uint32_t* tw, const fe* loc, uint32_t c, uint32_t pos, f29& y0,
+                                             f29& y1, f29& y2, f29& y3) {
+  if (M & 1u) ntt_last_stage_get_odd(lds, dstride, tw, loc, M, c, pos, y0, y1, y2, y3);
+  else ntt_last_round_get(lds, dstride, tw, loc, M, c, pos, y0, y1, y2, y3);
+}
+constexpr bool ntt_fused_geometry(uint32_t DS, uint32_t M) { return DS != 0 && M >= 4; }
 
 __device__ __forceinline__ f29 pow2tab(const fe* lo, const fe* hi, uint32_t h, uint32_t e) {  // Mont261
   return f29_mul<F9>(load_unpack(&hi[e >> h]), load_unpack(&lo[e & ((1u << h) - 1)]));
@@ -341,7 +362,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
   const size_t base = (size_t)seg << p.log_seg;
   const uint32_t sh = p.log_n - p.log_seg;
 
-  if (ntt_fused_geometry(DS, M) && T * 4 == DS && !p.nofuse) {  // one quad per thread: first round on the loaded registers, last round into the store
+  if constexpr (ntt_fused_geometry(DS, M)) if (T * 4 == DS && !p.nofuse) {  // one quad per thread: first round on the loaded registers, last round into the store
     const uint32_t c = tid & (C - 1), e0 = tid >> logC, Q = 1u << (m - 2);
     auto ld = [&](uint32_t k) {
       const size_t idx = base + ((size_t)(e0 + k * Q) << logS) + jl0 + c;
@@ -360,7 +381,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_col(PassParams p) {
     __syncthreads();
     ntt_middle_rounds(lds, dstride, tw, p.loc, m, logC);
     f29 y0, y1, y2, y3;
-    ntt_last_round_get(lds, dstride, tw, p.loc, m, c, e0, y0, y1, y2, y3);  // pos = e0: this thread's outputs k = e0 + j Q of DFT c
+    ntt_last_get<M>(lds, dstride, tw, p.loc, c, e0, y0, y1, y2, y3);  // pos = e0: this thread's outputs k = e0 + j Q of DFT c
     auto st = [&](uint32_t j, const f29& y) {
       const uint32_t k = e0 + j * Q, o = (k << logC) | c;
       f29 v;
@@ -425,7 +446,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
   const uint32_t k2 = tile & ((1u << p.logN2) - 1);
   const uint32_t k1_0 = (tile >> p.logN2) << logC;
 
-  if (ntt_fused_geometry(DS, M) && T * 4 == DS && !p.nofuse) {  // see k_ntt_pass_col
+  if constexpr (ntt_fused_geometry(DS, M)) if (T * 4 == DS && !p.nofuse) {  // see k_ntt_pass_col
     const uint32_t Q = 1u << (m - 2);
     {
       const uint32_t c = tid >> (m - 2), e0 = tid & (Q - 1);  // loads: a wavefront reads 64 consecutive elements of one row
@@ -447,7 +468,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass_row(PassParams p) {
     ntt_middle_rounds(lds, dstride, tw, p.loc, m, logC);
     const uint32_t c = tid & (C - 1), pos = tid >> logC;  // stores: the C rows' outputs k are adjacent in memory
     f29 y0, y1, y2, y3;
-    ntt_last_round_get(lds, dstride, tw, p.loc, m, c, pos, y0, y1, y2, y3);
+    ntt_last_get<M>(lds, dstride, tw, p.loc, c, pos, y0, y1, y2, y3);
     const f29 fin = p.post;
     auto st = [&](uint32_t j, const f29& y) {
       const uint32_t k = pos + j * Q;
