@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
-# A/B of the C++ host headers on one GPU box: examples/ab_old/* (built on the dev box from an earlier commit's include/, see
+# A/B of the C++ host on one GPU box: examples/ab_old/* (built on the dev box from an earlier commit: its include/ and, when examples/ab_old/lib/libh2mi.so
+# exists, its library through the binaries' RUNPATH; see
 # DESIGN 4.5) against the current examples, alternating, steady-state ms per proof.  tools/ab_host.sh [ROUNDS] [PROOFS]
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
