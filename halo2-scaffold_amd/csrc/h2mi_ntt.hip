@@ -1563,6 +1563,41 @@ struct CallScope {  // one per ABI call that uses cached tables
   CallScope() { g_epoch++; }
 };
 
+// Power tables are ONE allocation (lo, then hi) and evicted ones are kept in a small pool keyed by size instead of going back to the
+// runtime (round 4): a proof builds about a dozen per-challenge tables (evaluation points, their inverses: 16 - 64 KB each), and two
+// hipMalloc + two hipFree per table were host time on every proof's critical path.  In a prover loop the sizes repeat, so after the first
+// eviction no table build allocates at all.
+constexpr size_t TABLE_POOL_MAX_BYTES = (size_t)256 << 20;
+static std::multimap<size_t, fe*> g_table_pool;
+static size_t g_table_pool_bytes = 0;
+static fe* table_alloc(size_t bytes) {
+  auto it = g_table_pool.find(bytes);
+  if (it != g_table_pool.end()) {
+    fe* p = it->second;
+    g_table_pool.erase(it);
+    g_table_pool_bytes -= bytes;
+    return p;
+  }
+  fe* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+// the caller has made sure nothing reads the table any more (evictions run behind a device synchronisation)
+static void table_release(fe* p, size_t bytes) {
+  if (!p) return;
+  if (g_table_pool_bytes + bytes <= TABLE_POOL_MAX_BYTES) {
+    g_table_pool.insert({bytes, p});
+    g_table_pool_bytes += bytes;
+  } else {
+    H2_IGNORE(hipFree(p));
+  }
+}
+static void table_pool_clear() {
+  for (auto& kv : g_table_pool) H2_IGNORE(hipFree(kv.second));
+  g_table_pool.clear();
+  g_table_pool_bytes = 0;
+}
+
 static void free_plan(Plan& pl) {
   for (int i = 0; i < 3; i++) {
     fe* p = pl.loc[i];
@@ -1598,8 +1633,7 @@ static int evict_tables() {
     for (auto& e : order) {
       if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES) break;
       auto it = g_powtabs.find(e.second);
-      H2_IGNORE(hipFree(it->second.lo));
-      H2_IGNORE(hipFree(it->second.hi));
+      table_release(it->second.lo, it->second.bytes);  // hi lives in the same allocation
       it->second.built.destroy();
       g_powtab_bytes -= it->second.bytes;
       g_powtabs.erase(it);
@@ -1647,11 +1681,9 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
   t.h = full ? log_n : (log_n + 1) / 2;
   uint32_t nlo = 1u << t.h, nhi = 1u << (log_n - t.h);
   t.bytes = ((size_t)nlo + nhi) * 32;
-  H2_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
-  if (hipMalloc(&t.hi, (size_t)nhi * 32) != hipSuccess) {
-    H2_IGNORE(hipFree(t.lo));
-    return H2MI_ENOMEM;
-  }
+  t.lo = table_alloc(t.bytes);
+  if (!t.lo) return H2MI_ENOMEM;
+  t.hi = t.lo + nlo;
   fe b = host_fe(base);
   H2_LAUNCH("k_pow_table", k_pow_table2, dim3(ceil_div_u32(std::max(nlo, nhi), 256), 2), 256, 0, s, t.lo, t.hi, t.h, log_n - t.h, b);
   H2_HIP(t.built.mark(s));
@@ -1760,12 +1792,12 @@ void ntt_teardown() {
   for (auto& kv : g_plans) free_plan(kv.second);
   g_plans.clear();
   for (auto& kv : g_powtabs) {
-    H2_IGNORE(hipFree(kv.second.lo));
-    H2_IGNORE(hipFree(kv.second.hi));
+    H2_IGNORE(hipFree(kv.second.lo));  // hi lives in the same allocation
     kv.second.built.destroy();
   }
   g_powtabs.clear();
   g_powtab_bytes = 0;
+  table_pool_clear();
   for (Scratch& c : g_scratch) {
     if (c.p) H2_IGNORE(hipFree(c.p));
     if (c.event) H2_IGNORE(hipEventDestroy(c.event));
