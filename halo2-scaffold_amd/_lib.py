@@ -41,6 +41,7 @@ def _load():
         "h2mi_memcpy_h2d": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_h2d_async": ([vp, vp, sz], C.c_int),
         "h2mi_memcpy_d2h": ([vp, vp, sz], C.c_int),
+        "h2mi_fr_patch_cells_dev": ([vp, vp, sz, vp], C.c_int),
         "h2mi_memcpy_d2d": ([vp, vp, sz], C.c_int),
         "h2mi_memset_zero": ([vp, sz], C.c_int),
         "h2mi_sync": ([], C.c_int),

@@ -342,6 +342,38 @@ int h2mi_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes) {
   H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, primary_stream()));
   return H2MI_OK;
 }
+// up to PATCH_MAX 32-byte cells travel in the kernel's ARGUMENTS: no staging buffer, no copy engine — one launch
+constexpr uint32_t PATCH_MAX = 64;
+struct PatchArgs {
+  fe* dst[PATCH_MAX];
+  fe val[PATCH_MAX];
+};
+__global__ void __launch_bounds__(64) k_patch_cells(const PatchArgs a, uint32_t count) {
+  const uint32_t i = threadIdx.x;
+  if (i < count) fe_store(a.dst[i], a.val[i]);
+}
+int h2mi_fr_patch_cells_dev(void* const* d_cells, const uint64_t* values, size_t count, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (count && (!d_cells || !values)) return H2MI_EINVAL;
+  for (size_t i = 0; i < count; i++)
+    if (!d_cells[i] || ((uintptr_t)d_cells[i] & 15u)) return H2MI_EINVAL;
+  hipStream_t s = stream ? (hipStream_t)stream : primary_stream();
+  for (size_t i0 = 0; i0 < count; i0 += PATCH_MAX) {
+    const uint32_t m = (uint32_t)std::min<size_t>(PATCH_MAX, count - i0);
+    PatchArgs a;
+    for (uint32_t i = 0; i < m; i++) {
+      a.dst[i] = (fe*)d_cells[i0 + i];
+      memcpy(a.val[i].v, values + 4 * (i0 + i), 32);
+    }
+    for (uint32_t i = m; i < PATCH_MAX; i++) {
+      a.dst[i] = a.dst[0];
+      a.val[i] = a.val[0];
+    }
+    hipLaunchKernelGGL(k_patch_cells, dim3(1), dim3(64), 0, s, a, m);
+    H2_HIP(hipGetLastError());
+  }
+  return H2MI_OK;
+}
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
   H2_REQUIRE_INIT();
   {

@@ -1610,7 +1610,9 @@ static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_
   const bool shifted = B->has_sum && n == B->n;
   const size_t n_eff = n + (shifted ? 1 : 0);
   const uint32_t total = (uint32_t)(n_eff * W);
-  hipStream_t hs = ctx().head_stream, as = ctx().accum_stream;
+  // the second partition level and the accumulation share ONE stream here: the separate accumulation stream exists so that the next
+  // MSM's partition overlaps this one's accumulation, which a batch does not need — and a stream hop is ~10 us on the phase's critical path
+  hipStream_t hs = ctx().head_stream, as = hs;
   uint32_t s0_fixed = chunk_override();
   while (s0_fixed && s0_fixed < S0_MAX && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) s0_fixed++;
   if (s0_fixed && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) return H2MI_ERANGE;
@@ -1691,7 +1693,7 @@ static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_
     slots[j]->head_pending = true;
     slots[j]->head_ever = true;
   }
-  H2_HIP(hipStreamWaitEvent(as, slots[m - 1]->head_done, 0));
+  if (as != hs) H2_HIP(hipStreamWaitEvent(as, slots[m - 1]->head_done, 0));
   static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
   H2_LAUNCH("k_msm_accum", k_msm_accum_b, dim3(ceil_div_u32(chunks0, 256), mm), 256, accum_lds, as, hb, nb, (const uint8_t*)B->table);
   for (size_t j = 0; j < m; j++) {

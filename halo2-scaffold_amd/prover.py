@@ -99,6 +99,12 @@ def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, l
     _write_phase_points(ws, transcript, len(columns))
 
 
+def _patch_cells(addrs, values: np.ndarray):
+    """values[i] (Montgomery limbs) -> device address addrs[i], one launch per 64 cells on the library stream"""
+    ptrs = (C.c_void_p * len(addrs))(*addrs)
+    check(lib.h2mi_fr_patch_cells_dev(ptrs, values.ctypes.data, len(addrs), None), "patch_cells")
+
+
 def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool):
     """queue the commitments of one phase into result slots 0 .. len - 1 with ONE call (h2mi_msm_bn254_g1_batch_dev): below 2^17 rows
     their partition and accumulation kernels are launched once for the whole phase"""
@@ -138,16 +144,18 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     # ---- advice: witness cells (host, a handful) + blinding rows, committed in the Lagrange basis ----------------
     syn = circuit.synthesize()
     blind = synth.uniform_fr(cs.N_ADVICE * (bf + 1), seed + 1)
+    # assigned cells and blinding rows of every column in ONE launch (h2mi_fr_patch_cells_dev: the cells travel in the kernel's
+    # arguments) instead of two small copies per column on the library stream in front of the phase's commitments
+    addrs, vals = [], []
     for j, col in enumerate(ws.advice):
         check(lib.h2mi_memset_zero(col.ptr, n * 32), "zero")
-        rows = sorted(syn.advice[j])
-        if rows:  # assigned cells are contiguous at the top for this circuit: one upload per column
-            lo, hi = rows[0], rows[-1] + 1
-            cells = np.zeros((hi - lo, 4), dtype=np.uint64)
-            for r in rows:
-                cells[r - lo] = _m(syn.advice[j][r])
-            col.patch(cells, offset=lo * 32)
-        col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
+        for r in sorted(syn.advice[j]):
+            addrs.append(col.ptr + r * 32)
+            vals.append(_m(syn.advice[j][r]))
+        for r in range(bf + 1):
+            addrs.append(col.ptr + (u + r) * 32)
+            vals.append(blind[j * (bf + 1) + r])
+    _patch_cells(addrs, np.ascontiguousarray(np.stack(vals)))
     _commit_columns(params, ws, [(c, 0) for c in ws.advice], True)
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join below
     # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
@@ -172,8 +180,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     zblind = synth.uniform_fr(len(ws.z) * bf, seed + 2)
     gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z,
                             active=pk.active_rows)
-    for m, z in enumerate(ws.z):
-        z.patch(zblind[m * bf : (m + 1) * bf], offset=(u + 1) * 32)
+    _patch_cells([z.ptr + (u + 1 + r) * 32 for z in ws.z for r in range(bf)], np.ascontiguousarray(zblind[: len(ws.z) * bf]))
     _commit_columns(params, ws, [(z, 0) for z in ws.z], True)
     check(lib.h2mi_msm_flush(), "flush")
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind

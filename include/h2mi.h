@@ -69,6 +69,12 @@ int h2mi_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 /* queued on the library's stream without waiting for it (pageable `src` is staged by the runtime before the call
  * returns): for the small patches a prover writes into device-resident columns (assigned cells, blinding rows) */
 int h2mi_memcpy_h2d_async(void* d_dst, const void* src, size_t bytes);
+/* `count` 32-byte field elements (Montgomery limbs, host memory) written to `count` device addresses (16-byte aligned) by ONE kernel
+ * launch per 64 cells — the cells travel in the launch's arguments, so `values` may be reused at once.  For the handful of assigned
+ * cells and blinding rows a prover patches into zeroed columns (create_proof's `advice[column][row] = value`): a dozen 32-byte
+ * hipMemcpyAsync calls cost ~10 us each on the library stream in front of a phase's first commitment.  Stream-ordered on `stream`
+ * (NULL = the library stream); cells given twice keep one of the values. */
+int h2mi_fr_patch_cells_dev(void* const* d_cells, const uint64_t* values, size_t count, h2mi_stream_t stream);
 int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int h2mi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int h2mi_memset_zero(void* d_ptr, size_t bytes); /* asynchronous on the library's stream */

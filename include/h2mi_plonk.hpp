@@ -749,11 +749,23 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   std::vector<Fr> blind = uniform_fr(seed + 1, (size_t)na * (bf + 1));
   std::vector<Dev>&advice = ws.advice, &advice_polys = ws.advice_polys, &advice_cosets = ws.advice_cosets, &z = ws.z, &z_polys = ws.z_polys,
               &z_cosets = ws.z_cosets;
-  for (uint32_t j = 0; j < na; j++) {
-    DeviceVec& col = *advice[j];
-    check(h2mi_memset_zero(col.p, n * 32), "zero");
-    for (const auto& kv : syn.advice[j]) patch(col, kv.first, kv.second);
-    check(h2mi_memcpy_h2d_async((char*)col.p + (size_t)u * 32, &blind[(size_t)j * (bf + 1)], (bf + 1) * 32), "blinding rows");
+  {
+    // assigned cells and blinding rows of every column in ONE launch (h2mi_fr_patch_cells_dev) instead of a dozen 32-byte copies
+    std::vector<void*> cells;
+    std::vector<Fr> vals;
+    for (uint32_t j = 0; j < na; j++) {
+      DeviceVec& col = *advice[j];
+      check(h2mi_memset_zero(col.p, n * 32), "zero");
+      for (const auto& kv : syn.advice[j]) {
+        cells.push_back((char*)col.p + (size_t)kv.first * 32);
+        vals.push_back(kv.second);
+      }
+      for (uint32_t r = 0; r <= bf; r++) {
+        cells.push_back((char*)col.p + (size_t)(u + r) * 32);
+        vals.push_back(blind[(size_t)j * (bf + 1) + r]);
+      }
+    }
+    check(h2mi_fr_patch_cells_dev(cells.data(), (const uint64_t*)vals.data(), cells.size(), nullptr), "advice cells");
   }
   {
     std::vector<const void*> cols;
@@ -790,8 +802,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
                                                    (const uint64_t*)bd.data(), omega.l, pk.active_rows->p, pk.n_active, zs.data(), nullptr),
         "permutation_products");
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)na * bf);
-  for (uint32_t m = 0; m < na; m++)
-    check(h2mi_memcpy_h2d_async((char*)z[m]->p + (size_t)(u + 1) * 32, &zblind[(size_t)m * bf], bf * 32), "z blinding rows");
+  {
+    std::vector<void*> cells;
+    for (uint32_t m = 0; m < na; m++)
+      for (uint32_t r = 0; r < bf; r++) cells.push_back((char*)z[m]->p + (size_t)(u + 1 + r) * 32);
+    check(h2mi_fr_patch_cells_dev(cells.data(), (const uint64_t*)zblind.data(), cells.size(), nullptr), "z blinding rows");
+  }
   {
     std::vector<const void*> cols;
     for (uint32_t m = 0; m < na; m++) cols.push_back(z[m]->p);

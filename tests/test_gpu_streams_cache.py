@@ -353,3 +353,35 @@ def test_shutdown_releases_module_state_and_reinit_works(gpu, tmp_path):
     script.write_text(_REINIT_WORKER.format(root=root))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0 and "REINIT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_patch_cells_writes_every_cell_once(gpu):
+    """h2mi_fr_patch_cells_dev: field elements carried in kernel arguments to scattered device addresses — counts below, at and above
+    the 64 cells of one launch, two destination buffers, the rest of the buffers untouched; argument checks."""
+    import ctypes as C
+
+    from halo2_scaffold_amd.device import DevBuf
+    from oracle import bn254 as o
+
+    n = 1000
+    base_a, base_b = o.random_field_limbs(n, 41), o.random_field_limbs(n, 42)
+    for count in (0, 1, 5, 64, 65, 200):
+        a, b = DevBuf.from_numpy(base_a), DevBuf.from_numpy(base_b)
+        rng = np.random.default_rng(count)
+        rows = rng.choice(2 * n, size=count, replace=False)
+        vals = o.random_field_limbs(max(count, 1), 43 + count)[:count]
+        addrs = [(a.ptr if r < n else b.ptr) + int(r % n) * 32 for r in rows]
+        ptrs = (C.c_void_p * max(count, 1))(*addrs) if count else None
+        assert gpu.lib.h2mi_fr_patch_cells_dev(ptrs, np.ascontiguousarray(vals).ctypes.data if count else None, count, None) == 0
+        want_a, want_b = base_a.copy(), base_b.copy()
+        for r, v in zip(rows, vals):
+            (want_a if r < n else want_b)[r % n] = v
+        assert np.array_equal(a.to_numpy(shape=(n, 4)), want_a) and np.array_equal(b.to_numpy(shape=(n, 4)), want_b), count
+        a.free()
+        b.free()
+    d = DevBuf.from_numpy(base_a)
+    one = (C.c_void_p * 1)(d.ptr + 8)  # misaligned cell
+    assert gpu.lib.h2mi_fr_patch_cells_dev(one, base_b.ctypes.data, 1, None) != 0
+    assert gpu.lib.h2mi_fr_patch_cells_dev(None, base_b.ctypes.data, 1, None) != 0
+    d.free()
