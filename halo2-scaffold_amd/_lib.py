@@ -85,6 +85,8 @@ def _load():
         "h2mi_fr_scale_powers_dev": ([vp, sz, vp, vp, vp], C.c_int),
         "h2mi_fr_eval_poly_dev": ([vp, sz, vp, vp, vp], C.c_int),
         "h2mi_fr_eval_polys_dev": ([vp, sz, sz, vp, vp, vp], C.c_int),
+        "h2mi_fr_eval_polys_multi_dev": ([vp, vp, vp, sz, sz, vp, vp], C.c_int),
+        "h2mi_fr_powtab_prefetch_dev": ([vp, sz, sz, vp], C.c_int),
         "h2mi_plonk_permutation_products_dev": ([vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_plonk_permutation_products_sparse_dev": ([vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32, vp, vp],
                                                        C.c_int),

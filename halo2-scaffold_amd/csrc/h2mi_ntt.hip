@@ -72,6 +72,32 @@ __global__ void __launch_bounds__(256) k_pow_table2(fe* lo, fe* hi, uint32_t h, 
   fe_store(&(is_hi ? hi : lo)[i], o);
 }
 
+// up to POW_BATCH two-level tables of one geometry in one launch (blockIdx.z = table): a proof's evaluation points and the division
+// roots' powers are known together, and one launch per table was a dozen 10-us launches per proof
+constexpr uint32_t POW_BATCH = 8;
+struct PowBatch {
+  fe* lo[POW_BATCH];
+  fe* hi[POW_BATCH];
+  fe base[POW_BATCH];
+};
+__global__ void __launch_bounds__(256) k_pow_table2_b(const PowBatch pb, uint32_t h, uint32_t hi_bits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.z;
+  const bool is_hi = blockIdx.y != 0;
+  const uint32_t count = 1u << (is_hi ? hi_bits : h);
+  if (i >= count) return;
+  f29 b = f29_from_mont256<F9>(pb.base[t].v);
+  if (is_hi)
+    for (uint32_t s = 0; s < h; s++) b = f29_sqr<F9>(b);
+  f29 r = f29_const<F9>(F9::ONE);
+  for (int bit = (int)(is_hi ? hi_bits : h) - 1; bit >= 0; bit--) {
+    r = f29_sqr<F9>(r);
+    if ((i >> bit) & 1u) r = f29_mul<F9>(r, b);
+  }
+  fe o;
+  f29_pack(f29_reduce_canonical<F9>(f29_mul<F9>(r, f29_const<F9>(F9::ONE))), o.v);
+  fe_store(&(is_hi ? pb.hi[t] : pb.lo[t])[i], o);
+}
+
 struct PassParams {
   const fe* in;
   fe* out;
@@ -576,9 +602,9 @@ struct PolyList {
 struct EvalPowers {
   f29 y1, y2, y3;  // Montgomery-2^261
 };
-__global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uint32_t logT, EvalPowers yp, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
+__device__ __forceinline__ void eval_poly_body(const fe* poly, size_t n, uint32_t logT, const EvalPowers& yp, const fe* lo, const fe* hi, uint32_t h,
+                                               fe* partial) {
   __shared__ fe red[256];
-  const fe* poly = polys.p[blockIdx.y];
   const uint32_t T = 1u << logT, t = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t m = t < n ? (n - 1 - t) / T + 1 : 0;  // coefficients t, t+T, ... < n
   f29 acc = f29_zero();
@@ -599,6 +625,22 @@ __global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uin
     __syncthreads();
   }
   if (threadIdx.x == 0) fe_store(&partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x], red[0]);
+}
+__global__ void __launch_bounds__(256) k_eval_poly(PolyList polys, size_t n, uint32_t logT, EvalPowers yp, const fe* lo, const fe* hi, uint32_t h, fe* partial) {
+  eval_poly_body(polys.p[blockIdx.y], n, logT, yp, lo, hi, h, partial);
+}
+// the same for polynomials opened at up to EVAL_POINTS different points: polynomial blockIdx.y is evaluated at point grp[blockIdx.y]
+constexpr uint32_t EVAL_POINTS = 4;
+struct EvalMulti {
+  const fe* p[24];
+  uint8_t grp[24];
+  EvalPowers yp[EVAL_POINTS];
+  const fe* lo[EVAL_POINTS];
+  const fe* hi[EVAL_POINTS];
+};
+__global__ void __launch_bounds__(256) k_eval_poly_multi(const EvalMulti em, size_t n, uint32_t logT, uint32_t h, fe* partial) {
+  const uint32_t g = em.grp[blockIdx.y];
+  eval_poly_body(em.p[blockIdx.y], n, logT, em.yp[g], em.lo[g], em.hi[g], h, partial);
 }
 // out[y] = sum of the `count` field elements of row y (one block per row)
 __global__ void __launch_bounds__(256) k_sum_fe(const fe* in, uint32_t count, fe* out) {
@@ -1694,6 +1736,77 @@ static int get_powtab(const uint64_t base[4], uint32_t log_n, hipStream_t s, Pow
   return H2MI_OK;
 }
 
+// the tables of `m` bases at one size: cache hits as get_powtab, the missing ones allocated and built by ONE launch per POW_BATCH
+static int get_powtabs(const uint64_t* bases /* m x 4 */, size_t m, uint32_t log_n, hipStream_t s, PowTab* out) {
+  std::vector<size_t> missing;
+  for (size_t i = 0; i < m; i++) {
+    Key k;
+    memcpy(k.w, bases + 4 * i, 32);
+    k.log_n = log_n;
+    k.full = false;
+    auto it = g_powtabs.find(k);
+    if (it != g_powtabs.end()) {
+      it->second.last_use = g_epoch;
+      H2_HIP(it->second.built.use(s));
+      out[i] = it->second;
+      continue;
+    }
+    bool dup = false;  // the same base twice in one request: built once, copied below
+    for (size_t j : missing) dup = dup || memcmp(bases + 4 * j, bases + 4 * i, 32) == 0;
+    if (!dup) missing.push_back(i);
+  }
+  static const size_t max_entries = getenv("H2MI_POWTAB_MAX") ? (size_t)atoi(getenv("H2MI_POWTAB_MAX")) : POWTAB_MAX_ENTRIES;
+  if (!missing.empty() && (g_powtabs.size() + missing.size() > max_entries || g_powtab_bytes > POWTAB_MAX_BYTES)) {
+    int rc = evict_tables();  // entries handed out above carry this call's epoch: never evicted
+    if (rc) return rc;
+  }
+  const uint32_t h = (log_n + 1) / 2, nlo = 1u << h, nhi = 1u << (log_n - h);
+  for (size_t b0 = 0; b0 < missing.size(); b0 += POW_BATCH) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(POW_BATCH, missing.size() - b0);
+    PowBatch pb;
+    PowTab tabs[POW_BATCH];
+    for (uint32_t j = 0; j < cnt; j++) {
+      PowTab& t = tabs[j];
+      t.full = false;
+      t.h = h;
+      t.bytes = ((size_t)nlo + nhi) * 32;
+      t.lo = table_alloc(t.bytes);
+      if (!t.lo) {
+        for (uint32_t q = 0; q < j; q++) table_release(tabs[q].lo, tabs[q].bytes);
+        return H2MI_ENOMEM;
+      }
+      t.hi = t.lo + nlo;
+      pb.lo[j] = t.lo;
+      pb.hi[j] = t.hi;
+      pb.base[j] = host_fe(bases + 4 * missing[b0 + j]);
+    }
+    for (uint32_t j = cnt; j < POW_BATCH; j++) { pb.lo[j] = pb.lo[0]; pb.hi[j] = pb.hi[0]; pb.base[j] = pb.base[0]; }
+    H2_LAUNCH("k_pow_table", k_pow_table2_b, dim3(ceil_div_u32(std::max(nlo, nhi), 256), 2, cnt), 256, 0, s, pb, h, log_n - h);
+    for (uint32_t j = 0; j < cnt; j++) {
+      PowTab& t = tabs[j];
+      H2_HIP(t.built.mark(s));
+      t.last_use = g_epoch;
+      g_powtab_bytes += t.bytes;
+      Key k;
+      memcpy(k.w, bases + 4 * missing[b0 + j], 32);
+      k.log_n = log_n;
+      k.full = false;
+      g_powtabs[k] = t;
+    }
+  }
+  for (size_t i = 0; i < m; i++) {  // the freshly built ones (and duplicates of them)
+    Key k;
+    memcpy(k.w, bases + 4 * i, 32);
+    k.log_n = log_n;
+    k.full = false;
+    auto it = g_powtabs.find(k);
+    if (it == g_powtabs.end()) return H2MI_EHIP;
+    H2_HIP(it->second.built.use(s));
+    out[i] = it->second;
+  }
+  return H2MI_OK;
+}
+
 static void choose_split(uint32_t log_n, Plan* pl) {
   static const uint32_t MAXM = ab_env("H2MI_NTT_MAXM") ? (uint32_t)atoi(ab_env("H2MI_NTT_MAXM")) : 10;  // tuning knob (7 .. 10)
   if (const char* ev = ab_env("H2MI_NTT_SPLIT")) {  // tuning knob: "8,8,4" — used for the size whose log_n the parts add up to
@@ -2067,12 +2180,21 @@ int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_strea
 }
 
 
+static uint32_t eval_logT(uint32_t log_n) { return log_n > 20 ? 16 : log_n > 12 ? log_n - 4 : 8; }
+static EvalPowers eval_powers(const uint64_t point[4], uint32_t logT) {
+  EvalPowers yp;  // y = x^T, y^2, y^3 on the host (logT squarings of the same header code)
+  yp.y1 = f29_from_mont256<F9>(host_fe(point).v);
+  for (uint32_t i = 0; i < logT; i++) yp.y1 = f29_sqr<F9>(yp.y1);
+  yp.y2 = f29_sqr<F9>(yp.y1);
+  yp.y3 = f29_mul<F9>(yp.y2, yp.y1);
+  return yp;
+}
 // `count` polynomials of n coefficients at one point: one launch (blockIdx.y = polynomial) + one row-sum launch
 static int eval_polys(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, hipStream_t s) {
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
   if (log_n > 30) return H2MI_ERANGE;
-  uint32_t logT = log_n > 20 ? 16 : log_n > 12 ? log_n - 4 : 8;  // T threads, >= 256
+  uint32_t logT = eval_logT(log_n);  // T threads, >= 256
   PowTab pt;
   int rc = get_powtab(point, logT, s, &pt);  // x^i, i < T
   if (rc) return rc;
@@ -2082,14 +2204,75 @@ static int eval_polys(const void* const* d_polys, size_t count, size_t n, const 
   PolyList pl;
   memset(&pl, 0, sizeof(pl));
   for (size_t i = 0; i < count; i++) pl.p[i] = (const fe*)d_polys[i];
-  EvalPowers yp;  // y = x^T, y^2, y^3 on the host (logT squarings of the same header code)
-  yp.y1 = f29_from_mont256<F9>(host_fe(point).v);
-  for (uint32_t i = 0; i < logT; i++) yp.y1 = f29_sqr<F9>(yp.y1);
-  yp.y2 = f29_sqr<F9>(yp.y1);
-  yp.y3 = f29_mul<F9>(yp.y2, yp.y1);
+  const EvalPowers yp = eval_powers(point, logT);
   H2_LAUNCH("k_eval_poly", k_eval_poly, dim3(nblocks, (uint32_t)count), 256, 0, s, pl, n, logT, yp, (const fe*)pt.lo, (const fe*)pt.hi, pt.h, g_tmp);
   H2_LAUNCH("k_sum_fe", k_sum_fe, (uint32_t)count, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
   return release_tmp(s);
+}
+
+// groups of polynomials, group g opened at points[g]: the power tables of all points in one launch, one evaluation launch, one row sum
+int h2mi_fr_eval_polys_multi_dev(const void* const* d_polys, const size_t* group_counts, const uint64_t* points, size_t ngroups, size_t n, void* d_out,
+                                 h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_polys || !group_counts || !points || !d_out || n == 0 || ngroups == 0) return H2MI_EINVAL;
+  size_t total = 0;
+  for (size_t g = 0; g < ngroups; g++) {
+    if (group_counts[g] == 0) return H2MI_EINVAL;
+    total += group_counts[g];
+  }
+  for (size_t i = 0; i < total; i++)
+    if (!d_polys[i]) return H2MI_EINVAL;
+  if (ngroups > EVAL_POINTS || total > 24) {  // beyond one launch's descriptor: group by group
+    size_t off = 0;
+    for (size_t g = 0; g < ngroups; g++) {
+      if (group_counts[g] > 24) return H2MI_EINVAL;
+      int rc = h2mi_fr_eval_polys_dev(d_polys + off, group_counts[g], n, points + 4 * g, (char*)d_out + 32 * off, stream);
+      if (rc) return rc;
+      off += group_counts[g];
+    }
+    return H2MI_OK;
+  }
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  hipStream_t s = pick_stream(stream);
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 30) return H2MI_ERANGE;
+  const uint32_t logT = eval_logT(log_n);
+  PowTab pt[EVAL_POINTS];
+  int rc = get_powtabs(points, ngroups, logT, s, pt);
+  if (rc) return rc;
+  const uint32_t nblocks = (1u << logT) / 256;
+  rc = ensure_tmp((size_t)nblocks * total + 8, s);
+  if (rc) return rc;
+  EvalMulti em;
+  memset(&em, 0, sizeof(em));
+  size_t i = 0;
+  for (size_t g = 0; g < ngroups; g++) {
+    em.yp[g] = eval_powers(points + 4 * g, logT);
+    em.lo[g] = pt[g].lo;
+    em.hi[g] = pt[g].hi;
+    for (size_t j = 0; j < group_counts[g]; j++, i++) {
+      em.p[i] = (const fe*)d_polys[i];
+      em.grp[i] = (uint8_t)g;
+    }
+  }
+  H2_LAUNCH("k_eval_poly", k_eval_poly_multi, dim3(nblocks, (uint32_t)total), 256, 0, s, em, n, logT, pt[0].h, g_tmp);
+  H2_LAUNCH("k_sum_fe", k_sum_fe, (uint32_t)total, 256, 0, s, (const fe*)g_tmp, nblocks, (fe*)d_out);
+  return release_tmp(s);
+}
+// builds (or refreshes) the cached power tables of `count` bases at the size the division / evaluation helpers use for n coefficients,
+// missing ones in one launch: call it with a rotation set's roots and their inverses before the divisions that use them
+int h2mi_fr_powtab_prefetch_dev(const uint64_t* bases, size_t count, size_t n, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!bases || count == 0 || n == 0 || count > 32) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  CallScope scope_;
+  uint32_t log_n = 0;
+  while (((size_t)1 << log_n) < n) log_n++;
+  if (log_n > 30) return H2MI_ERANGE;
+  std::vector<PowTab> out(count);
+  return get_powtabs(bases, count, log_n, pick_stream(stream), out.data());
 }
 
 int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream) {
@@ -2134,10 +2317,13 @@ int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4],
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) log_n++;
   if (log_n > 30) return H2MI_ERANGE;
-  PowTab pb, pi;
-  int rc = get_powtab(b, log_n, s, &pb);
-  if (!rc) rc = get_powtab(b_inv, log_n, s, &pi);  // exponents i + 1 <= n - 1 < 2^log_n
+  uint64_t both[8];
+  memcpy(both, b, 32);
+  memcpy(both + 4, b_inv, 32);
+  PowTab tabs[2];
+  int rc = get_powtabs(both, 2, log_n, s, tabs);  // exponents i + 1 <= n - 1 < 2^log_n; both tables in one launch
   if (rc) return rc;
+  const PowTab &pb = tabs[0], &pi = tabs[1];
   KateRoots R;
   memset(&R, 0, sizeof(R));
   R.m = 1;
@@ -2176,11 +2362,14 @@ int h2mi_fr_kate_division_multi_dev(const void* d_poly, size_t n, const uint64_t
   KateRoots R;
   memset(&R, 0, sizeof(R));
   R.m = (uint32_t)m;
+  uint64_t all[2 * KATE_MULTI_MAX * 4];  // roots, then inverses: the missing tables of both in one launch
+  memcpy(all, roots, 32 * m);
+  memcpy(all + 4 * m, roots_inv, 32 * m);
+  PowTab tabs[2 * KATE_MULTI_MAX];
+  int rc = get_powtabs(all, 2 * m, log_n, s, tabs);
+  if (rc) return rc;
   for (size_t r = 0; r < m; r++) {
-    PowTab pb, pi;
-    int rc = get_powtab(roots + 4 * r, log_n, s, &pb);
-    if (!rc) rc = get_powtab(roots_inv + 4 * r, log_n, s, &pi);
-    if (rc) return rc;
+    const PowTab &pb = tabs[r], &pi = tabs[m + r];
     R.lo[r] = pb.lo; R.hi[r] = pb.hi; R.h[r] = pb.h;
     R.ilo[r] = pi.lo; R.ihi[r] = pi.hi; R.ih[r] = pi.h;
     // the weight enters a mixed-domain product (see k_kate_finish_multi): c 2^256 -> c 2^261, i.e. five doublings

@@ -223,16 +223,21 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
         if i + 1 < len(ws.z_polys):
             written.append((zp, x_last))
     extra = [(ws.h_poly, x)]  # opened but not written (the verifier recomputes it)
-    # one launch per distinct point (x: 17 polynomials, omega x: 3, omega^last x: 2)
+    # every evaluation in ONE call, grouped by distinct point (x: 17 polynomials, omega x: 3, omega^last x: 2)
     todo = written + extra
     slot = {}
-    for pt in dict.fromkeys(p for _, p in todo):
+    points = list(dict.fromkeys(p for _, p in todo))
+    ordered, counts = [], []
+    for pt in points:
         group = [poly for poly, p in todo if p == pt]
-        ptrs = (C.c_void_p * len(group))(*[g.ptr for g in group])
-        pt_l = _m(pt)  # named: the array must outlive the call that reads its memory
-        check(lib.h2mi_fr_eval_polys_dev(ptrs, len(group), n, pt_l.ctypes.data, ws.evals.ptr + 32 * len(slot), None), "eval")
+        counts.append(len(group))
         for g in group:
             slot[(id(g), pt)] = len(slot)
+            ordered.append(g)
+    ptrs = (C.c_void_p * len(ordered))(*[g.ptr for g in ordered])
+    cnt_arr = (C.c_size_t * len(counts))(*counts)
+    pts_l = np.ascontiguousarray(np.stack([_m(pt) for pt in points]))  # named: the arrays must outlive the call that reads them
+    check(lib.h2mi_fr_eval_polys_multi_dev(ptrs, cnt_arr, pts_l.ctypes.data, len(points), n, ws.evals.ptr, None), "eval")
     ev = ws.evals.to_numpy(shape=(32, 4))
     value = {key: F.fr_from_mont_limbs(ev[i]) for key, i in slot.items()}
     for poly, pt in written:

@@ -167,6 +167,10 @@ class ProverSHPLONK:
         sets, super_points = construct_intermediate_sets(queries)
         assert len(sets) <= len(self._q)
         v = F.fr_from_mont_limbs(transcript.squeeze_challenge())
+        # the divisions below need the power tables of every opening point and of its inverse: built now, in one launch
+        if 0 < len(super_points) <= 16:
+            bases = np.ascontiguousarray(np.stack([_m(p) for p in super_points] + [_m(pow(p, -1, R)) for p in super_points]))
+            check(lib.h2mi_fr_powtab_prefetch_dev(bases.ctypes.data, len(bases), n, None), "powtab_prefetch")
         # quotient contributions Q_i = (sum_j y^j (P_ij - R_ij)) / Z_i.  The sets are independent chains of small
         # launches (one linear combination, one division per point of the set): set i runs on lane i mod 3, so the
         # longest chain, not their sum, is what the proof waits for.

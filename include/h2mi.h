@@ -201,6 +201,16 @@ int h2mi_fr_eval_poly_dev(const void* d_poly, size_t n, const uint64_t point[4],
 /* the same for `count` <= 24 polynomials of n coefficients at ONE point (create_proof evaluates every queried
  * column at x): one launch; result k at d_out + 32 k */
 int h2mi_fr_eval_polys_dev(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, h2mi_stream_t stream);
+/* every evaluation a proof writes, in ONE call: `ngroups` groups of polynomials (d_polys holds them group after group, group g has
+ * group_counts[g] members) opened at points[g] (ngroups x 4 limbs); d_out receives the values in d_polys' order.  Up to 4 points and 24
+ * polynomials share one power-table launch, one evaluation launch and one row sum (create_proof opens at x, omega x and omega^-(b+1) x:
+ * nine launches through the per-point form); larger requests are served group by group. */
+int h2mi_fr_eval_polys_multi_dev(const void* const* d_polys, const size_t* group_counts, const uint64_t* points, size_t ngroups, size_t n, void* d_out,
+                                 h2mi_stream_t stream);
+/* builds the cached power tables of `count` <= 32 bases (count x 4 limbs) at the size the helpers use for n-coefficient vectors, the
+ * missing ones in one launch: with an opening argument's roots and their inverses known up front, the divisions that follow find their
+ * tables instead of building them one launch at a time.  Purely a scheduling hint: results never depend on it. */
+int h2mi_fr_powtab_prefetch_dev(const uint64_t* bases, size_t count, size_t n, h2mi_stream_t stream);
 /* halo2_proofs::arithmetic::kate_division(a, b): quotient of a(X) by (X - b), n - 1 coefficients at d_out
  * (the remainder a(b) is dropped, as in the crate).  The caller passes b^-1 (one CPU inversion). */
 int h2mi_fr_kate_division_dev(const void* d_poly, size_t n, const uint64_t b[4], const uint64_t b_inv[4], void* d_out,

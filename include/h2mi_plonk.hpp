@@ -601,6 +601,12 @@ inline void shplonk_create_proof(size_t n, transcript::Blake2bWrite& tr, const s
     rs->members.push_back({e.first, evals});
   }
   const Fr v = tr.squeeze_challenge();
+  {  // the divisions below need the power tables of every opening point and of its inverse: built now, in one launch
+    std::vector<Fr> bases = super_points;
+    const std::vector<Fr> inv = fr::batch_invert(super_points);
+    bases.insert(bases.end(), inv.begin(), inv.end());
+    if (!bases.empty() && bases.size() <= 32) check(h2mi_fr_powtab_prefetch_dev((const uint64_t*)bases.data(), bases.size(), n, nullptr), "powtab_prefetch");
+  }
   DeviceVec &nx = *sc.nx, &tmp = *sc.tmp, &h_x = *sc.h_x, &l_x = *sc.l_x, &h2_x = *sc.h2_x;
   std::vector<Dev>& q = *sc.q;
   std::vector<Dev>& ssum = *sc.s;
@@ -885,15 +891,20 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   std::vector<Fr> distinct;
   for (const Q& q : todo)
     if (!contains(distinct, q.point)) distinct.push_back(q.point);
-  for (const Fr& pt : distinct) {  // one launch per distinct point
-    std::vector<const void*> group;
-    for (size_t i = 0; i < todo.size(); i++)
-      if (todo[i].point == pt) {
-        slot[i] = next_slot + group.size();
-        group.push_back(todo[i].poly->p);
-      }
-    check(h2mi_fr_eval_polys_dev(group.data(), group.size(), n, pt.l, (char*)evals.p + 32 * next_slot, nullptr), "eval");
-    next_slot += group.size();
+  {  // every evaluation in one call: groups by distinct point (h2mi_fr_eval_polys_multi_dev)
+    std::vector<const void*> polys;
+    std::vector<size_t> counts;
+    for (const Fr& pt : distinct) {
+      size_t cnt = 0;
+      for (size_t i = 0; i < todo.size(); i++)
+        if (todo[i].point == pt) {
+          slot[i] = next_slot + cnt++;
+          polys.push_back(todo[i].poly->p);
+        }
+      counts.push_back(cnt);
+      next_slot += cnt;
+    }
+    check(h2mi_fr_eval_polys_multi_dev(polys.data(), counts.data(), (const uint64_t*)distinct.data(), distinct.size(), n, evals.p, nullptr), "eval");
   }
   std::vector<Fr> ev(todo.size());
   check(h2mi_memcpy_d2h(ev.data(), evals.p, todo.size() * 32), "d2h");

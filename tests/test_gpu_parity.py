@@ -1164,3 +1164,54 @@ def test_msm_batch_entry_matches_single_calls_and_oracle(gpu, n, small):
         d.free()
     d_out.free()
     assert gpu.lib.h2mi_bases_release(h.value) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [300, 1 << 13, (1 << 16) + 5])
+def test_eval_polys_multi_and_powtab_prefetch_match_oracle(gpu, n):
+    """round 4: h2mi_fr_eval_polys_multi_dev (every evaluation of a proof in one call: groups of polynomials, one point per group) against
+    Horner's rule on integers, in one-launch shape (3 points, 9 polynomials), in fallback shape (5 points) and with a repeated point;
+    h2mi_fr_powtab_prefetch_dev changes nothing but the schedule: a division after it gives the oracle's quotient."""
+    from halo2_scaffold_amd.device import DevBuf
+
+    rng = np.random.default_rng(n)
+    polys = [o.random_field_limbs(n, 9100 + i) for i in range(9)]
+    ints = [o.unpack(p, o.R) for p in polys]
+    d = [DevBuf.from_numpy(p) for p in polys]
+    pts = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(5)]
+
+    def horner(c, x):
+        acc = 0
+        for v in reversed(c):
+            acc = (acc * x + v) % o.R
+        return acc
+
+    out = DevBuf(32 * 16)
+    for groups in ([[0, 1, 2, 3, 4], [5, 6], [7, 8]], [[0], [1], [2], [3], [4, 5, 6, 7, 8]], [[0, 1], [0, 1]]):
+        order = [i for g in groups for i in g]
+        ptrs = (C.c_void_p * len(order))(*[d[i].ptr for i in order])
+        counts = (C.c_size_t * len(groups))(*[len(g) for g in groups])
+        P = o.pack(pts[: len(groups)] if groups[0] != groups[-1] or len(groups) != 2 else [pts[0], pts[0]], o.R)
+        use = o.unpack(P, o.R)
+        assert gpu.lib.h2mi_fr_eval_polys_multi_dev(ptrs, counts, P.ctypes.data, len(groups), n, out.ptr, None) == 0
+        got = o.unpack(out.to_numpy(shape=(16, 4))[: len(order)], o.R)
+        want = [horner(ints[i], use[g]) for g, grp in enumerate(groups) for i in grp]
+        assert got == want
+    # prefetch of a root and its inverse, then the division that uses them
+    b = pts[0]
+    B = o.pack([b, pow(b, -1, o.R), pts[1]], o.R)
+    assert gpu.lib.h2mi_fr_powtab_prefetch_dev(B.ctypes.data, 3, n, None) == 0
+    q = DevBuf(32 * n)
+    assert gpu.lib.h2mi_memset_zero(q.ptr, 32 * n) == 0
+    assert gpu.lib.h2mi_fr_kate_division_dev(d[0].ptr, n, B[0].ctypes.data, B[1].ctypes.data, q.ptr, None) == 0
+    gotq = o.unpack(q.to_numpy(shape=(n, 4)), o.R)
+    wantq, carry = [0] * n, 0
+    for i in range(n - 1, 0, -1):  # synthetic division by (X - b)
+        carry = (ints[0][i] + carry * b) % o.R
+        wantq[i - 1] = carry
+    assert gotq[: n - 1] == wantq[: n - 1]
+    assert gpu.lib.h2mi_fr_powtab_prefetch_dev(None, 3, n, None) != 0
+    for x in d:
+        x.free()
+    out.free()
+    q.free()
