@@ -2225,10 +2225,12 @@ int h2mi_fr_eval_polys_multi_dev(const void* const* d_polys, const size_t* group
   if (ngroups > EVAL_POINTS || total > 24) {  // beyond one launch's descriptor: group by group
     size_t off = 0;
     for (size_t g = 0; g < ngroups; g++) {
-      if (group_counts[g] > 24) return H2MI_EINVAL;
-      int rc = h2mi_fr_eval_polys_dev(d_polys + off, group_counts[g], n, points + 4 * g, (char*)d_out + 32 * off, stream);
-      if (rc) return rc;
-      off += group_counts[g];
+      for (size_t c0 = 0; c0 < group_counts[g]; c0 += 24) {  // a launch's descriptor holds 24 polynomials
+        const size_t part = std::min<size_t>(24, group_counts[g] - c0);
+        int rc = h2mi_fr_eval_polys_dev(d_polys + off, part, n, points + 4 * g, (char*)d_out + 32 * off, stream);
+        if (rc) return rc;
+        off += part;
+      }
     }
     return H2MI_OK;
   }

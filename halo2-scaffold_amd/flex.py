@@ -667,16 +667,22 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     todo = written + [(h_poly, x)]
     evals = dev(len(todo) + 8)
     slot_of = {}
+    ordered, counts, group_pts = [], [], []
     for pt in dict.fromkeys(p for _, p in todo):
         group = list(dict.fromkeys(id(poly) for poly, p in todo if p == pt))
         by_id = {id(poly): poly for poly, p in todo if p == pt}
-        pt_l = _m(pt)
-        for c0 in range(0, len(group), 24):  # one launch takes up to 24 polynomials (a four-column range circuit opens 32 at x)
+        for c0 in range(0, len(group), 24):  # a group holds up to 24 polynomials (a four-column range circuit opens 32 at x)
             part = group[c0 : c0 + 24]
-            gptrs = (C.c_void_p * len(part))(*[by_id[g].ptr for g in part])
-            check(lib.h2mi_fr_eval_polys_dev(gptrs, len(part), n, pt_l.ctypes.data, evals.ptr + 32 * len(slot_of), None), "eval")
+            counts.append(len(part))
+            group_pts.append(_m(pt))
             for g in part:
                 slot_of[(g, pt)] = len(slot_of)
+                ordered.append(by_id[g])
+    # every evaluation in one call (h2mi_fr_eval_polys_multi_dev: one launch set while they fit its descriptor, group by group beyond)
+    gptrs = (C.c_void_p * len(ordered))(*[g.ptr for g in ordered])
+    cnt_arr = (C.c_size_t * len(counts))(*counts)
+    pts_l = np.ascontiguousarray(np.stack(group_pts))
+    check(lib.h2mi_fr_eval_polys_multi_dev(gptrs, cnt_arr, pts_l.ctypes.data, len(counts), n, evals.ptr, None), "eval")
     ev = evals.to_numpy(shape=(len(todo) + 8, 4))
     value = {key: F.fr_from_mont_limbs(ev[i]) for key, i in slot_of.items()}
     for poly, pt in written:

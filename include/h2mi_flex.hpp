@@ -719,18 +719,22 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   };
   std::vector<Slot> slots;
   DeviceVec& evals = ws.take(todo.size() + 8);
-  for (const Fr& pt : distinct) {
-    std::vector<const void*> group;
-    const size_t first = slots.size();
-    for (const Q& q : todo) {
-      if (!(q.point == pt)) continue;
-      bool seen = false;
-      for (size_t i = first; i < slots.size(); i++) seen = seen || slots[i].poly == q.poly;
-      if (seen) continue;
-      slots.push_back({q.poly, pt, slots.size()});
-      group.push_back(q.poly->p);
+  {  // every evaluation in one call (h2mi_fr_eval_polys_multi_dev), grouped by distinct point
+    std::vector<const void*> polys;
+    std::vector<size_t> counts;
+    for (const Fr& pt : distinct) {
+      const size_t first = slots.size();
+      for (const Q& q : todo) {
+        if (!(q.point == pt)) continue;
+        bool seen = false;
+        for (size_t i = first; i < slots.size(); i++) seen = seen || slots[i].poly == q.poly;
+        if (seen) continue;
+        slots.push_back({q.poly, pt, slots.size()});
+        polys.push_back(q.poly->p);
+      }
+      counts.push_back(slots.size() - first);
     }
-    check(h2mi_fr_eval_polys_dev(group.data(), group.size(), n, pt.l, (char*)evals.p + 32 * first, nullptr), "eval");
+    check(h2mi_fr_eval_polys_multi_dev(polys.data(), counts.data(), (const uint64_t*)distinct.data(), distinct.size(), n, evals.p, nullptr), "eval");
   }
   std::vector<Fr> ev(slots.size());
   check(h2mi_memcpy_d2h(ev.data(), evals.p, slots.size() * 32), "d2h");
