@@ -381,6 +381,19 @@ int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
     int rc = msm_join_all(primary_stream());
     if (rc) return rc;
   }
+  // small read-backs (a phase's points, a proof's evaluations: what every transcript join waits for) land in a pinned buffer of the
+  // library's: a copy to pageable memory goes through the runtime's own staging and a second wait
+  constexpr size_t PINNED_BYTES = 4096;
+  static thread_local void* pinned = nullptr;  // per calling thread: two threads may read back at once
+  if (bytes <= PINNED_BYTES && !ab_env("H2MI_NO_PINNED_READBACK")) {
+    if (!pinned && hipHostMalloc(&pinned, PINNED_BYTES, hipHostMallocPortable) != hipSuccess) pinned = nullptr;
+    if (pinned) {
+      H2_HIP(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, primary_stream()));
+      H2_HIP(hipStreamSynchronize(primary_stream()));
+      memcpy(dst, pinned, bytes);
+      return H2MI_OK;
+    }
+  }
   H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, primary_stream()));
   H2_HIP(hipStreamSynchronize(primary_stream()));
   return H2MI_OK;
