@@ -389,7 +389,7 @@ int h2mi_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
     if (!pinned && hipHostMalloc(&pinned, PINNED_BYTES, hipHostMallocPortable) != hipSuccess) pinned = nullptr;
     if (pinned) {
       H2_HIP(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, primary_stream()));
-      H2_HIP(hipStreamSynchronize(primary_stream()));
+      H2_HIP(hipStreamSynchronize(primary_stream()));  // (polling hipStreamQuery instead: no difference, measured — the runtime's wait spins)
       memcpy(dst, pinned, bytes);
       return H2MI_OK;
     }
