@@ -2451,7 +2451,15 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
   return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream));
 }
 
+static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse);
 int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
+  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, false);
+}
+int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
+                                       h2mi_stream_t stream) {
+  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"));
+}
+static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse) {
   H2_REQUIRE_INIT();
   if (!d_out_jacobian || !d_scalars || count == 0) return H2MI_EINVAL;
   for (size_t j = 0; j < count; j++)
@@ -2463,7 +2471,10 @@ int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, s
   static const bool eager = ab_env("H2MI_MSM_EAGER_TAIL") != nullptr;
   // batched launches: a plain (unsharded) handle on the library stream, narrow windows or the small path, small enough that launch
   // pace and not stage overlap is what the phase waits for; everything else is the loop the caller would have written
-  if (n != 0 && count > 1 && g_head_batch && pipelined && !eager && it != g_bases.end() && n <= it->second->n && it->second->n <= HEAD_BATCH_MAX_N) {
+  // `sparse` (the caller's promise that the columns are mostly zeros or one repeated value): the kernels of such an MSM are short at
+  // EVERY size — a 2^20-row witness column is 25 us of digit counting and a handful of 6-us kernels — so the batch is taken at any size
+  if (n != 0 && count > 1 && g_head_batch && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
+      (it->second->n <= HEAD_BATCH_MAX_N || sparse)) {
     Bases* B = it->second;
     const bool small = B->small && g_small_path;
     if (small || B->seg_log == 0) {

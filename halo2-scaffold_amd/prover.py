@@ -105,13 +105,14 @@ def _patch_cells(addrs, values: np.ndarray):
     check(lib.h2mi_fr_patch_cells_dev(ptrs, values.ctypes.data, len(addrs), None), "patch_cells")
 
 
-def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool):
+def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool, sparse: bool = False):
     """queue the commitments of one phase into result slots 0 .. len - 1 with ONE call (h2mi_msm_bn254_g1_batch_dev): below 2^17 rows
     their partition and accumulation kernels are launched once for the whole phase"""
     h = params.g_lagrange_handle if lagrange else params.g_handle
     out = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
     ptrs = (C.c_void_p * len(columns))(*[buf.ptr + (offset_elems + params.lo) * 32 for buf, offset_elems in columns])
-    check(lib.h2mi_msm_bn254_g1_batch_dev(h, ptrs, len(columns), params.n, out, None), "commit")
+    fn = lib.h2mi_msm_bn254_g1_batch_sparse_dev if sparse else lib.h2mi_msm_bn254_g1_batch_dev  # sparse: batched launches at every size
+    check(fn(h, ptrs, len(columns), params.n, out, None), "commit")
 
 
 def _commit(params: ParamsKZG, ws: ProverWorkspace, buf: DevBuf, offset_elems: int, lagrange: bool, slot: int):
@@ -156,7 +157,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
             addrs.append(col.ptr + (u + r) * 32)
             vals.append(blind[j * (bf + 1) + r])
     _patch_cells(addrs, np.ascontiguousarray(np.stack(vals)))
-    _commit_columns(params, ws, [(c, 0) for c in ws.advice], True)
+    _commit_columns(params, ws, [(c, 0) for c in ws.advice], True, sparse=True)  # a handful of assigned rows
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join below
     # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
     # y): on a side stream they run beside the commitments' bucket reductions, the transcript round trip and the
@@ -181,7 +182,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     gp.permutation_products(d.k, [ws.advice[c] for c in cs.PERMUTATION_COLUMNS], pk.permutation.values, cs.CS_DEGREE - 2, beta, gamma, u, ws.z,
                             active=pk.active_rows)
     _patch_cells([z.ptr + (u + 1 + r) * 32 for z in ws.z for r in range(bf)], np.ascontiguousarray(zblind[: len(ws.z) * bf]))
-    _commit_columns(params, ws, [(z, 0) for z in ws.z], True)
+    _commit_columns(params, ws, [(z, 0) for z in ws.z], True, sparse=True)  # constant but for the copy constraints
     check(lib.h2mi_msm_flush(), "flush")
     # the coefficient / extended forms depend on the columns only (create_proof computes them after y): queued behind
     # the commitments, they run beside the MSMs' accumulation instead of delaying the grand products

@@ -146,6 +146,12 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
  * The scalars must stay untouched until work queued on `stream` after this call would run (as for the single form). */
 int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
                                 h2mi_stream_t stream);
+/* the same, with the caller's promise that the columns are SPARSE — mostly zeros, or one value repeated almost everywhere (witness
+ * columns of a padded circuit, permutation / lookup grand products): the kernels of such an MSM are short at every size, so the batched
+ * launches are used above 2^17 points as well (narrow windows; 20-bit windows take the loop).  Results do not depend on the promise;
+ * dense columns passed here only lose the overlap between one MSM's partition and the previous one's accumulation. */
+int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
+                                       h2mi_stream_t stream);
 /* test hook: 0 makes h2mi_msm_bn254_g1_batch_dev issue its MSMs one by one (parity tests, A/B); 1 (default) batches. */
 int h2mi_dbg_msm_batch(int on);
 /* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */

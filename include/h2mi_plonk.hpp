@@ -737,8 +737,9 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   };
   auto commit = [&](uint64_t handle, const void* col, size_t slot) { check(h2mi_msm_bn254_g1_dev(handle, col, n, (char*)points.p + 96 * slot, nullptr), "commit"); };
   // the commitments of one phase (results in slots 0 .. k-1): one call, so that small circuits get one set of launches for all of them
-  auto commit_phase = [&](uint64_t handle, const std::vector<const void*>& cols) {
-    check(h2mi_msm_bn254_g1_batch_dev(handle, cols.data(), cols.size(), n, points.p, nullptr), "commit");
+  // `sparse`: witness columns and grand products of this circuit (a handful of assigned rows; constant but for the copy constraints)
+  auto commit_phase = [&](uint64_t handle, const std::vector<const void*>& cols, bool sparse = false) {
+    check((sparse ? h2mi_msm_bn254_g1_batch_sparse_dev : h2mi_msm_bn254_g1_batch_dev)(handle, cols.data(), cols.size(), n, points.p, nullptr), "commit");
   };
 
   auto phase_t0 = std::chrono::steady_clock::now();
@@ -776,7 +777,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   {
     std::vector<const void*> cols;
     for (uint32_t j = 0; j < na; j++) cols.push_back(advice[j]->p);
-    commit_phase(params.g_lagrange_handle(), cols);
+    commit_phase(params.g_lagrange_handle(), cols, /*sparse=*/true);
   }
   check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // the advice columns' coefficient / extended forms wait for no challenge: on the side stream they run beside the
@@ -817,7 +818,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   {
     std::vector<const void*> cols;
     for (uint32_t m = 0; m < na; m++) cols.push_back(z[m]->p);
-    commit_phase(params.g_lagrange_handle(), cols);
+    commit_phase(params.g_lagrange_handle(), cols, /*sparse=*/true);
   }
   check(h2mi_msm_flush(), "flush");
   // coefficient / extended forms of z, queued behind the commitments on the library stream.  (Round 4 tried the side stream, so that the

@@ -1136,6 +1136,13 @@ def test_msm_batch_entry_matches_single_calls_and_oracle(gpu, n, small):
                 for j in range(count):
                     assert o.unpack_jacobian(got[j]) == want[j], (count, batch, j)
         assert gpu.lib.h2mi_dbg_msm_batch(1) == 0
+        # the sparse-promise form batches at every size (2^18 here goes through the batched kernels); dense columns stay correct
+        for count in (3, 4):
+            ptrs = (C.c_void_p * count)(*[d.ptr for d in d_cols[1 : 1 + count]])
+            assert gpu.lib.h2mi_msm_bn254_g1_batch_sparse_dev(h.value, ptrs, count, n, d_out.ptr, None) == 0
+            got = d_out.to_numpy(shape=(2 * len(cols), 12))
+            for j in range(count):
+                assert o.unpack_jacobian(got[j]) == want[1 + j], ("sparse", count, j)
         # two batches and a single call before one join: slots are reused across them, reductions deferred together
         p3 = (C.c_void_p * 3)(*[d.ptr for d in d_cols[:3]])
         q4 = (C.c_void_p * 4)(*[d.ptr for d in d_cols[3:7]])
