@@ -519,6 +519,14 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         h = params.g_lagrange_handle if lagrange else params.g_handle
         check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + (offset_elems + params.lo) * 32, params.n, out_base + 96 * slot, None), "commit")
 
+    def commit_many(bufs, lagrange, slot0, sparse):
+        """the commitments of one phase into slots slot0 .. with ONE call (batched launches below 2^17 rows; at every size for columns the
+        caller knows to be sparse: witness columns of a padded circuit, grand products)"""
+        h = params.g_lagrange_handle if lagrange else params.g_handle
+        ptrs = (C.c_void_p * len(bufs))(*[b.ptr + params.lo * 32 for b in bufs])
+        fn = lib.h2mi_msm_bn254_g1_batch_sparse_dev if sparse else lib.h2mi_msm_bn254_g1_batch_dev
+        check(fn(h, ptrs, len(bufs), params.n, out_base + 96 * slot0, None), "commit")
+
     def forms(col, stream=None):
         p, e = dev(n), dev(ext)
         d.lagrange_to_coeff_oop_dev(col, p, stream=stream)
@@ -537,8 +545,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         col = _column_from_cells(n, cells, into=dev(n))
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
         advice.append(col)
-    for j, col in enumerate(advice):
-        commit(col, True, j)
+    commit_many(advice, True, 0, sparse=True)
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join
     # coefficient / extended forms of the advice and instance columns: no challenge enters them, so they run on the side
     # stream beside the transcript round trips, the lookup's counting sort and the grand products (see prover.py)
@@ -605,10 +612,8 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     # polynomial's accumulation — had drained, 7 ms into the phase)
     side.after_library()
     z_f = [forms(z, side.handle) for z in zs]
-    slot = 0
-    for z in zs:
-        commit(z, True, slot)
-        slot += 1
+    commit_many(zs, True, 0, sparse=True)
+    slot = len(zs)
     lzb = synth.uniform_fr(bf * max(len(lk), 1), seed + 5)
     for l, entry in enumerate(lk):
         lz = dev(n)

@@ -612,7 +612,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   std::vector<Forms> z_f;
   for (uint32_t s = 0; s < n_sets; s++) z_f.push_back(forms(*zs[s], ws.side));
   size_t slot = 0;
-  for (uint32_t s = 0; s < n_sets; s++) commit(true, zs[s]->p, slot++);
+  {  // the grand products' commitments in one call: constant but for the copy constraints, so batched at every size
+    std::vector<const void*> cols;
+    for (uint32_t s = 0; s < n_sets; s++) cols.push_back(zs[s]->p);
+    check(h2mi_msm_bn254_g1_batch_sparse_dev(params.g_lagrange_handle(), cols.data(), cols.size(), n, (char*)points.p + 96 * slot, nullptr), "commit");
+    slot += n_sets;
+  }
   std::vector<Fr> lzblind;
   if (cs.lookup) {
     lz = &ws.take(n);
