@@ -96,6 +96,21 @@ def fuzz_msm():
     for i, v in enumerate(vecs):
         assert np.array_equal(cref.normalize(got[i]), cref.normalize(cref.msm(v, bases, 8))), ("batch", seed0, n, i, seed)
     counts["msm_batches"] += 1
+    # the same vectors through the phase-level entries (round 4): batched launches, the sparse promise, mixed with single calls
+    dout2 = DevBuf(96 * q)
+    cut = rng.randint(1, q - 1)
+    ptr_a = (C.c_void_p * cut)(*[d.ptr for d in dv[:cut]])
+    ptr_b = (C.c_void_p * (q - cut))(*[d.ptr for d in dv[cut:]])
+    fa = lib.h2mi_msm_bn254_g1_batch_sparse_dev if rng.random() < 0.5 else lib.h2mi_msm_bn254_g1_batch_dev
+    lib.h2mi_dbg_msm_small_path(rng.choice((0, 1)))
+    assert fa(h.value, ptr_a, cut, n, dout2.ptr, None) == 0
+    assert lib.h2mi_msm_bn254_g1_batch_dev(h.value, ptr_b, q - cut, n, dout2.ptr + 96 * cut, None) == 0
+    got2 = dout2.to_numpy(shape=(q, 12))
+    lib.h2mi_dbg_msm_small_path(1)
+    for i in range(q):
+        assert np.array_equal(cref.normalize(got2[i]), cref.normalize(got[i])), ("phase batch", seed0, n, i, cut, seed)
+    counts["msm_phase_batches"] = counts.get("msm_phase_batches", 0) + 1
+    dout2.free()
     for d in dv:
         d.free()
     dout.free()
