@@ -2473,7 +2473,7 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
   // pace and not stage overlap is what the phase waits for; everything else is the loop the caller would have written
   // `sparse` (the caller's promise that the columns are mostly zeros or one repeated value): the kernels of such an MSM are short at
   // EVERY size — a 2^20-row witness column is 25 us of digit counting and a handful of 6-us kernels — so the batch is taken at any size
-  if (n != 0 && count > 1 && g_head_batch && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
+  if (n != 0 && count > 1 && g_head_batch && !ab_env("H2MI_MSM_NO_HEAD_BATCH") && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
       (it->second->n <= HEAD_BATCH_MAX_N || sparse)) {
     Bases* B = it->second;
     const bool small = B->small && g_small_path;
