@@ -894,14 +894,23 @@ __device__ __forceinline__ xyzz29 shfl_down_xyzz(const xyzz29& a, uint32_t delta
   }
   return r;
 }
+__device__ __forceinline__ void msm_finish_hot_body(const TailDesc& d, uint32_t bx);
+// The first `hot_blocks` workgroups of the grid are the hot-bucket finishers (msm_finish_hot_body: they and the ordinary workers touch
+// disjoint buckets, so one launch serves both — a separate launch was 5 - 9 us on every join's chain even with no hot bucket at all);
+// they come first in the grid because a hot bucket's several hundred partials are the longest chain of the launch.
 template <bool QUAD, uint32_t FG>
-__global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb) {
+__global__ void __launch_bounds__(256) k_msm_finish(const TailBatch tb, uint32_t hot_blocks) {
   const TailDesc& d = tb.d[blockIdx.y];
+  if (blockIdx.x < hot_blocks) {
+    msm_finish_hot_body(d, blockIdx.x);
+    return;
+  }
+  const uint32_t bx = blockIdx.x - hot_blocks;
   const uint32_t nb = d.nb;
   constexpr uint32_t LW = QUAD ? 2 : 0;  // log2(lanes per worker)
-  const uint32_t worker = (blockIdx.x * blockDim.x + threadIdx.x) >> LW;
+  const uint32_t worker = (bx * blockDim.x + threadIdx.x) >> LW;
   const uint32_t b = worker / FG, l = worker % FG;
-  if ((blockIdx.x * blockDim.x >> LW) / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
+  if ((bx * blockDim.x >> LW) / FG >= nb) return;  // whole workgroup beyond this MSM's buckets
   xyzz29 acc = xyzz29_identity();
   bool hot = false;
   if (b < nb) {
@@ -939,11 +948,10 @@ __device__ __forceinline__ void block_tree_sum(xyzz29* lds, uint32_t count_pow2)
 // hot buckets (the 0 / 1 buckets of sparse witness columns: hundreds of folded partials): a whole workgroup of
 // 64 quads per bucket — each quad chains cnt / 64 additions, then a 6-level tree — instead of 8 workers chaining
 // cnt / 8.  A workgroup scans 256 buckets for hot ones (none in the uniform case: it returns after one load).
-__global__ void __launch_bounds__(256) k_msm_finish_hot(const TailBatch tb) {
-  const TailDesc& d = tb.d[blockIdx.y];
+__device__ __forceinline__ void msm_finish_hot_body(const TailDesc& d, uint32_t bx) {
   __shared__ uint32_t hot_list[256], nhot;
   const uint32_t tid = threadIdx.x, quad = tid >> 2;
-  const uint32_t b = blockIdx.x * 256 + tid;
+  const uint32_t b = bx * 256 + tid;
   if (tid == 0) nhot = 0;
   __syncthreads();
   if (b < d.nb && d.np1[b] > d.hot_min) hot_list[atomicAdd(&nhot, 1u)] = b;
@@ -1991,14 +1999,17 @@ static int launch_tails(const TailBatch& tb, uint32_t count, uint32_t max_tasks1
   } else {
     H2_LAUNCH("k_msm_fold", k_msm_fold<false>, dim3(ceil_div_u32(max_tasks1, 256), count), 256, 0, t, tb);
   }
+  const uint32_t hot_blocks = ceil_div_u32(max_nb, 256);  // hot-bucket finishers: the first workgroups of the finish launch
+  const size_t hot_lds = 64 * PART_BYTES;
   if (max_seg) {
-    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_WIDE>), dim3(ceil_div_u32((uint64_t)max_nb * FG_WIDE, 256), count), 256, 0, t, tb);
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_WIDE>), dim3(hot_blocks + ceil_div_u32((uint64_t)max_nb * FG_WIDE, 256), count), 256, hot_lds, t, tb, hot_blocks);
   } else if (!force_lane && (uint64_t)max_nb * FG_NARROW * count <= 65536) {
-    H2_LAUNCH("k_msm_finish", (k_msm_finish<true, FG_NARROW>), dim3(ceil_div_u32((uint64_t)max_nb * FG_NARROW * 4, 256), count), 256, 0, t, tb);
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<true, FG_NARROW>), dim3(hot_blocks + ceil_div_u32((uint64_t)max_nb * FG_NARROW * 4, 256), count), 256, hot_lds, t, tb,
+              hot_blocks);
   } else {
-    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_NARROW>), dim3(ceil_div_u32((uint64_t)max_nb * FG_NARROW, 256), count), 256, 0, t, tb);
+    H2_LAUNCH("k_msm_finish", (k_msm_finish<false, FG_NARROW>), dim3(hot_blocks + ceil_div_u32((uint64_t)max_nb * FG_NARROW, 256), count), 256, hot_lds, t, tb,
+              hot_blocks);
   }
-  H2_LAUNCH("k_msm_hot_finish", k_msm_finish_hot, dim3(ceil_div_u32(max_nb, 256), count), 256, 64 * PART_BYTES, t, tb);
   if (max_seg) H2_LAUNCH("k_msm_seg", k_msm_seg, dim3((4u << MAT_LOG) / 256, count), 256, 0, t, tb);
   H2_LAUNCH("k_msm_rowcol", k_msm_rowcol, dim3(((max_seg ? 2u : 1u) << max_logNh) + (1u << max_logNl), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
   H2_LAUNCH("k_msm_weighted", k_msm_weighted, dim3(max_logNh + max_logNl + 1 + (max_seg ? 1 : 0), count), TAIL_THREADS, 256 * PART_BYTES, t, tb);
