@@ -213,7 +213,7 @@ def main(argv=None):
     R.finish()
     lib.h2mi_profile_enable(0)
     phases = {}
-    for name in ["k_msm_bin_count", "binscan_hipcub", "k_scan_seg", "k_msm_bin_scatter", "k_msm_bin_sort", "k_msm_accum", "k_msm_fold", "k_msm_finish", "k_msm_hot_finish", "k_msm_rowcol", "k_msm_weighted", "k_msm_final",
+    for name in ["k_msm_bin_count", "binscan_hipcub", "k_scan_seg", "k_msm_bin_scatter", "k_msm_bin_sort", "k_msm_accum", "k_msm_fold", "k_msm_finish", "k_msm_rowcol", "k_msm_weighted", "k_msm_final",
                  "k_ntt_pass_col", "k_ntt_pass_row", "k_scale_powers"]:
         lib.h2mi_profile_query(name.encode(), C.byref(tot_ms), C.byref(cnt))
         phases[name] = {"ms": round(tot_ms.value, 4), "launches": cnt.value}

@@ -34,7 +34,7 @@ for k in ks:
     p.commit_dev(sc, out); lib.h2mi_sync(); lib.h2mi_profile_enable(0)
     parts = {}
     tot, cnt = C.c_double(), C.c_uint64()
-    for name in ["k_msm_digits", "hipcub_radix", "k_msm_bounds", "k_msm_bin_count", "binscan_hipcub", "k_msm_bin_scatter", "k_msm_bin_sort", "hipcub_scan", "k_scan_segsum", "k_scan_seg_bins", "k_scan_seg_tasks", "k_msm_accum", "k_msm_fold", "k_msm_finish", "k_msm_hot_finish", "k_msm_seg", "k_msm_rowcol", "k_msm_weighted", "k_msm_final"]:
+    for name in ["k_msm_digits", "hipcub_radix", "k_msm_bounds", "k_msm_bin_count", "binscan_hipcub", "k_msm_bin_scatter", "k_msm_bin_sort", "hipcub_scan", "k_scan_segsum", "k_scan_seg_bins", "k_scan_seg_tasks", "k_msm_accum", "k_msm_fold", "k_msm_finish", "k_msm_seg", "k_msm_rowcol", "k_msm_weighted", "k_msm_final"]:
         lib.h2mi_profile_query(name.encode(), C.byref(tot), C.byref(cnt)); 
         if cnt.value: parts[name.replace("k_msm_", "")] = round(tot.value * 1e3)
     lib.h2mi_profile_reset()
