@@ -604,8 +604,8 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     zs = [dev(n) for _ in range(n_sets)]
     gp.permutation_products(d.k, perm_values, list(pk.sigma_values), cs.chunk, beta, gamma, u, zs, active=pk.active_rows)
     zblind = synth.uniform_fr(n_sets * bf, seed + 2)
-    for s, z in enumerate(zs):
-        z.patch(zblind[s * bf : (s + 1) * bf], offset=(u + 1) * 32)
+    zcells = (C.c_void_p * (n_sets * bf))(*[z.ptr + (u + 1 + r) * 32 for z in zs for r in range(bf)])  # every blinding row: one launch
+    check(lib.h2mi_fr_patch_cells_dev(zcells, np.ascontiguousarray(zblind[: n_sets * bf]).ctypes.data, n_sets * bf, None), "z blinding rows")
     # coefficient / extended forms of the grand products: on the side stream, ordered behind the columns themselves and
     # AHEAD of their commitments' partition kernels (round 3: queued behind the commitments on the library stream, the six
     # 2^24-point transforms of the DEGREE 22 range proof started only when the partitions — starved by the random

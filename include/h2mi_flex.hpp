@@ -567,8 +567,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
                                         s_perm->p, &missing, nullptr), "lookup_permute");
     if (missing) throw Error(H2MI_EINVAL, "lookup input not in the table (ConstraintSystemFailure)");
     std::vector<Fr> lb = uniform_fr(seed + 4, 2 * (bf + 1));
-    check(h2mi_memcpy_h2d_async((char*)a_perm->p + (size_t)u * 32, lb.data(), (bf + 1) * 32), "blinding rows");
-    check(h2mi_memcpy_h2d_async((char*)s_perm->p + (size_t)u * 32, lb.data() + (bf + 1), (bf + 1) * 32), "blinding rows");
+    {
+      std::vector<void*> cells;
+      for (uint32_t r = 0; r <= bf; r++) cells.push_back((char*)a_perm->p + (size_t)(u + r) * 32);
+      for (uint32_t r = 0; r <= bf; r++) cells.push_back((char*)s_perm->p + (size_t)(u + r) * 32);
+      check(h2mi_fr_patch_cells_dev(cells.data(), (const uint64_t*)lb.data(), cells.size(), nullptr), "blinding rows");
+    }
     commit(true, a_perm->p, 0);
     commit(true, s_perm->p, 1);
     check(h2mi_msm_flush(), "flush");
@@ -604,8 +608,12 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   check(h2mi_plonk_permutation_products_sparse_dev(vals.data(), sigs.data(), m, cs.chunk, d.k(), u, beta.l, gamma.l, (const uint64_t*)bd.data(), omega.l,
                                                    pk.active_rows->p, pk.n_active, zptr.data(), nullptr), "permutation_products");
   std::vector<Fr> zblind = uniform_fr(seed + 2, (size_t)n_sets * bf);
-  for (uint32_t s = 0; s < n_sets; s++)
-    check(h2mi_memcpy_h2d_async((char*)zs[s]->p + (size_t)(u + 1) * 32, &zblind[(size_t)s * bf], bf * 32), "z blinding rows");
+  {  // every grand product's blinding rows from one launch's arguments (h2mi_fr_patch_cells_dev)
+    std::vector<void*> cells;
+    for (uint32_t s = 0; s < n_sets; s++)
+      for (uint32_t r = 0; r < bf; r++) cells.push_back((char*)zs[s]->p + (size_t)(u + 1 + r) * 32);
+    check(h2mi_fr_patch_cells_dev(cells.data(), (const uint64_t*)zblind.data(), cells.size(), nullptr), "z blinding rows");
+  }
   // the grand products' coefficient / extended forms: side stream, behind the columns and AHEAD of their commitments'
   // partition kernels (which a dense accumulation in flight starves for milliseconds at DEGREE 22)
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
