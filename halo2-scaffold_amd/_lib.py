@@ -53,6 +53,7 @@ def _load():
         "h2mi_bases_info": ([C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p], C.c_int),
         "h2mi_msm_bn254_g1": ([C.c_uint64, vp, vp, sz, vp], C.c_int),
         "h2mi_msm_bn254_g1_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
+        "h2mi_msm_bn254_g1_inorder_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
         "h2mi_msm_bn254_g1_batch_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
         "h2mi_msm_bn254_g1_batch_sparse_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
         "h2mi_dbg_msm_batch": ([C.c_int], C.c_int),

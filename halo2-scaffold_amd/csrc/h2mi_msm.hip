@@ -1429,7 +1429,7 @@ static void free_bases(Bases* B) {
     }                                                          \
   } while (0)
 
-static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder = false);
 
 static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s, bool allow_small = true) {
   if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
@@ -1606,7 +1606,7 @@ static TailDesc tail_desc(const Bases* B, const Slot& S);
 // partition and the accumulation; the latency-bound bucket reduction is deferred to the next join
 // (msm_join_all: h2mi_join / h2mi_sync / h2mi_memcpy_d2h), a full batch, or the reuse of the slot.
 // On a caller-provided stream everything runs in order on that stream.
-static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s);
+static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder = false);
 static bool g_head_batch = true;  // h2mi_dbg_msm_batch(0): h2mi_msm_bn254_g1_batch_dev issues its MSMs one by one (parity tests, A/B)
 constexpr size_t HEAD_BATCH_MAX_N = (size_t)1 << 17;  // largest base set whose MSMs are partitioned and accumulated as a batch
 
@@ -1757,14 +1757,17 @@ static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, siz
   return H2MI_OK;
 }
 
-static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
-  if (B->small && g_small_path) return msm_small(B, d_scalars, n, d_out, s);
+// `inorder`: partition, accumulation and bucket reduction one after the other on `s`, nothing deferred and no stream hops — for a LONE
+// commitment whose point the caller reads next (h2mi_msm_bn254_g1_inorder_dev): the three-stream split buys overlap between consecutive
+// MSMs and costs a lone one ~50 us of event hops (2^20: 1645 -> 1580 us, 2^16: 386 -> 336)
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder) {
+  if (B->small && g_small_path) return msm_small(B, d_scalars, n, d_out, s, inorder);
   const uint32_t nb = B->nb, W = B->W;
   // dominant-value shift: only when the MSM covers every registered base (the extra base is their sum)
   const bool shifted = B->has_sum && n == B->n;
   const size_t n_eff = n + (shifted ? 1 : 0);
   const uint32_t total = (uint32_t)(n_eff * W);
-  const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
+  const bool pipelined = !inorder && (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
   B->next_slot = (B->next_slot + 1) % B->nslot;
@@ -1942,8 +1945,8 @@ static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts
 // One MSM over the first n bases of a small base set.  The digit kernel runs on the caller's stream (it is the only reader of
 // the scalars: work queued on s afterwards may overwrite them); on the library stream the accumulate + final pair is deferred
 // to the next join / flush and batched with the other small MSMs of the phase, on a caller's stream it follows in order.
-static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s) {
-  const bool pipelined = (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
+static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder) {
+  const bool pipelined = !inorder && (s == ctx().stream) && ctx().tail_stream && !getenv("H2MI_MSM_NO_PIPELINE");
   Slot& S = B->slot[B->next_slot];
   B->last_slot = B->next_slot;
   B->next_slot = (B->next_slot + 1) % B->nslot;
@@ -2443,7 +2446,14 @@ static int adhoc_handle(const uint64_t* bases, size_t n, uint64_t* handle_out) {
 // G1::identity() = (0, 1, 0) in Montgomery form: what best_multiexp returns for empty slices
 static const uint64_t G1_IDENTITY[12] = {0, 0, 0, 0, 0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL, 0, 0, 0, 0};
 
+static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder);
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
+  return msm_dev_entry(handle, d_scalars, n, d_out_jacobian, stream, false);
+}
+int h2mi_msm_bn254_g1_inorder_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
+  return msm_dev_entry(handle, d_scalars, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_INORDER"));
+}
+static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder) {
   H2_REQUIRE_INIT();
   if (!d_out_jacobian || (!d_scalars && n != 0)) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
@@ -2459,7 +2469,7 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (n > it->second->n) return H2MI_ERANGE;
-  return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream));
+  return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream), inorder);
 }
 
 static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse);

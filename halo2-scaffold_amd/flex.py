@@ -715,7 +715,8 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
     q(random_poly, x)
 
     def commit_and_write(poly):
-        commit(poly, False, 0)
+        # a lone commitment, read back at once: in order on one stream, nothing deferred (h2mi_msm_bn254_g1_inorder_dev)
+        check(lib.h2mi_msm_bn254_g1_inorder_dev(params.g_handle, poly.ptr + params.lo * 32, params.n, out_base, None), "commit")
         _write_points(ws, transcript, 1)
 
     ws.shplonk.create_proof(transcript, queries, commit_and_write)

@@ -263,7 +263,10 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
     q(ws.random_poly, x)
 
     def commit_and_write(poly: DevBuf):
-        _commit_phase(params, ws, transcript, [(poly, 0)], lagrange=False)
+        # a lone commitment, read back at once: in order on one stream, nothing deferred (h2mi_msm_bn254_g1_inorder_dev)
+        out = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
+        check(lib.h2mi_msm_bn254_g1_inorder_dev(params.g_handle, poly.ptr + params.lo * 32, params.n, out, None), "commit")
+        _write_phase_points(ws, transcript, 1)
 
     ws.shplonk.create_proof(transcript, queries, commit_and_write)
     mark("shplonk done")

@@ -137,6 +137,10 @@ int h2mi_msm_adhoc_builds(uint64_t* builds_out);
 /* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
                           h2mi_stream_t stream);
+/* the same MSM for a LONE commitment whose point the caller reads next (SHPLONK's two commitments: each is followed by a challenge):
+ * partition, accumulation and bucket reduction run in order on one stream, nothing is deferred to the join — the library's three-stream
+ * split overlaps CONSECUTIVE MSMs and costs a lone one ~50 us of stream hops.  Same result; sharded handles take the ordinary path. */
+int h2mi_msm_bn254_g1_inorder_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream);
 /* `count` MSMs of n scalars each over ONE registered base set — the commitments of a prover phase (create_proof commits a phase's
  * advice columns, then its grand products, then the quotient's pieces, each group before one challenge: reference
  * examples/standard_plonk.rs:41-49 through halo2_proofs' create_proof).  Result j goes to d_out_jacobian + 96 j; the results are the

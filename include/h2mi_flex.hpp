@@ -778,7 +778,8 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   q(&random_poly, x);
   ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, &ws.shplonk_s, ws.lanes->lanes()};
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
-    commit(false, poly.p, 0);
+    // a lone commitment, read back at once: in order on one stream, nothing deferred
+    check(h2mi_msm_bn254_g1_inorder_dev(params.g_handle(), poly.p, n, points.p, nullptr), "commit");
     write_points(1);
   }, scratch);
   check(h2mi_sync(), "sync");

@@ -933,7 +933,8 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   ShplonkScratch scratch{ws.nx.get(), ws.tmp.get(), ws.h_x.get(), ws.l_x.get(), ws.h2_x.get(), &ws.shplonk_q, &ws.shplonk_s, ws.lanes->lanes()};
   int shplonk_commit = 0;
   shplonk_create_proof(n, tr, queries, [&](DeviceVec& poly) {
-    commit(params.g_handle(), poly.p, 0);
+    // a lone commitment, read back at once: in order on one stream, nothing deferred
+    check(h2mi_msm_bn254_g1_inorder_dev(params.g_handle(), poly.p, n, points.p, nullptr), "commit");
     write_phase_points(1);
     mark(4 + shplonk_commit++);
   }, scratch);

@@ -1152,6 +1152,12 @@ def test_msm_batch_entry_matches_single_calls_and_oracle(gpu, n, small):
         got = d_out.to_numpy(shape=(2 * len(cols), 12))
         for j in range(8):
             assert o.unpack_jacobian(got[j]) == want[j], ("mixed", j)
+        # the in-order form of a lone commitment (nothing deferred, one stream), between two deferred ones
+        assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_cols[0].ptr, n, d_out.ptr, None) == 0
+        assert gpu.lib.h2mi_msm_bn254_g1_inorder_dev(h.value, d_cols[4].ptr, n, d_out.ptr + 96, None) == 0
+        assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_cols[2].ptr, n, d_out.ptr + 192, None) == 0
+        got = d_out.to_numpy(shape=(2 * len(cols), 12))
+        assert [o.unpack_jacobian(got[j]) for j in range(3)] == [want[0], want[4], want[2]]
         # a prefix of the base set: no sum point, no shift
         m = n - 5
         wantp = [o.unpack_jacobian(cref.msm(np.ascontiguousarray(c[:m]), bases[:m], 8)) for c in cols[:3]]
