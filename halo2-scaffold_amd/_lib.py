@@ -56,6 +56,7 @@ def _load():
         "h2mi_msm_bn254_g1_inorder_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
         "h2mi_msm_bn254_g1_batch_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
         "h2mi_msm_bn254_g1_batch_sparse_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
+        "h2mi_msm_bn254_g1_phase_dev": ([C.c_uint64, vp, sz, sz, vp, C.c_uint, vp], C.c_int),
         "h2mi_dbg_msm_batch": ([C.c_int], C.c_int),
         "h2mi_msm_adhoc_builds": ([u64p], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),

@@ -1613,14 +1613,15 @@ constexpr size_t HEAD_BATCH_MAX_N = (size_t)1 << 17;  // largest base set whose 
 // `m` <= HEAD_BATCH MSMs of n scalars each over B, results to d_out + 96 j: what m calls of msm_dev would compute, with the partition
 // and the accumulation of all m as ONE set of launches (narrow windows, library stream).  Slots, events and the deferred bucket
 // reductions are those of m single calls.
-static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s) {
+static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s, bool inorder) {
   const uint32_t nb = B->nb, W = B->W;
   const bool shifted = B->has_sum && n == B->n;
   const size_t n_eff = n + (shifted ? 1 : 0);
   const uint32_t total = (uint32_t)(n_eff * W);
   // the second partition level and the accumulation share ONE stream here: the separate accumulation stream exists so that the next
   // MSM's partition overlaps this one's accumulation, which a batch does not need — and a stream hop is ~10 us on the phase's critical path
-  hipStream_t hs = ctx().head_stream, as = hs;
+  // `inorder` (the batch is all its phase commits and is read back next): everything, the bucket reductions included, on `s` itself
+  hipStream_t hs = inorder ? s : ctx().head_stream, as = hs;
   uint32_t s0_fixed = chunk_override();
   while (s0_fixed && s0_fixed < S0_MAX && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) s0_fixed++;
   if (s0_fixed && ((uint64_t)total + s0_fixed - 1) / s0_fixed + nb > B->max_tasks0) return H2MI_ERANGE;
@@ -1684,8 +1685,10 @@ static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_
 #undef H2_BIN_COUNT_B
 #undef H2_BIN_SCATTER_B
   // one event for the batch's inputs; the slots' own events for what later calls wait on per slot
-  H2_HIP(hipEventRecord(slots[0]->input_ready, s));
-  H2_HIP(hipStreamWaitEvent(hs, slots[0]->input_ready, 0));
+  if (hs != s) {
+    H2_HIP(hipEventRecord(slots[0]->input_ready, s));
+    H2_HIP(hipStreamWaitEvent(hs, slots[0]->input_ready, 0));
+  }
   for (size_t j = 0; j < m; j++) {
     Slot& S = *slots[j];
     if (S.accum_pending) H2_HIP(hipStreamWaitEvent(hs, S.accum_done, 0));
@@ -1711,15 +1714,33 @@ static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_
     H2_HIP(hipEventRecord(S.accum_done, as));
     S.accum_pending = true;
     S.accum_ever = true;
-    S.tail_deferred = true;
-    g_deferred.push_back({B, &S});
+    if (!inorder) {
+      S.tail_deferred = true;
+      g_deferred.push_back({B, &S});
+    }
+  }
+  if (inorder) {  // the batch's own reductions at once, behind its accumulation on the same stream
+    TailBatch tb;
+    for (size_t j = 0; j < m; j++) tb.d[j] = tail_desc(B, *slots[j]);
+    for (size_t j = m; j < TAIL_BATCH; j++) tb.d[j] = tb.d[0];
+    int rc = launch_tails(tb, mm, slots[0]->tasks1, nb, B->logNh, B->logNl, B->seg_log, s);
+    if (rc) return rc;
+    for (size_t j = 0; j < m; j++) {
+      Slot& S = *slots[j];
+      H2_HIP(hipEventRecord(S.tail_done, s));
+      S.tail_pending = true;
+      S.tail_ever = true;
+    }
+    return H2MI_OK;
   }
   if (g_deferred.size() >= (size_t)std::max(1, B->nslot / 2)) return flush_tails();
   return H2MI_OK;
 }
 
 // the small path's batch: one digit launch for the m MSMs; their accumulate / final pair is deferred and batched as ever
-static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s) {
+static SmallDesc small_desc(const Bases* B, const Slot& S);
+static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts, hipStream_t t);
+static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, size_t n, void* d_out, hipStream_t s, bool inorder) {
   SmallHeadBatch hb;
   memset(&hb, 0, sizeof(hb));
   Slot* slots[HEAD_BATCH];
@@ -1744,6 +1765,24 @@ static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, siz
   }
   for (size_t j = m; j < HEAD_BATCH; j++) { hb.scalars[j] = hb.scalars[0]; hb.dig[j] = hb.dig[0]; }
   H2_LAUNCH("k_msm_small_digits", k_msm_small_digits_b, dim3(ceil_div_u32(n, 64), (uint32_t)m), 64, 0, s, hb, (uint32_t)n, (uint32_t)B->n, B->sc, B->sW);
+  if (inorder) {  // accumulate + final for the batch at once (on the small path they run on `s` anyway: nothing to defer for)
+    SmallBatch sb;
+    uint32_t max_parts = 0;
+    for (size_t j = 0; j < m; j++) {
+      sb.d[j] = small_desc(B, *slots[j]);
+      max_parts = std::max(max_parts, sb.d[j].G);
+    }
+    for (size_t j = m; j < SMALL_BATCH; j++) sb.d[j] = sb.d[0];
+    int rc = launch_small(sb, (uint32_t)m, max_parts, s);
+    if (rc) return rc;
+    for (size_t j = 0; j < m; j++) {
+      Slot& S = *slots[j];
+      H2_HIP(hipEventRecord(S.tail_done, s));
+      S.tail_pending = true;
+      S.tail_ever = true;
+    }
+    return H2MI_OK;
+  }
   for (size_t j = 0; j < m; j++) {
     Slot& S = *slots[j];
     H2_HIP(hipEventRecord(S.accum_done, s));  // "inputs consumed": what the deferred pair waits for
@@ -2472,15 +2511,23 @@ static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void*
   return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream), inorder);
 }
 
-static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse);
+static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse,
+                           bool inorder);
 int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
-  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, false);
+  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, false, false);
 }
 int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
                                        h2mi_stream_t stream) {
-  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"));
+  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"), false);
 }
-static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse) {
+int h2mi_msm_bn254_g1_phase_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, unsigned flags,
+                                h2mi_stream_t stream) {
+  if (flags & ~(unsigned)(H2MI_MSM_SPARSE | H2MI_MSM_INORDER)) return H2MI_EINVAL;
+  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, (flags & H2MI_MSM_SPARSE) && !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"),
+                         (flags & H2MI_MSM_INORDER) && !ab_env("H2MI_MSM_IGNORE_INORDER"));
+}
+static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse,
+                           bool inorder) {
   H2_REQUIRE_INIT();
   if (!d_out_jacobian || !d_scalars || count == 0) return H2MI_EINVAL;
   for (size_t j = 0; j < count; j++)
@@ -2494,6 +2541,7 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
   // pace and not stage overlap is what the phase waits for; everything else is the loop the caller would have written
   // `sparse` (the caller's promise that the columns are mostly zeros or one repeated value): the kernels of such an MSM are short at
   // EVERY size — a 2^20-row witness column is 25 us of digit counting and a handful of 6-us kernels — so the batch is taken at any size
+  if (count == 1 && inorder) return msm_dev_entry(handle, d_scalars[0], n, d_out_jacobian, stream, true);
   if (n != 0 && count > 1 && g_head_batch && !ab_env("H2MI_MSM_NO_HEAD_BATCH") && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
       (it->second->n <= HEAD_BATCH_MAX_N || sparse)) {
     Bases* B = it->second;
@@ -2501,8 +2549,8 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
     if (small || B->seg_log == 0) {
       for (size_t j0 = 0; j0 < count;) {
         const size_t m = std::min({count - j0, (size_t)HEAD_BATCH, (size_t)B->nslot});
-        int rc = small ? msm_small_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s)
-                       : msm_dev_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s);
+        int rc = small ? msm_small_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s, inorder)
+                       : msm_dev_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s, inorder);
         if (rc) return rc;
         j0 += m;
       }

@@ -95,7 +95,7 @@ def _write_phase_points(ws: ProverWorkspace, transcript, k: int):
 def _commit_phase(params: ParamsKZG, ws: ProverWorkspace, transcript, columns, lagrange: bool):
     """commit the columns of one phase (MSMs queued back to back, bucket reductions batched by the join) and write the
     points to the transcript"""
-    _commit_columns(params, ws, columns, lagrange)
+    _commit_columns(params, ws, columns, lagrange, inorder=True)
     _write_phase_points(ws, transcript, len(columns))
 
 
@@ -105,14 +105,15 @@ def _patch_cells(addrs, values: np.ndarray):
     check(lib.h2mi_fr_patch_cells_dev(ptrs, values.ctypes.data, len(addrs), None), "patch_cells")
 
 
-def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool, sparse: bool = False):
+def _commit_columns(params: ParamsKZG, ws: ProverWorkspace, columns, lagrange: bool, sparse: bool = False, inorder: bool = False):
     """queue the commitments of one phase into result slots 0 .. len - 1 with ONE call (h2mi_msm_bn254_g1_batch_dev): below 2^17 rows
     their partition and accumulation kernels are launched once for the whole phase"""
     h = params.g_lagrange_handle if lagrange else params.g_handle
     out = ws.combiner.partial_ptr if ws.combiner is not None else ws.points.ptr
     ptrs = (C.c_void_p * len(columns))(*[buf.ptr + (offset_elems + params.lo) * 32 for buf, offset_elems in columns])
-    fn = lib.h2mi_msm_bn254_g1_batch_sparse_dev if sparse else lib.h2mi_msm_bn254_g1_batch_dev  # sparse: batched launches at every size
-    check(fn(h, ptrs, len(columns), params.n, out, None), "commit")
+    # flags: 1 = the sparse promise (batched launches at every size), 2 = in order (the group is all its phase commits and is read back
+    # next: its bucket reductions follow its accumulation on one stream) — H2MI_MSM_SPARSE / H2MI_MSM_INORDER of h2mi.h
+    check(lib.h2mi_msm_bn254_g1_phase_dev(h, ptrs, len(columns), params.n, out, (1 if sparse else 0) | (2 if inorder else 0), None), "commit")
 
 
 def _commit(params: ParamsKZG, ws: ProverWorkspace, buf: DevBuf, offset_elems: int, lagrange: bool, slot: int):
@@ -157,7 +158,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, circuit, seed: int, transcri
             addrs.append(col.ptr + (u + r) * 32)
             vals.append(blind[j * (bf + 1) + r])
     _patch_cells(addrs, np.ascontiguousarray(np.stack(vals)))
-    _commit_columns(params, ws, [(c, 0) for c in ws.advice], True, sparse=True)  # a handful of assigned rows
+    _commit_columns(params, ws, [(c, 0) for c in ws.advice], True, sparse=True, inorder=True)  # a handful of assigned rows
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join below
     # The coefficient / extended forms of the advice columns depend on no challenge (create_proof computes them after
     # y): on a side stream they run beside the commitments' bucket reductions, the transcript round trip and the

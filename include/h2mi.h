@@ -156,6 +156,13 @@ int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, s
  * dense columns passed here only lose the overlap between one MSM's partition and the previous one's accumulation. */
 int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
                                        h2mi_stream_t stream);
+/* the general form of the three entries above: `flags` = H2MI_MSM_SPARSE (the sparse promise) | H2MI_MSM_INORDER (the group is all its
+ * phase commits and its points are read back next: partition, accumulation AND bucket reductions of the group run on one stream, nothing is
+ * deferred — where the batched launches are taken; a dense group above 2^17 points keeps the pipelined loop, whose overlap is worth more). */
+#define H2MI_MSM_SPARSE 1u
+#define H2MI_MSM_INORDER 2u
+int h2mi_msm_bn254_g1_phase_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, unsigned flags,
+                                h2mi_stream_t stream);
 /* test hook: 0 makes h2mi_msm_bn254_g1_batch_dev issue its MSMs one by one (parity tests, A/B); 1 (default) batches. */
 int h2mi_dbg_msm_batch(int on);
 /* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */

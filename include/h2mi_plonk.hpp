@@ -738,8 +738,10 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   auto commit = [&](uint64_t handle, const void* col, size_t slot) { check(h2mi_msm_bn254_g1_dev(handle, col, n, (char*)points.p + 96 * slot, nullptr), "commit"); };
   // the commitments of one phase (results in slots 0 .. k-1): one call, so that small circuits get one set of launches for all of them
   // `sparse`: witness columns and grand products of this circuit (a handful of assigned rows; constant but for the copy constraints)
-  auto commit_phase = [&](uint64_t handle, const std::vector<const void*>& cols, bool sparse = false) {
-    check((sparse ? h2mi_msm_bn254_g1_batch_sparse_dev : h2mi_msm_bn254_g1_batch_dev)(handle, cols.data(), cols.size(), n, points.p, nullptr), "commit");
+  // `inorder`: the group is everything its phase commits and is read back next — its reductions follow its accumulation on one stream
+  auto commit_phase = [&](uint64_t handle, const std::vector<const void*>& cols, bool sparse = false, bool inorder = false) {
+    const unsigned flags = (sparse ? H2MI_MSM_SPARSE : 0u) | (inorder ? H2MI_MSM_INORDER : 0u);
+    check(h2mi_msm_bn254_g1_phase_dev(handle, cols.data(), cols.size(), n, points.p, flags, nullptr), "commit");
   };
 
   auto phase_t0 = std::chrono::steady_clock::now();
@@ -777,7 +779,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   {
     std::vector<const void*> cols;
     for (uint32_t j = 0; j < na; j++) cols.push_back(advice[j]->p);
-    commit_phase(params.g_lagrange_handle(), cols, /*sparse=*/true);
+    commit_phase(params.g_lagrange_handle(), cols, /*sparse=*/true, /*inorder=*/true);
   }
   check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // the advice columns' coefficient / extended forms wait for no challenge: on the side stream they run beside the
@@ -854,7 +856,7 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const ProvingKey& p
   {
     std::vector<const void*> cols;
     for (uint32_t i = 0; i < pieces; i++) cols.push_back((char*)h.p + (size_t)i * n * 32);
-    commit_phase(params.g_handle(), cols);
+    commit_phase(params.g_handle(), cols, /*sparse=*/false, /*inorder=*/true);
   }
   write_phase_points(pieces);
   mark(2);

@@ -1152,6 +1152,13 @@ def test_msm_batch_entry_matches_single_calls_and_oracle(gpu, n, small):
         got = d_out.to_numpy(shape=(2 * len(cols), 12))
         for j in range(8):
             assert o.unpack_jacobian(got[j]) == want[j], ("mixed", j)
+        # the general entry with every flag combination (1 = sparse promise, 2 = in order)
+        for flags in (0, 1, 2, 3):
+            p4 = (C.c_void_p * 4)(*[d.ptr for d in d_cols[2:6]])
+            assert gpu.lib.h2mi_msm_bn254_g1_phase_dev(h.value, p4, 4, n, d_out.ptr, flags, None) == 0
+            got = d_out.to_numpy(shape=(2 * len(cols), 12))
+            assert [o.unpack_jacobian(got[j]) for j in range(4)] == want[2:6], ("phase flags", flags)
+        assert gpu.lib.h2mi_msm_bn254_g1_phase_dev(h.value, p4, 4, n, d_out.ptr, 8, None) != 0  # unknown flag
         # the in-order form of a lone commitment (nothing deferred, one stream), between two deferred ones
         assert gpu.lib.h2mi_msm_bn254_g1_dev(h.value, d_cols[0].ptr, n, d_out.ptr, None) == 0
         assert gpu.lib.h2mi_msm_bn254_g1_inorder_dev(h.value, d_cols[4].ptr, n, d_out.ptr + 96, None) == 0
