@@ -519,13 +519,14 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         h = params.g_lagrange_handle if lagrange else params.g_handle
         check(lib.h2mi_msm_bn254_g1_dev(h, buf.ptr + (offset_elems + params.lo) * 32, params.n, out_base + 96 * slot, None), "commit")
 
-    def commit_many(bufs, lagrange, slot0, sparse):
+    def commit_many(bufs, lagrange, slot0, sparse, inorder=False, offsets=None):
         """the commitments of one phase into slots slot0 .. with ONE call (batched launches below 2^17 rows; at every size for columns the
         caller knows to be sparse: witness columns of a padded circuit, grand products)"""
         h = params.g_lagrange_handle if lagrange else params.g_handle
-        ptrs = (C.c_void_p * len(bufs))(*[b.ptr + params.lo * 32 for b in bufs])
-        fn = lib.h2mi_msm_bn254_g1_batch_sparse_dev if sparse else lib.h2mi_msm_bn254_g1_batch_dev
-        check(fn(h, ptrs, len(bufs), params.n, out_base + 96 * slot0, None), "commit")
+        offsets = offsets or [0] * len(bufs)
+        ptrs = (C.c_void_p * len(bufs))(*[b.ptr + (off + params.lo) * 32 for b, off in zip(bufs, offsets)])
+        # flags: 1 = sparse promise, 2 = in order (the group is all its phase commits and is read back next): h2mi.h H2MI_MSM_*
+        check(lib.h2mi_msm_bn254_g1_phase_dev(h, ptrs, len(bufs), params.n, out_base + 96 * slot0, (1 if sparse else 0) | (2 if inorder else 0), None), "commit")
 
     def forms(col, stream=None):
         p, e = dev(n), dev(ext)
@@ -545,7 +546,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
         col = _column_from_cells(n, cells, into=dev(n))
         col.patch(blind[j * (bf + 1) : (j + 1) * (bf + 1)], offset=u * 32)
         advice.append(col)
-    commit_many(advice, True, 0, sparse=True)
+    commit_many(advice, True, 0, sparse=True, inorder=True)
     check(lib.h2mi_msm_flush(), "flush")  # the bucket reductions start now, not when the host reaches the join
     # coefficient / extended forms of the advice and instance columns: no challenge enters them, so they run on the side
     # stream beside the transcript round trips, the lookup's counting sort and the grand products (see prover.py)
@@ -647,8 +648,7 @@ def _create_proof(params: ParamsKZG, pk: FlexKeys, asg: Assignment, seed: int, t
                            pk.l0, pk.l_last, pk.l_active, beta, gamma, y, h, blinding_factors=bf)
     d.extended_to_coeff_dev(h)
     pieces = d.quotient_poly_degree
-    for i in range(pieces):
-        commit(h, False, i, offset_elems=i * n)
+    commit_many([h] * pieces, False, 0, sparse=False, inorder=True, offsets=[i * n for i in range(pieces)])
     _write_points(ws, transcript, pieces)
     x = sq()
     xn = pow(x, n, R)

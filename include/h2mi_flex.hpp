@@ -538,7 +538,8 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
   check(h2mi_memcpy_h2d(advice.p, asg.advice.data(), asg.advice.size() * 32), "advice cells");
   std::vector<Fr> blind = uniform_fr(seed + 1, bf + 1);
   check(h2mi_memcpy_h2d_async((char*)advice.p + (size_t)u * 32, blind.data(), (bf + 1) * 32), "blinding rows");
-  commit(true, advice.p, 0);
+  // the one advice column: a lone commitment read back next — in order on one stream, nothing deferred
+  check(h2mi_msm_bn254_g1_inorder_dev(params.g_lagrange_handle(), advice.p, n, points.p, nullptr), "commit");
   check(h2mi_msm_flush(), "flush");  // the bucket reductions start now, not when the host reaches the join
   // coefficient / extended forms that wait for no challenge: on the side stream, beside the transcript round trips
   check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
@@ -573,8 +574,10 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
       for (uint32_t r = 0; r <= bf; r++) cells.push_back((char*)s_perm->p + (size_t)(u + r) * 32);
       check(h2mi_fr_patch_cells_dev(cells.data(), (const uint64_t*)lb.data(), cells.size(), nullptr), "blinding rows");
     }
-    commit(true, a_perm->p, 0);
-    commit(true, s_perm->p, 1);
+    {  // the permuted pair is all this phase commits and is read back next
+      const void* cols[2] = {a_perm->p, s_perm->p};
+      check(h2mi_msm_bn254_g1_phase_dev(params.g_lagrange_handle(), cols, 2, n, points.p, H2MI_MSM_INORDER, nullptr), "commit");
+    }
     check(h2mi_msm_flush(), "flush");
     check(h2mi_stream_wait(ws.side, nullptr), "stream_wait");
     ap_f = forms(*a_perm, ws.side);
@@ -680,7 +683,11 @@ inline void create_proof(const poly::kzg::ParamsKZG& params, const FlexKeys& pk,
     check(h2mi_fr_scale_powers_dev(h.p, ext, d.get_g_coset_inv().l, d.get_extended_ifft_divisor().l, nullptr), "distribute_powers_zeta");
   }
   const uint32_t pieces = cs.degree - 1;
-  for (uint32_t i = 0; i < pieces; i++) commit(false, (char*)h.p + (size_t)i * n * 32, i);
+  {
+    std::vector<const void*> cols;
+    for (uint32_t i = 0; i < pieces; i++) cols.push_back((char*)h.p + (size_t)i * n * 32);
+    check(h2mi_msm_bn254_g1_phase_dev(params.g_handle(), cols.data(), cols.size(), n, points.p, H2MI_MSM_INORDER, nullptr), "commit");
+  }
   write_points(pieces);
   const Fr x = tr.squeeze_challenge();
   const Fr xn = fr::pow_u64(x, n);
