@@ -2543,7 +2543,7 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
   // EVERY size — a 2^20-row witness column is 25 us of digit counting and a handful of 6-us kernels — so the batch is taken at any size
   if (count == 1 && inorder) return msm_dev_entry(handle, d_scalars[0], n, d_out_jacobian, stream, true);
   if (n != 0 && count > 1 && g_head_batch && !ab_env("H2MI_MSM_NO_HEAD_BATCH") && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
-      (it->second->n <= HEAD_BATCH_MAX_N || sparse)) {
+      (it->second->n <= (ab_env("H2MI_HEAD_BATCH_MAX_LOG") ? (size_t)1 << atoi(ab_env("H2MI_HEAD_BATCH_MAX_LOG")) : HEAD_BATCH_MAX_N) || sparse)) {
     Bases* B = it->second;
     const bool small = B->small && g_small_path;
     if (small || B->seg_log == 0) {
