@@ -2608,7 +2608,7 @@ int h2mi_msm_bn254_g1(uint64_t handle, const uint64_t* bases, const uint64_t* sc
   // nothing deferred: ~50 us less than the pipelined form) and the 96 bytes come back through pinned memory
   if (!rc) rc = msm_dev(it->second, d + 96, n, d, s, /*inorder=*/!ab_env("H2MI_MSM_IGNORE_INORDER"));
   if (!rc) rc = msm_join_all(s);
-  static thread_local void* pinned = nullptr;
+  static thread_local void* pinned = nullptr;  // 96 B of pinned host memory per calling thread, kept for the life of the thread
   if (!pinned && hipHostMalloc(&pinned, 96, hipHostMallocPortable) != hipSuccess) pinned = nullptr;
   void* back = pinned ? pinned : (void*)out;
   if (!rc && hipMemcpyAsync(back, d, 96, hipMemcpyDeviceToHost, s) != hipSuccess) rc = H2MI_EHIP;
