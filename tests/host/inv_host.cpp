@@ -1,6 +1,6 @@
 // Host-side test shim for include/h2mi.hpp's single-element inversion (detail::inv_mod_odd): tests/test_host.py drives it
 // against Python's pow(x, -1, p).  Test infrastructure, not product.
-#include "../../include/h2mi_plonk.hpp"
+#include "../../halo2-scaffold_amd/csrc/h2mi_hostmath.hpp"
 #include "../../halo2-scaffold_amd/csrc/inv_divsteps.cuh"
 
 extern "C" {

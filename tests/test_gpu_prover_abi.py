@@ -1,0 +1,225 @@
+"""The resident prover behind its phase-level C ABI (include/h2mi_prover.h; round 5).
+
+create_proof as the reference's callers see it (examples/standard_plonk.rs:40-50, src/scaffold.rs:322-331) is driven here through
+ONLY h2mi_prover_* calls plus the Python Blake2b transcript — every other export of the library is made to raise while a proof
+runs — and reproduces every committed golden proof of the small sizes (tests/golden/standard_plonk_proofs.json,
+flex_proofs.json, flex_multi_proofs.json; the 2^16 / 2^20 / 2^22 goldens run through the same path in
+tests/test_gpu_big_golden.py).  Then the ABI's own contract: phase order, key / prover lifetimes, validation of the constraint
+system, error codes."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class _OnlyProver:
+    """stands where engine.lib does while a proof runs: h2mi_prover_* pass through (and are counted), anything else raises"""
+
+    def __init__(self, real):
+        self._real, self.calls = real, {}
+
+    def __getattr__(self, name):
+        if not name.startswith("h2mi_prover_"):
+            raise AssertionError(f"create_proof reached past the prover ABI: {name}")
+        self.calls[name] = self.calls.get(name, 0) + 1
+        return getattr(self._real, name)
+
+
+@pytest.fixture
+def only_prover(gpu, monkeypatch):
+    from halo2_scaffold_amd import engine
+
+    spy = _OnlyProver(engine.lib)
+
+    def arm():
+        monkeypatch.setattr(engine, "lib", spy)
+
+    def disarm():
+        monkeypatch.setattr(engine, "lib", spy._real)
+
+    spy.arm, spy.disarm = arm, disarm
+    yield spy
+    disarm()
+
+
+def test_golden_proofs_through_prover_calls_only(gpu, only_prover):
+    from halo2_scaffold_amd import circuits, flex, keygen, poseidon, prover
+
+    spy = only_prover
+    proofs = 0
+    g = json.load(open(os.path.join(GOLD, "standard_plonk_proofs.json")))
+    for case in g["cases"]:
+        params = gpu.ParamsKZG.setup(case["k"], int(g["srs_secret"], 16))
+        circuit = circuits.StandardPlonk(None)
+        vk = keygen.keygen_vk(params, circuit)
+        pk = keygen.keygen_pk(params, vk, circuit)
+        assert vk.to_bytes().hex() == case["vk_bytes"]
+        ws = prover.ProverWorkspace(params, pk)
+        spy.arm()
+        proof = prover.create_proof(params, pk, circuits.StandardPlonk(int(case["witness_x"], 16)), case["seed"], ws=ws)
+        spy.disarm()
+        assert proof.hex() == case["proof"]
+        proofs += 1
+        ws.release()
+        pk.release()
+        params.release()
+    for name in ("flex_proofs.json", "flex_multi_proofs.json"):
+        g = json.load(open(os.path.join(GOLD, name)))
+        for case in g["cases"]:
+            shape, k, bits, x, seed = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16), case["seed"]
+            closure = ((lambda cs: flex.range_closure(cs, x, bits)) if shape == "range" else (lambda cs: poseidon.hash_two_closure(cs, x, x + 1))
+                       if shape == "poseidon" else (lambda cs: flex.halo2_lib_closure(cs, x)))
+            cs = flex.configure(shape == "range", k, closure) if "num_advice" in case else flex.FlexGateCS(lookup=shape == "range")
+            asg = closure(cs)
+            params = gpu.ParamsKZG.setup(k, int(g["srs_secret"], 16))
+            keys = flex.FlexKeys(params, cs, asg)
+            assert keys.vk_bytes().hex() == case["vk_bytes"], (name, shape, k)
+            ws = flex.FlexWorkspace(params, keys)
+            spy.arm()
+            proof = flex.create_proof(params, keys, asg, seed, ws=ws)
+            spy.disarm()
+            assert proof.hex() == case["proof"], (name, shape, k, bits)
+            proofs += 1
+            ws.release()
+            keys.release()
+            params.release()
+    assert proofs >= 8
+    # seven phase calls per proof (six without lookups), nothing else
+    per_proof = {"h2mi_prover_advice", "h2mi_prover_products", "h2mi_prover_quotient", "h2mi_prover_evaluations", "h2mi_prover_shplonk_quotient",
+                 "h2mi_prover_shplonk_open"}
+    assert set(spy.calls) - {"h2mi_prover_lookups"} == per_proof
+    assert all(spy.calls[name] == proofs for name in per_proof) and 0 < spy.calls["h2mi_prover_lookups"] < proofs
+
+
+def _standard_keys(gpu, k):
+    from halo2_scaffold_amd import circuits, keygen
+
+    params = gpu.ParamsKZG.setup(k, 0x5EC2E7)
+    circuit = circuits.StandardPlonk(None)
+    pk = keygen.keygen_pk(params, keygen.keygen_vk(params, circuit), circuit)
+    return params, pk
+
+
+def test_phase_order_and_lifetimes(gpu):
+    from halo2_scaffold_amd import circuits, engine, keygen, prover
+
+    lib = gpu.lib
+    params, pk = _standard_keys(gpu, 6)
+    ws = prover.ProverWorkspace(params, pk)
+    h = ws.prover.handle
+    pts = np.zeros((8, 8), dtype=np.uint64)
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    # a phase before its predecessor: H2MI_EINVAL, and the proof in flight is abandoned
+    assert lib.h2mi_prover_quotient(h, one.ctypes.data, pts.ctypes.data) == -1
+    assert lib.h2mi_prover_shplonk_open(h, one.ctypes.data, pts.ctypes.data) == -1
+    cells, keep = engine.pack_cells(circuits.StandardPlonk(5).synthesize().advice)
+    assert lib.h2mi_prover_advice(h, cells, None, 0, 3, pts.ctypes.data) == 0
+    assert pts[:3].any(axis=1).all()
+    assert lib.h2mi_prover_quotient(h, one.ctypes.data, pts.ctypes.data) == -1            # products first
+    assert lib.h2mi_prover_products(h, one.ctypes.data, one.ctypes.data, pts.ctypes.data) == -1  # ... and the slip reset the proof
+    assert lib.h2mi_prover_advice(h, cells, None, 0, 1 << 32, pts.ctypes.data) == -1      # seed must be below 2^32
+    # public inputs for a circuit without an instance column
+    assert lib.h2mi_prover_advice(h, cells, one.ctypes.data, 1, 3, pts.ctypes.data) == -1
+    # a cell in the blinding rows
+    bad = [{(1 << 6) - 3: 1}, {}, {}]
+    bcells, bkeep = engine.pack_cells(bad)
+    assert lib.h2mi_prover_advice(h, bcells, None, 0, 3, pts.ctypes.data) == -6
+    # a full proof still works afterwards, and equals a fresh workspace's
+    p1 = prover.create_proof(params, pk, circuits.StandardPlonk(77), 9, ws=ws)
+    assert p1 == prover.create_proof(params, pk, circuits.StandardPlonk(77), 9)
+    # lifetimes: the key cannot go while a prover uses it; handles are checked
+    assert lib.h2mi_prover_pk_release(pk.keys.handle) == -1
+    assert lib.h2mi_prover_destroy(h) == 0 and lib.h2mi_prover_destroy(h) == -5
+    ws.prover.handle = None
+    assert lib.h2mi_prover_advice(h, cells, None, 0, 3, pts.ctypes.data) == -5
+    pk.release()
+    # vk-only keys hold no proving key
+    vko = keygen._keygen(params, circuits.StandardPlonk(None), vk_only=True)
+    out = C.c_void_p()
+    assert lib.h2mi_prover_create(vko.handle, params.g_handle, params.g_lagrange_handle, 0, params.n, C.byref(out)) == -1
+    vko.release()
+    params.release()
+
+
+def test_constraint_system_validation(gpu):
+    from halo2_scaffold_amd import circuits, engine, flex, keygen
+
+    params = gpu.ParamsKZG.setup(6, 0x5EC2E7)
+    syn = circuits.StandardPlonk(None).synthesize()
+    copies = [(lc, lr, rc, rr) for (lc, lr), (rc, rr) in syn.copies]
+
+    def code(cs, fixed=syn.fixed, cp=copies):
+        try:
+            engine.Keys(cs, params, fixed, cp).release()
+            return 0
+        except gpu.H2miError as e:
+            return e.code
+
+    good = keygen.constraint_system(circuits.StandardPlonk, 6)
+    assert code(good) == 0
+    for field, value in (("degree", 4), ("n_advice", 2), ("n_lookups", 1), ("gates", 9), ("n_instance", 1)):
+        cs = keygen.constraint_system(circuits.StandardPlonk, 6)
+        setattr(cs, field, value)
+        assert code(cs) == -1, field
+    cs = keygen.constraint_system(circuits.StandardPlonk, 6)
+    cs.k = 2  # fewer rows than blinding factors
+    assert code(cs) == -6
+    cs = keygen.constraint_system(circuits.StandardPlonk, 7)  # the SRS has 2^6 points
+    assert code(cs) == -6
+    assert code(good, cp=[(3, 0, 0, 0)]) == -1   # a copy constraint on a column outside the permutation
+    assert code(good, cp=[(0, 64, 0, 0)]) == -6  # ... beyond the last row
+    assert code(good, fixed=[{64: 1}, {}, {}, {}, {}]) == -6
+    r = gpu.field.FR_MODULUS
+    assert code(good, fixed=[{0: r}, {}, {}, {}, {}]) == -1  # not reduced
+    # the halo2-lib shapes: a lookup selector that is not a fixed column, too many commitments for one phase
+    fcs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(fcs, 1234, 4)
+    a = fcs.abi(6)
+    a.lookups[0].selector_fixed = 9
+    with pytest.raises(gpu.H2miError):
+        engine.Keys(a, params, [{} for _ in range(4)], [])
+    a = flex.FlexGateCS(lookup=False).abi(6)
+    a.n_perm = 8
+    for j in range(8):
+        a.perm_columns[j] = engine.Column(engine.ADVICE, 0)
+    with pytest.raises(gpu.H2miError):
+        engine.Keys(a, params, [{}, {}], [])  # eight permutation sets + the random polynomial: nine commitments in one phase
+    del asg
+    params.release()
+
+
+def test_lookup_failure_code_and_identity_point(gpu):
+    """H2MI_EUNSAT when a looked-up cell is not a table value (the crate: ConstraintSystemFailure); an identity commitment
+    would come back as (0, 0), which the caller's transcript refuses as the crate's does."""
+    from halo2_scaffold_amd import engine, flex, transcript
+
+    lib = gpu.lib
+    params = gpu.ParamsKZG.setup(7, 0x5EC2E7)
+    cs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(cs, 1234567, 4)
+    keys = flex.FlexKeys(params, cs, asg)
+    ws = flex.FlexWorkspace(params, keys)
+    asg.advice[0][sorted(asg.fixed[cs.col_qlookup])[2]] = 16
+    cells, keep = engine.pack_cells(asg.advice)
+    inst = np.stack([gpu.field.fr_to_mont_limbs(v) for v in asg.instance])
+    pts = np.zeros((8, 8), dtype=np.uint64)
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    assert lib.h2mi_prover_advice(ws.prover.handle, cells, inst.ctypes.data, len(inst), 5, pts.ctypes.data) == 0
+    assert lib.h2mi_prover_lookups(ws.prover.handle, one.ctypes.data, pts.ctypes.data) == -7
+    assert b"not satisfied" in lib.h2mi_strerror(-7)
+    # the same failure through the host layer: the crate's error, no proof
+    with pytest.raises(ValueError, match="not in the table"):
+        flex.create_proof(params, keys, asg, 5, ws=ws)
+    # (0, 0) — how a phase reports an identity commitment — is refused by the caller's transcript, as by the crate's
+    t = transcript.Blake2bWrite.init()
+    with pytest.raises(ValueError, match="infinity"):
+        t.write_point(np.zeros(8, dtype=np.uint64))
+    ws.release()
+    keys.release()
+    params.release()

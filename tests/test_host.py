@@ -16,9 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol(h2):
-    hdr = open(os.path.join(ROOT, "include", "h2mi.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "h2mi.h")).read() + open(os.path.join(ROOT, "include", "h2mi_prover.h")).read()  # every C header
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prose in comments names callbacks and macros, not exports
     declared = set(re.findall(r"\b(h2mi_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 25
+    assert len(declared) >= 25 and "h2mi_prover_quotient" in declared
     for name in sorted(declared):
         assert hasattr(h2.lib, name), f"libh2mi.so does not export {name}"
     assert set(h2.lib._h2mi_symbols) == declared  # the ctypes binding covers the whole header
