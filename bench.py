@@ -374,11 +374,19 @@ def main(argv=None):
                 out["halo2_lib_create_proof"] = time_halo2_lib_examples(h2, R)
             except Exception as e:  # never lose the headline line to an auxiliary measurement
                 out["halo2_lib_create_proof"] = {"error": repr(e)}
+    parity_ok = True
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, args, n)
+        par = out["cpu_baseline"].pop("parity")
+        out["parity_in_run"] = bool(par["msm_commitment_equal"] and par["ntt_limbs_equal"])
+        out["parity_in_run_detail"] = par
+        parity_ok = out["parity_in_run"]
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if not parity_ok:  # a fast kernel whose results differ from the oracle's is not a measurement
+        sys.stderr.write("bench.py: parity_in_run is FALSE — the GPU's results differ from the CPU restatement's on the same vectors\n")
+        sys.exit(3)
 
 
 def time_msm_only(h2, R, args, dist, coll_dev, n_devices, torch, sync_all):
@@ -759,7 +767,7 @@ def cpu_baseline(R, args, n):
     bases = R.params.get_g_lagrange()[:ns].copy()
     cref.msm(scal[:1024], bases[:1024], threads)  # warm the thread pool / page in
     t0 = time.perf_counter()
-    cref.msm(scal, bases, threads)
+    cpu_point = cref.msm(scal, bases, threads)
     t_msm = time.perf_counter() - t0
     # G1 additions of the reference algorithm on this sample (per thread chunk: window c = ceil(ln chunk))
     chunk = max(ns // threads, 1) if ns > threads else ns
@@ -775,6 +783,26 @@ def cpu_baseline(R, args, n):
     t0 = time.perf_counter()
     cref.ntt(a, w, ls, threads)
     t_ntt = time.perf_counter() - t0
+    # parity in the run (the reference's only check is in-run too: verify_proof after create_proof, src/scaffold.rs:354-361): the
+    # GPU's commitment and transform of the SAME vectors the CPU restatement just processed must be the same group element / the
+    # same limbs.  The oracle is the checker here, never the thing measured.
+    import ctypes as C
+
+    from halo2_scaffold_amd.device import DevBuf
+
+    import _load_pkg
+
+    h2 = _load_pkg.load()
+    d_out = DevBuf(96)
+    h2._lib.check(h2.lib.h2mi_msm_bn254_g1_dev(R.params.g_lagrange_handle, R.cols[0].ptr, ns, d_out.ptr, None), "parity msm")
+    gpu_point = d_out.to_numpy(shape=(12,))
+    d_out.free()
+    msm_equal = bool(np.array_equal(cref.normalize(gpu_point), cref.normalize(cpu_point)))
+    g = scal.copy()
+    h2.best_fft(g, w, ls)
+    ntt_equal = bool(np.array_equal(g, a))
+    parity = {"msm_commitment_equal": msm_equal, "ntt_limbs_equal": ntt_equal,
+              "what": f"GPU MSM(2^{ls}) and NTT(2^{ls}) of the vectors the CPU baseline just processed, against oracle/h2ref.c's results"}
     with open("/proc/cpuinfo") as f:
         model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
     return {
@@ -791,6 +819,7 @@ def cpu_baseline(R, args, n):
         "projected_step_seconds": round(R.shape.msm_per_proof * t_msm * (n / ns)
                                         + (R.shape.ntt_per_proof["intt_n"] + (R.domain.extended_len() // n) * (R.shape.ntt_per_proof["coset_ntt_ext"] + 1)) * t_ntt * (n / ns), 3),
         "label": "restated CPU baseline (C), not the Rust binary",
+        "parity": parity,
     }
 
 

@@ -14,8 +14,10 @@
  *               the slice is split into one contiguous chunk per thread and the partial points are
  *               folded by addition.
  *   h2ref_ntt   halo2_proofs::arithmetic::best_fft: bit-reversal permutation, n/2 twiddles by
- *               repeated multiplication, log n rounds of radix-2 butterflies (each round split across
- *               threads).
+ *               repeated multiplication, log n rounds of radix-2 butterflies; threads as the crate's
+ *               recursive_butterfly_arithmetic uses them: independent sub-transforms in parallel, the
+ *               rounds that combine them serial per block (round 5; rounds 1-4 split every round across
+ *               all threads, which lost to one thread at 2^16).
  *   field       halo2curves::bn256::{Fq, Fr}: 4 x 64-bit limbs, Montgomery form R = 2^256, CIOS
  *               multiplication, results always fully reduced.
  *   curve       halo2curves::bn256::{G1Affine, G1}: y^2 = x^3 + 3, Jacobian coordinates,
@@ -376,18 +378,13 @@ static void* fft_round_worker(void* arg) {
   }
   return NULL;
 }
-typedef struct { fe* a; const fe* tw; size_t half, twiddle_chunk, lo, hi; } fft_job2;
-static void* fft_round_worker_wide(void* arg) { /* few big blocks: split the butterflies of each block */
-  fft_job2* J = (fft_job2*)arg;
-  for (size_t i = J->lo; i < J->hi; i++) {
-    fe* left = J->a;
-    fe* right = J->a + J->half;
-    fe t;
-    if (i == 0) t = right[0];
-    else fe_mul(&t, &right[i], &J->tw[i * J->twiddle_chunk], &FR);
-    fe u = left[i];
-    fe_add(&left[i], &u, &t, &FR);
-    fe_sub(&right[i], &u, &t, &FR);
+/* one thread's sub-transform: every round whose blocks fit inside region [region * sub, (region + 1) * sub) */
+typedef struct { fe* a; const fe* tw; size_t n, sub, region; } fft_sub_job;
+static void* fft_sub_worker(void* arg) {
+  fft_sub_job* S = (fft_sub_job*)arg;
+  for (size_t chunk = 2; chunk <= S->sub; chunk *= 2) {
+    fft_job J = {S->a, S->tw, S->n, chunk, S->n / chunk, S->region * S->sub / chunk, (S->region + 1) * S->sub / chunk};
+    fft_round_worker(&J);
   }
   return NULL;
 }
@@ -411,37 +408,41 @@ void h2ref_ntt(uint64_t* data, const uint64_t omega[4], uint32_t log_n, int thre
   fe w = FR.one, om;
   memcpy(om.l, omega, 32);
   for (size_t i = 0; i < n / 2; i++) { tw[i] = w; fe_mul(&w, &w, &om, &FR); }
-  size_t chunk = 2, twiddle_chunk = n / 2;
-  pthread_t* th = (pthread_t*)malloc((size_t)threads * sizeof(pthread_t));
-  for (uint32_t r = 0; r < log_n; r++) {
-    size_t nblocks = n / chunk;
-    if (threads == 1 || n < 1024) {
-      fft_job J = {a, tw, n, chunk, twiddle_chunk, 0, nblocks};
-      fft_round_worker(&J);
-    } else if (nblocks >= (size_t)threads) {
-      fft_job* jobs = (fft_job*)malloc((size_t)threads * sizeof(fft_job));
-      for (int t = 0; t < threads; t++) {
-        fft_job J = {a, tw, n, chunk, twiddle_chunk, nblocks * (size_t)t / (size_t)threads, nblocks * (size_t)(t + 1) / (size_t)threads};
-        jobs[t] = J;
-        pthread_create(&th[t], NULL, fft_round_worker, &jobs[t]);
-      }
-      for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-      free(jobs);
-    } else {
-      size_t half = chunk / 2;
-      fft_job2* jobs = (fft_job2*)malloc((size_t)threads * sizeof(fft_job2));
-      for (size_t blk = 0; blk < nblocks; blk++) {
-        for (int t = 0; t < threads; t++) {
-          fft_job2 J = {a + blk * chunk, tw, half, twiddle_chunk, half * (size_t)t / (size_t)threads, half * (size_t)(t + 1) / (size_t)threads};
-          jobs[t] = J;
-          pthread_create(&th[t], NULL, fft_round_worker_wide, &jobs[t]);
-        }
-        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-      }
-      free(jobs);
+  /* The crate's split (best_fft with log_n > log_threads: recursive_butterfly_arithmetic under rayon::join): the two halves of a
+   * block are independent sub-transforms run in parallel, the butterflies that combine them are ONE serial loop.  With
+   * 2^d <= threads workers that is 2^d independent sub-transforms of n / 2^d points, one per thread, then d top rounds in which
+   * round j has 2^(d-j) blocks, each combined serially by its own thread (the last round: one thread, n / 2 butterflies). */
+  uint32_t d = 0;
+  while (((size_t)2 << d) <= (size_t)threads) d++;
+  if (log_n <= d) d = 0; /* "log_n <= log_threads": the serial iterative loop */
+  /* rayon hands a sub-transform to a pooled worker for nothing; a pthread costs tens of microseconds: keep 2^12 points per thread */
+  while (d > 0 && log_n < d + 12) d--;
+  size_t sub = n >> d, regions = (size_t)1 << d;
+  pthread_t* th = (pthread_t*)malloc(regions * sizeof(pthread_t));
+  if (d == 0) {
+    fft_sub_job S = {a, tw, n, n, 0};
+    fft_sub_worker(&S);
+  } else {
+    fft_sub_job* subs = (fft_sub_job*)malloc(regions * sizeof(fft_sub_job));
+    for (size_t g = 0; g < regions; g++) {
+      fft_sub_job S = {a, tw, n, sub, g};
+      subs[g] = S;
+      pthread_create(&th[g], NULL, fft_sub_worker, &subs[g]);
     }
-    chunk *= 2;
-    twiddle_chunk /= 2;
+    for (size_t g = 0; g < regions; g++) pthread_join(th[g], NULL);
+    free(subs);
+    fft_job* jobs = (fft_job*)malloc(regions * sizeof(fft_job));
+    for (size_t chunk = 2 * sub; chunk <= n; chunk *= 2) {
+      size_t nblocks = n / chunk;
+      for (size_t b = 0; b < nblocks; b++) {
+        fft_job J = {a, tw, n, chunk, n / chunk, b, b + 1};
+        jobs[b] = J;
+        if (nblocks > 1) pthread_create(&th[b], NULL, fft_round_worker, &jobs[b]);
+      }
+      if (nblocks > 1) for (size_t b = 0; b < nblocks; b++) pthread_join(th[b], NULL);
+      else fft_round_worker(&jobs[0]);
+    }
+    free(jobs);
   }
   free(th);
   free(tw);

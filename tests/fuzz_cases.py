@@ -1,0 +1,226 @@
+"""Randomised parity cases against the C oracle (oracle/h2ref.c through oracle/cref.py) and the oracle verifiers: the generator
+behind tests/test_gpu_fuzz.py (a bounded, seeded run under the driver's `pytest -m gpu`) and tools/fuzz_parity.py (the long sweep).
+Every case is derived from one printed seed; a failure names it.
+  MSM   registered base sets of random size around the path thresholds (1 .. 2^15, and 2^17 from a cached base set), scalar vectors of
+        every distribution a prover produces (uniform, sparse, one value repeated, 0 / 1 columns, small integers, r - 1, zeros),
+        prefixes m <= n, through the small path and (test hook) the general pipeline; device-resident batches before one join; the
+        phase entry under every flag combination
+  NTT   log_n 1 .. 19: forward, inverse with n^-1 fused, coset pre-scale, zero-extended out-of-place
+  PROOF StandardPlonk at 2^5 .. 2^14 through the prover ABI (the oracle verifier against the closed-form verifying key), range through
+        the single- and multi-column configurations (oracle/flex.py verifier)"""
+import ctypes as C
+import random
+import time
+
+import numpy as np
+
+from oracle import bn254 as o, cref
+from oracle import flex as FX
+from oracle import prover as OP
+
+S = 0x5EC2E7 + 0x48324D49
+KINDS = ["uniform", "sparse", "constant", "grand", "bits", "small", "minus_one", "zeros"]
+
+
+def scalars(n, kind, seed):
+    r = o.random_field_limbs(n, seed)
+    if kind == "uniform":
+        return r
+    if kind == "sparse":
+        z = np.zeros((n, 4), dtype=np.uint64)
+        idx = np.random.default_rng(seed).choice(n, size=max(1, n // 50), replace=False)
+        z[idx] = r[idx]
+        return z
+    if kind == "constant":
+        return np.tile(r[0], (n, 1))
+    if kind == "grand":  # a constant with a few exceptions, like a permutation product
+        c = np.tile(r[0], (n, 1))
+        c[: min(3, n)] = r[: min(3, n)]
+        return c
+    if kind == "bits":
+        return o.witness_like_limbs(n, seed & 0xFFFF)
+    if kind == "small":
+        return o.pack([(seed * (i + 1)) % 1000 for i in range(n)], o.R)
+    if kind == "minus_one":
+        return np.tile(o.pack([o.R - 1], o.R)[0], (n, 1))
+    return np.zeros((n, 4), dtype=np.uint64)
+
+
+
+class Fuzzer:
+    def __init__(self, h2, seed: int):
+        """h2: the loaded product package (initialised on a GPU)"""
+        self.h2, self.seed0 = h2, seed
+        self.rng = random.Random(seed)
+        self.counts = {"msm": 0, "msm_batches": 0, "msm_phase_batches": 0, "ntt": 0, "proof": 0, "flex": 0}
+        self._big_bases = {}
+
+    def run(self, budget_s: float, progress=None) -> dict:
+        t0 = last = time.time()
+        while time.time() - t0 < budget_s:
+            which = self.rng.random()
+            (self.fuzz_msm if which < 0.45 else self.fuzz_ntt if which < 0.75 else self.fuzz_proof if which < 0.9 else self.fuzz_flex)()
+            if progress is not None and time.time() - last > 45:
+                last = time.time()
+                progress(last - t0, self.counts)
+        return self.counts
+
+    def fuzz_msm(self):
+        h2, rng, counts, seed0 = self.h2, self.rng, self.counts, self.seed0
+        lib = h2.lib
+        from halo2_scaffold_amd.device import DevBuf
+
+        lg = rng.choice([0, 1, 3, 5, 8, 10, 12, 12, 13, 14, 14, 15, 17])
+        n = max(1, min((1 << lg) + rng.randint(-3, 3), 1 << 17))
+        seed = rng.randrange(1 << 30)
+        if lg >= 15:  # a big base set costs seconds of CPU scalar multiplications: one per size, cut to n
+            if lg not in self._big_bases:
+                self._big_bases[lg] = cref.g1_mul_gen(o.random_field_limbs((1 << lg) + 3, seed), 16)
+            bases = np.ascontiguousarray(self._big_bases[lg][:n]).copy()
+        else:
+            bases = cref.g1_mul_gen(o.random_field_limbs(n, seed), 8)
+        if n > 4 and rng.random() < 0.3:
+            bases[rng.randrange(n)] = 0  # an identity base
+            j = rng.randrange(n - 1)
+            bases[j + 1] = bases[j]  # a duplicated base
+        h = C.c_uint64()
+        assert lib.h2mi_bases_register(bases.ctypes.data, n, C.byref(h)) == 0
+        out = np.zeros(12, dtype=np.uint64)
+        for kind in rng.sample(KINDS, 4):
+            m = n if rng.random() < 0.6 else rng.randint(1, n)
+            sc = np.ascontiguousarray(scalars(n, kind, seed + len(kind))[:m])
+            want = cref.normalize(cref.msm(sc, bases[:m], 8))
+            for small in (1, 0):
+                lib.h2mi_dbg_msm_small_path(small)
+                assert lib.h2mi_msm_bn254_g1(h.value, None, sc.ctypes.data, m, out.ctypes.data) == 0
+                assert np.array_equal(cref.normalize(out), want), ("msm", seed0, n, m, kind, small, seed)
+                counts["msm"] += 1
+            lib.h2mi_dbg_msm_small_path(1)
+        # a batch queued on the library stream before one join
+        q = rng.randint(2, 9)
+        vecs = [np.ascontiguousarray(scalars(n, rng.choice(KINDS), seed + 100 + i)) for i in range(q)]
+        dv = [DevBuf.from_numpy(v) for v in vecs]
+        dout = DevBuf(96 * q)
+        for i, d in enumerate(dv):
+            assert lib.h2mi_msm_bn254_g1_dev(h.value, d.ptr, n, dout.ptr + 96 * i, None) == 0
+        got = dout.to_numpy(shape=(q, 12))
+        for i, v in enumerate(vecs):
+            assert np.array_equal(cref.normalize(got[i]), cref.normalize(cref.msm(v, bases, 8))), ("batch", seed0, n, i, seed)
+        counts["msm_batches"] += 1
+        # the same vectors through the phase-level entries (round 4): batched launches, the sparse promise, mixed with single calls
+        dout2 = DevBuf(96 * q)
+        cut = rng.randint(1, q - 1)
+        ptr_a = (C.c_void_p * cut)(*[d.ptr for d in dv[:cut]])
+        ptr_b = (C.c_void_p * (q - cut))(*[d.ptr for d in dv[cut:]])
+        lib.h2mi_dbg_msm_small_path(rng.choice((0, 1)))
+        fa, fb = rng.choice((0, 1, 2, 3)), rng.choice((0, 1, 2, 3))  # H2MI_MSM_SPARSE | H2MI_MSM_INORDER
+        assert lib.h2mi_msm_bn254_g1_phase_dev(h.value, ptr_a, cut, n, dout2.ptr, fa, None) == 0
+        assert lib.h2mi_msm_bn254_g1_phase_dev(h.value, ptr_b, q - cut, n, dout2.ptr + 96 * cut, fb, None) == 0
+        got2 = dout2.to_numpy(shape=(q, 12))
+        lib.h2mi_dbg_msm_small_path(1)
+        for i in range(q):
+            assert np.array_equal(cref.normalize(got2[i]), cref.normalize(got[i])), ("phase batch", seed0, n, i, cut, fa, fb, seed)
+        counts["msm_phase_batches"] += 1
+        dout2.free()
+        for d in dv:
+            d.free()
+        dout.free()
+        assert lib.h2mi_bases_release(h.value) == 0
+
+
+    def fuzz_ntt(self):
+        h2, rng, counts, seed0 = self.h2, self.rng, self.counts, self.seed0
+        lib = h2.lib
+        from halo2_scaffold_amd import field as F
+
+        lg = rng.randint(1, 19)
+        n = 1 << lg
+        seed = rng.randrange(1 << 30)
+        a = o.random_field_limbs(n, seed)
+        w = F.omega_for(lg)
+        wl, wil = F.fr_to_mont_limbs(w), F.fr_to_mont_limbs(F.fr_inv(w))
+        ref = a.copy()
+        cref.ntt(ref, wl, lg, 8)
+        x = a.copy()
+        h2.best_fft(x, wl, lg)
+        assert np.array_equal(x, ref), ("ntt", seed0, lg, seed)
+        # inverse with the fused n^-1 returns the input
+        ninv = F.fr_to_mont_limbs(F.fr_inv(n))
+        assert lib.h2mi_ntt_ext_bn254_fr(x.ctypes.data, lg, wil.ctypes.data, None, ninv.ctypes.data) == 0
+        assert np.array_equal(x, a), ("intt", seed0, lg, seed)
+        # coset pre-scale == scaling by zeta^i on the host side of the C oracle, then the plain transform
+        zeta = F.fr_to_mont_limbs(F.FR_ZETA)
+        y = a.copy()
+        assert lib.h2mi_ntt_ext_bn254_fr(y.ctypes.data, lg, wl.ctypes.data, zeta.ctypes.data, None) == 0
+        pw = o.unpack(a, o.R)
+        zp, cur = [], 1
+        for v in pw[: min(n, 64)]:
+            zp.append(v * cur % o.R)
+            cur = cur * F.FR_ZETA % o.R
+        if n <= 64:
+            sc = o.pack(zp, o.R)
+            cref.ntt(sc, wl, lg, 8)
+            assert np.array_equal(y, sc), ("coset", seed0, lg, seed)
+        # zero-extended out of place (coeff_to_extended): a transform of size 4n of n coefficients
+        if lg <= 17:
+            dom = h2.EvaluationDomain(5, lg)
+            ext = dom.coeff_to_extended(a)
+            pad = np.zeros((dom.extended_len(), 4), dtype=np.uint64)  # the same transform in place on an explicitly padded vector
+            pad[:n] = a
+            assert lib.h2mi_ntt_ext_bn254_fr(pad.ctypes.data, dom.extended_k, F.fr_to_mont_limbs(dom.extended_omega).ctypes.data, zeta.ctypes.data, None) == 0
+            assert np.array_equal(ext, pad), ("extended", seed0, lg, seed)
+        counts["ntt"] += 1
+
+
+    def fuzz_proof(self):
+        h2, rng, counts, seed0 = self.h2, self.rng, self.counts, self.seed0
+        from halo2_scaffold_amd import circuits, keygen, prover
+
+        k = rng.randint(5, 14)
+        x, seed = rng.randrange(1 << 60), rng.randrange(1 << 30)
+        params = h2.ParamsKZG.setup(k, S)
+        c = circuits.StandardPlonk(None)
+        pk = keygen.keygen_pk(params, keygen.keygen_vk(params, c), c)
+        proof = prover.create_proof(params, pk, circuits.StandardPlonk(x), seed)
+        assert OP.verify_proof(OP.VerifierKey.closed_form(k, S), proof), ("proof", seed0, k, x, seed)
+        bad = bytearray(proof)
+        bad[rng.randrange(len(bad))] ^= 1
+        assert not OP.verify_proof(OP.VerifierKey.closed_form(k, S), bytes(bad)), ("tampered proof accepted", seed0, k)
+        pk.release()
+        params.release()
+        counts["proof"] += 1
+
+
+    def fuzz_flex(self):
+        h2, rng, counts, seed0 = self.h2, self.rng, self.counts, self.seed0
+        from halo2_scaffold_amd import flex
+
+        bits = rng.choice([3, 4, 5, 6, 7])
+        k = rng.choice([5, 6, 7, 8])
+        if (1 << bits) >= (1 << k) - 7:
+            return
+        x = rng.randrange(1 << 64)
+        closure = lambda cs: flex.range_closure(cs, x, bits)
+        try:
+            cs = flex.configure(True, k, closure)
+            asg = closure(cs)
+        except (ValueError, AssertionError) as e:  # more columns than the crate's formula takes, or than the device kernel supports: as in halo2-base
+            if "NOT ENOUGH" in str(e) or "device quotient kernel" in str(e):
+                return
+            raise
+        flex.mock(asg)
+        params = h2.ParamsKZG.setup(k, S)
+        keys = flex.FlexKeys(params, cs, asg)
+        proof = flex.create_proof(params, keys, asg, rng.randrange(1 << 30))
+        if cs.num_advice > 1:
+            ocs = FX.flex_multi_cs(True, cs.num_advice, cs.num_lookup_advice)
+            oasg = FX.range_assignment_multi(ocs, x, bits, k)
+        else:
+            ocs = FX.flex_gate_cs(True)
+            oasg = FX.range_assignment(ocs, x, bits, 1 << k)
+        vk = FX.VerifierKeys(ocs, k, S, oasg.fixed, oasg.copies)
+        assert FX.verify(vk, proof, [asg.instance]), ("flex", seed0, k, bits, x, cs.num_advice)
+        keys.release()
+        params.release()
+        counts["flex"] += 1
+
