@@ -53,15 +53,10 @@ def _load():
         "h2mi_bases_info": ([C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p], C.c_int),
         "h2mi_msm_bn254_g1": ([C.c_uint64, vp, vp, sz, vp], C.c_int),
         "h2mi_msm_bn254_g1_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
-        "h2mi_msm_bn254_g1_inorder_dev": ([C.c_uint64, vp, sz, vp, vp], C.c_int),
-        "h2mi_msm_bn254_g1_batch_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
-        "h2mi_msm_bn254_g1_batch_sparse_dev": ([C.c_uint64, vp, sz, sz, vp, vp], C.c_int),
         "h2mi_msm_bn254_g1_phase_dev": ([C.c_uint64, vp, sz, sz, vp, C.c_uint, vp], C.c_int),
-        "h2mi_dbg_msm_batch": ([C.c_int], C.c_int),
         "h2mi_msm_adhoc_builds": ([u64p], C.c_int),
         "h2mi_msm_last_stats": ([C.c_uint64, u64p, u64p], C.c_int),
         "h2mi_msm_set_canonical": ([C.c_int], C.c_int),
-        "h2mi_dbg_msm_small_path": ([C.c_int], C.c_int),
         "h2mi_fe_to_repr_dev": ([C.c_int, vp, sz, vp, vp], C.c_int),
         "h2mi_fe_from_repr_dev": ([C.c_int, vp, sz, vp, u64p], C.c_int),
         "h2mi_g1_compress_dev": ([vp, sz, vp, vp], C.c_int),
@@ -128,9 +123,6 @@ def _load():
         "h2mi_prover_shplonk_open": ([vp, vp, vp], C.c_int),
         "h2mi_prover_buffer": ([vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(sz)], C.c_int),
         "h2mi_prover_pk_buffer": ([vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(sz)], C.c_int),
-        "h2mi_dbg_field_op": ([C.c_int, C.c_int, vp, vp, vp, sz], C.c_int),
-        "h2mi_dbg_g1_op": ([C.c_int, vp, vp, vp, sz], C.c_int),
-        "h2mi_dbg_g1_quad_op": ([C.c_int, vp, vp, vp, sz], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)  # AttributeError here = a symbol the header declares is missing

@@ -1,4 +1,4 @@
-// libh2mi.so — lifecycle, device memory, profiling, elementwise test hooks and the small G1 helpers.
+// libh2mi.so — lifecycle, device memory, profiling and the small G1 helpers.
 #include <algorithm>
 
 #include "g1.cuh"
@@ -59,55 +59,6 @@ void prof_begin(const char* name, hipStream_t s) {
   ctx().prof.push_back(r);
 }
 void prof_end(hipStream_t s) { H2_IGNORE(hipEventRecord(ctx().prof.back().b, s)); }
-
-// ---- elementwise field kernels (test hooks) -------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(256) k_dbg_field(int op, const fe* a, const fe* b, fe* out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fe x = fe_load(&a[i]);
-  fe y = b ? fe_load(&b[i]) : fe_zero();
-  fe r;
-  switch (op) {
-    case 0: r = fe_mul<F>(x, y); break;
-    case 1: r = fe_add<F>(x, y); break;
-    case 2: r = fe_sub<F>(x, y); break;
-    case 3: r = fe_sqr<F>(x); break;
-    case 4: r = fe_inv<F>(x); break;
-    case 5: r = fe_from_mont<F>(x); break;
-    case 6: r = fe_to_mont<F>(x); break;
-    case 7: r = fe_neg<F>(x); break;
-    case 9: r = fe_inv_ds<F>(x); break;
-    case 10: r = fe_inv_gcd<F>(x); break;
-    default: r = fe_dbl<F>(x); break;
-  }
-  fe_store(&out[i], r);
-}
-
-__global__ void __launch_bounds__(256) k_dbg_g1(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  affine P = affine_load(p + i * 64);
-  xyzz acc;
-  if (op == 0) {
-    affine Q = affine_load(q + i * 64);
-    acc = xyzz_from_affine(P);
-    xyzz_madd(acc, Q);
-  } else if (op == 1) {
-    acc = xyzz_from_affine(P);
-    acc = xyzz_dbl(acc);
-  } else {
-    affine Q = affine_load(q + i * 64);
-    acc = xyzz_from_affine(P);
-    // make the second operand a non-trivial XYZZ representative: (2Q) - Q computed as 2Q + (-Q)
-    xyzz b = xyzz_dbl(xyzz_from_affine(Q));
-    affine nq = Q;
-    nq.y = fe_neg<Fq>(Q.y);
-    xyzz_madd(b, nq);
-    xyzz_add(acc, b);
-  }
-  jac_store(out + i * 96, xyzz_to_jac(acc));
-}
 
 // sum of k Jacobian points by one thread (k is tiny: the number of GPUs)
 __global__ void k_g1_sum_jac(const uint8_t* pts, size_t k, uint8_t* out) {
@@ -490,51 +441,6 @@ int h2mi_profile_dump(char* buf, size_t cap, size_t* needed_out) {
   }
   return H2MI_OK;
 }
-
-int h2mi_dbg_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  H2_REQUIRE_INIT();
-  if (!a || !out || n == 0) return H2MI_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  hipStream_t s = ctx().stream;
-  DevMem da, db, dout;
-  H2_HIP(da.alloc(n * 32));
-  H2_HIP(dout.alloc(n * 32));
-  H2_HIP(hipMemcpyAsync(da.p, a, n * 32, hipMemcpyHostToDevice, s));
-  if (b) {
-    H2_HIP(db.alloc(n * 32));
-    H2_HIP(hipMemcpyAsync(db.p, b, n * 32, hipMemcpyHostToDevice, s));
-  }
-  uint32_t grid = ceil_div_u32(n, 256);
-  if (field == 0) {
-    H2_LAUNCH("k_dbg_field_fq", k_dbg_field<FqP>, grid, 256, 0, s, op, da.as<fe>(), db.as<fe>(), dout.as<fe>(), n);
-  } else {
-    H2_LAUNCH("k_dbg_field_fr", k_dbg_field<FrP>, grid, 256, 0, s, op, da.as<fe>(), db.as<fe>(), dout.as<fe>(), n);
-  }
-  H2_HIP(hipMemcpyAsync(out, dout.p, n * 32, hipMemcpyDeviceToHost, s));
-  H2_HIP(hipStreamSynchronize(s));
-  return H2MI_OK;
-}
-
-
-int h2mi_dbg_g1_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {
-  H2_REQUIRE_INIT();
-  if (!p || !out_jac || n == 0 || (op != 1 && !q)) return H2MI_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  hipStream_t s = ctx().stream;
-  DevMem dp, dq, dout;
-  H2_HIP(dp.alloc(n * 64));
-  H2_HIP(dout.alloc(n * 96));
-  H2_HIP(hipMemcpyAsync(dp.p, p, n * 64, hipMemcpyHostToDevice, s));
-  if (q) {
-    H2_HIP(dq.alloc(n * 64));
-    H2_HIP(hipMemcpyAsync(dq.p, q, n * 64, hipMemcpyHostToDevice, s));
-  }
-  H2_LAUNCH("k_dbg_g1", k_dbg_g1, ceil_div_u32(n, 256), 256, 0, s, op, dp.as<uint8_t>(), dq.as<uint8_t>(), dout.as<uint8_t>(), n);
-  H2_HIP(hipMemcpyAsync(out_jac, dout.p, n * 96, hipMemcpyDeviceToHost, s));
-  H2_HIP(hipStreamSynchronize(s));
-  return H2MI_OK;
-}
-
 
 int h2mi_g1_sum_jacobian(const uint64_t* points, size_t k, uint64_t out_jacobian[12]) {
   H2_REQUIRE_INIT();

@@ -129,6 +129,8 @@ struct Bases {
   bool small = false;
   uint32_t sc = 0, sW = 0, slanes = 0, sr = 0, sG = 0;  // window bits, windows, gathering lanes, cells per lane, workgroups (= partial sums)
   uint8_t* stable = nullptr;    // [2^(sc-1)][sW][n] affine: j 2^(sc w) P_i
+  uint32_t since_join = 0;      // MSMs issued on this handle since the last join (msm_join_all): how deep the caller's queue is
+  bool last_small = false;      // the path the last MSM took (h2mi_msm_last_stats)
 };
 
 static std::map<uint64_t, Bases*> g_bases;
@@ -143,7 +145,15 @@ static std::vector<AdHoc> g_adhoc;
 static uint64_t g_adhoc_clock = 0, g_adhoc_builds = 0;
 constexpr size_t ADHOC_MAX = 4;  // g, g_lagrange and a couple of slices
 static bool g_canonical = false;
-static bool g_small_path = true;  // h2mi_dbg_msm_small_path(0): small base sets take the general pipeline (parity tests, A/B)
+// Which pipeline a base set with a digit-multiples table takes, per MSM (round 5; rounds 3-4 chose by size alone).  The latency
+// path wins a LONE commitment and a prover phase of up to four at every size it is built for, but from 2^13 points its 2.5x more mixed
+// additions lose to the general pipeline once MSMs stream back to back (2^14: 116.7 vs 96.0 us per MSM, profiles/r04_msm_sweep.txt) —
+// the workload of an 8-GPU rank's 2^13 .. 2^14-point slices of a 2^16 / 2^17-row proof.  So: the caller can force the general pipeline
+// (H2MI_MSM_GENERAL on the phase entry), and without the flag a base set above SMALL_STREAM_N points switches to it after
+// SMALL_STREAM_AFTER MSMs have been issued without a join — a phase (<= 4 commitments, then the transcript needs them) never gets
+// there, a stream does after its first four.  Results do not depend on the path (tests/test_gpu_parity.py runs both against the oracle).
+constexpr size_t SMALL_STREAM_N = (size_t)1 << 12;
+constexpr uint32_t SMALL_STREAM_AFTER = 4;
 static uint64_t g_next_handle = 1;
 
 // ---- registration: table[w][i] = 2^(c*w) * P_i, stored as canonical Montgomery-2^261 words -------------
@@ -1302,34 +1312,6 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small_accum(const SmallBa
   small_finish(d, tree);
 }
 
-// debug hook for the lane-cooperative point operations (g1_29_quad.cuh): four lanes per element.
-// op 0: (P) + (Q) with both operands brought to non-trivial XYZZ representatives; op 1: 2 (P).
-__global__ void __launch_bounds__(256) k_dbg_quad(int op, const uint8_t* pp, const uint8_t* qq, uint8_t* out, size_t n) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  if (i >= n) return;  // n is padded by the host so that whole quads share the decision
-  auto lift = [](const uint8_t* src) {  // affine Mont256 -> XYZZ with ZZ != 1: (2P) + (-P)
-    affine a = affine_load(src);
-    if (affine_is_identity(a)) return xyzz29_identity();
-    f29 x = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.x.v));
-    f29 y = f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(a.y.v));
-    xyzz29 r = xyzz29_dbl_affine(x, y);
-    xyzz29_madd(r, x, f29_sub(f29_zero(), y, Fq29::K2));
-    return r;
-  };
-  xyzz29 a = lift(pp + i * 64);
-  xyzz29 r = op == 0 ? xyzz29_add_quad(a, lift(qq + i * 64)) : xyzz29_dbl_quad(a);
-  if ((threadIdx.x & 3u) != (uint32_t)(i & 3u)) return;  // one lane of the quad writes (a different one per element)
-  jac j;
-  if (xyzz29_is_identity(r)) {
-    j.x = fe_zero(); j.y = fe_one<Fq>(); j.z = fe_zero();
-  } else {
-    f29_to_mont256<Fq29>(f29_mul<Fq29>(r.x, r.zz), j.x.v);
-    f29_to_mont256<Fq29>(f29_mul<Fq29>(r.y, r.zzz), j.y.v);
-    f29_to_mont256<Fq29>(r.zz, j.z.v);
-  }
-  jac_store(out + i * 96, j);
-}
-
 // ---- host -----------------------------------------------------------------------------------------
 static uint32_t pick_window(size_t n) {
   const char* ev = getenv("H2MI_MSM_C");
@@ -1429,7 +1411,7 @@ static void free_bases(Bases* B) {
     }                                                          \
   } while (0)
 
-static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder = false);
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder = false, bool general = false);
 
 static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hipStream_t s, bool allow_small = true) {
   if (n == 0 || n > ((size_t)1 << 26)) return H2MI_ERANGE;
@@ -1514,20 +1496,36 @@ static int register_dev(const void* d_bases, size_t n, uint64_t* handle_out, hip
     B->sG = ceil_div_u32((uint64_t)n * B->sW, (uint64_t)B->slanes * B->sr);
     const uint32_t NBs = 1u << (B->sc - 1);
     const size_t plane = (size_t)B->sW * n;
-    H2_ALLOC(B->stable, (size_t)NBs * plane * 64);
-    for (int si_ = 0; si_ < B->nslot; si_++) {
+    // the latency path is an extra: when its table (up to SMALL_TABLE_BUDGET) or scratch does not fit, the handle keeps the general
+    // pipeline instead of failing the registration (round-4 ADVICE)
+    bool fits = hipMalloc((void**)&B->stable, (size_t)NBs * plane * 64) == hipSuccess;
+    for (int si_ = 0; fits && si_ < B->nslot; si_++) {
       Slot& S = B->slot[si_];
-      H2_ALLOC(S.sdig, plane);
-      H2_ALLOC(S.spart, (size_t)B->sG * PART_BYTES);
-      H2_ALLOC(S.scnt, (size_t)(B->sG + 1) * 4);
-      if (hipMemsetAsync(S.scnt, 0, (size_t)(B->sG + 1) * 4, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }  // [sG] = the arrival counter
+      fits = hipMalloc((void**)&S.sdig, plane) == hipSuccess && hipMalloc((void**)&S.spart, (size_t)B->sG * PART_BYTES) == hipSuccess &&
+             hipMalloc((void**)&S.scnt, (size_t)(B->sG + 1) * 4) == hipSuccess;
+      if (fits && hipMemsetAsync(S.scnt, 0, (size_t)(B->sG + 1) * 4, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }  // [sG] = the arrival counter
     }
+    if (!fits) {
+      (void)hipGetLastError();
+      H2_IGNORE(hipStreamSynchronize(s));
+      for (int si_ = 0; si_ < B->nslot; si_++) {
+        Slot& S = B->slot[si_];
+        if (S.sdig) H2_IGNORE(hipFree(S.sdig));
+        if (S.spart) H2_IGNORE(hipFree(S.spart));
+        if (S.scnt) H2_IGNORE(hipFree(S.scnt));
+        S.sdig = nullptr; S.spart = nullptr; S.scnt = nullptr;
+      }
+      if (B->stable) H2_IGNORE(hipFree(B->stable));
+      B->stable = nullptr;
+    }
+    if (fits) {
     if (hipMemcpyAsync(B->stable, B->table, n * 64, hipMemcpyDeviceToDevice, s) != hipSuccess) { free_bases(B); return H2MI_EHIP; }
     for (uint32_t w = 1; w < B->sW; w++)
       hipLaunchKernelGGL(k_msm_table_next, dim3(ceil_div_u32(n, 64)), dim3(64), 0, s, (const uint8_t*)(B->stable + (size_t)(w - 1) * n * 64),
                          B->stable + (size_t)w * n * 64, n, B->sc);
     hipLaunchKernelGGL(k_msm_small_multiples, dim3(ceil_div_u32(plane, 64)), dim3(64), 0, s, B->stable, plane, NBs);
     B->small = true;
+    }
   }
   // slot n of every window stays the identity until the sum point is known
   for (uint32_t w = 0; w < B->W; w++)
@@ -1607,7 +1605,9 @@ static TailDesc tail_desc(const Bases* B, const Slot& S);
 // (msm_join_all: h2mi_join / h2mi_sync / h2mi_memcpy_d2h), a full batch, or the reuse of the slot.
 // On a caller-provided stream everything runs in order on that stream.
 static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder = false);
-static bool g_head_batch = true;  // h2mi_dbg_msm_batch(0): h2mi_msm_bn254_g1_batch_dev issues its MSMs one by one (parity tests, A/B)
+static bool take_small(const Bases* B, bool general) {
+  return B->small && !general && !(B->n > SMALL_STREAM_N && B->since_join >= SMALL_STREAM_AFTER && !ab_env("H2MI_MSM_NO_AUTO_STREAM"));
+}
 constexpr size_t HEAD_BATCH_MAX_N = (size_t)1 << 17;  // largest base set whose MSMs are partitioned and accumulated as a batch
 
 // `m` <= HEAD_BATCH MSMs of n scalars each over B, results to d_out + 96 j: what m calls of msm_dev would compute, with the partition
@@ -1651,7 +1651,8 @@ static int msm_dev_batch(Bases* B, const void* const* d_scalars, size_t m, size_
   }
   for (size_t j = m; j < HEAD_BATCH; j++) hb.d[j] = hb.d[0];  // never launched (gridDim.y = m)
   const uint32_t ntiles = ceil_div_u32(n_eff, P1_TS), mm = (uint32_t)m;
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {};  // function attributes are per device (every shard of a sharded handle launches these)
+  bool& attr_set = attr_set_dev[ctx().cur & 15];
   if (!attr_set) {
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter_b<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1799,8 +1800,10 @@ static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, siz
 // `inorder`: partition, accumulation and bucket reduction one after the other on `s`, nothing deferred and no stream hops — for a LONE
 // commitment whose point the caller reads next (h2mi_msm_bn254_g1_inorder_dev): the three-stream split buys overlap between consecutive
 // MSMs and costs a lone one ~50 us of event hops (2^20: 1645 -> 1580 us, 2^16: 386 -> 336)
-static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder) {
-  if (B->small && g_small_path) return msm_small(B, d_scalars, n, d_out, s, inorder);
+static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder, bool general) {
+  B->last_small = take_small(B, general);
+  B->since_join++;
+  if (B->last_small) return msm_small(B, d_scalars, n, d_out, s, inorder);
   const uint32_t nb = B->nb, W = B->W;
   // dominant-value shift: only when the MSM covers every registered base (the extra base is their sum)
   const bool shifted = B->has_sum && n == B->n;
@@ -1843,7 +1846,8 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   S.last_stream = s;
   const uint32_t ntiles = ceil_div_u32(n_eff, P1_TS);
   const fe* shift = shifted ? S.shift : nullptr;
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {};  // function attributes are per device (every shard of a sharded handle launches these)
+  bool& attr_set = attr_set_dev[ctx().cur & 15];
   if ((size_t)P1_TS * W * 6 > 150 * 1024) return H2MI_ERANGE;
   if (!attr_set) {  // the scatter kernel stages up to 144 KiB of pairs in LDS (W = 24; 90 KiB at W = 15)
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_bin_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1972,7 +1976,8 @@ static SmallDesc small_desc(const Bases* B, const Slot& S) {
 
 static int launch_small(const SmallBatch& sb, uint32_t count, uint32_t max_parts, hipStream_t t) {
   constexpr size_t LDS = (size_t)SMALL_PARTS_MAX * PART_BYTES;  // 72 KB: above the 64 KB a kernel gets without asking
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {};  // function attributes are per device (every shard of a sharded handle launches these)
+  bool& attr_set = attr_set_dev[ctx().cur & 15];
   if (!attr_set) {
     H2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_small_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr_set = true;
@@ -2327,6 +2332,7 @@ int msm_flush_all() { return flush_tails(); }
 int msm_join_all(hipStream_t s) {
   int rc = flush_tails();
   if (rc) return rc;
+  for (auto& kv : g_bases) kv.second->since_join = 0;  // the caller has caught up with its queue
   for (auto& kv : g_bases)
     for (Slot& S : kv.second->slot)
       if (S.tail_pending) {
@@ -2485,14 +2491,11 @@ static int adhoc_handle(const uint64_t* bases, size_t n, uint64_t* handle_out) {
 // G1::identity() = (0, 1, 0) in Montgomery form: what best_multiexp returns for empty slices
 static const uint64_t G1_IDENTITY[12] = {0, 0, 0, 0, 0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL, 0, 0, 0, 0};
 
-static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder);
+static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder, bool general = false);
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
   return msm_dev_entry(handle, d_scalars, n, d_out_jacobian, stream, false);
 }
-int h2mi_msm_bn254_g1_inorder_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
-  return msm_dev_entry(handle, d_scalars, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_INORDER"));
-}
-static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder) {
+static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool inorder, bool general) {
   H2_REQUIRE_INIT();
   if (!d_out_jacobian || (!d_scalars && n != 0)) return H2MI_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
@@ -2508,26 +2511,19 @@ static int msm_dev_entry(uint64_t handle, const void* d_scalars, size_t n, void*
   auto it = g_bases.find(handle);
   if (it == g_bases.end()) return H2MI_EHANDLE;
   if (n > it->second->n) return H2MI_ERANGE;
-  return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream), inorder);
+  return msm_dev(it->second, d_scalars, n, d_out_jacobian, pick_stream(stream), inorder, general);
 }
 
 static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse,
-                           bool inorder);
-int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream) {
-  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, false, false);
-}
-int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
-                                       h2mi_stream_t stream) {
-  return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"), false);
-}
+                           bool inorder, bool general);
 int h2mi_msm_bn254_g1_phase_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, unsigned flags,
                                 h2mi_stream_t stream) {
-  if (flags & ~(unsigned)(H2MI_MSM_SPARSE | H2MI_MSM_INORDER)) return H2MI_EINVAL;
+  if (flags & ~(unsigned)(H2MI_MSM_SPARSE | H2MI_MSM_INORDER | H2MI_MSM_GENERAL)) return H2MI_EINVAL;
   return msm_batch_entry(handle, d_scalars, count, n, d_out_jacobian, stream, (flags & H2MI_MSM_SPARSE) && !ab_env("H2MI_MSM_IGNORE_SPARSE_HINT"),
-                         (flags & H2MI_MSM_INORDER) && !ab_env("H2MI_MSM_IGNORE_INORDER"));
+                         (flags & H2MI_MSM_INORDER) && !ab_env("H2MI_MSM_IGNORE_INORDER"), (flags & H2MI_MSM_GENERAL) != 0);
 }
 static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream, bool sparse,
-                           bool inorder) {
+                           bool inorder, bool general) {
   H2_REQUIRE_INIT();
   if (!d_out_jacobian || !d_scalars || count == 0) return H2MI_EINVAL;
   for (size_t j = 0; j < count; j++)
@@ -2541,14 +2537,16 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
   // pace and not stage overlap is what the phase waits for; everything else is the loop the caller would have written
   // `sparse` (the caller's promise that the columns are mostly zeros or one repeated value): the kernels of such an MSM are short at
   // EVERY size — a 2^20-row witness column is 25 us of digit counting and a handful of 6-us kernels — so the batch is taken at any size
-  if (count == 1 && inorder) return msm_dev_entry(handle, d_scalars[0], n, d_out_jacobian, stream, true);
-  if (n != 0 && count > 1 && g_head_batch && !ab_env("H2MI_MSM_NO_HEAD_BATCH") && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
+  if (count == 1 && inorder) return msm_dev_entry(handle, d_scalars[0], n, d_out_jacobian, stream, true, general);
+  if (n != 0 && count > 1 && !ab_env("H2MI_MSM_NO_HEAD_BATCH") && pipelined && !eager && it != g_bases.end() && n <= it->second->n &&
       (it->second->n <= (ab_env("H2MI_HEAD_BATCH_MAX_LOG") ? (size_t)1 << atoi(ab_env("H2MI_HEAD_BATCH_MAX_LOG")) : HEAD_BATCH_MAX_N) || sparse)) {
     Bases* B = it->second;
-    const bool small = B->small && g_small_path;
-    if (small || B->seg_log == 0) {
+    if (B->small || B->seg_log == 0) {
       for (size_t j0 = 0; j0 < count;) {
         const size_t m = std::min({count - j0, (size_t)HEAD_BATCH, (size_t)B->nslot});
+        const bool small = take_small(B, general);  // per group of launches: a long group crosses the streaming threshold on its way
+        B->last_small = small;
+        B->since_join += (uint32_t)m;
         int rc = small ? msm_small_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s, inorder)
                        : msm_dev_batch(B, d_scalars + j0, m, n, (char*)d_out_jacobian + 96 * j0, s, inorder);
         if (rc) return rc;
@@ -2558,7 +2556,7 @@ static int msm_batch_entry(uint64_t handle, const void* const* d_scalars, size_t
     }
   }
   for (size_t j = 0; j < count; j++) {
-    int rc = h2mi_msm_bn254_g1_dev(handle, d_scalars[j], n, (char*)d_out_jacobian + 96 * j, stream);
+    int rc = msm_dev_entry(handle, d_scalars[j], n, (char*)d_out_jacobian + 96 * j, stream, false, general);
     if (rc) return rc;
   }
   return H2MI_OK;
@@ -2624,39 +2622,6 @@ int h2mi_msm_adhoc_builds(uint64_t* builds_out) {
   return H2MI_OK;
 }
 
-int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_jac, size_t n) {
-  H2_REQUIRE_INIT();
-  if (!p || !out_jac || n == 0 || (op != 0 && op != 1) || (op == 0 && !q)) return H2MI_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  hipStream_t s = ctx().stream;
-  DevMem dp, dq, dout;
-  H2_HIP(dp.alloc(n * 64));
-  H2_HIP(dout.alloc(n * 96));
-  H2_HIP(hipMemcpyAsync(dp.p, p, n * 64, hipMemcpyHostToDevice, s));
-  if (q) {
-    H2_HIP(dq.alloc(n * 64));
-    H2_HIP(hipMemcpyAsync(dq.p, q, n * 64, hipMemcpyHostToDevice, s));
-  }
-  H2_LAUNCH("k_dbg_quad", k_dbg_quad, ceil_div_u32(n * 4, 256), 256, 0, s, op, dp.as<uint8_t>(), dq.as<uint8_t>(), dout.as<uint8_t>(), n);
-  H2_HIP(hipMemcpyAsync(out_jac, dout.p, n * 96, hipMemcpyDeviceToHost, s));
-  H2_HIP(hipStreamSynchronize(s));
-  return H2MI_OK;
-}
-
-int h2mi_dbg_msm_batch(int on) {
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  g_head_batch = on != 0;
-  return H2MI_OK;
-}
-int h2mi_dbg_msm_small_path(int on) {
-  H2_REQUIRE_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  int rc = flush_tails();  // what is queued keeps the path it was queued on
-  if (rc) return rc;
-  g_small_path = on != 0;
-  return H2MI_OK;
-}
-
 int h2mi_msm_set_canonical(int on) {
   H2_REQUIRE_INIT();
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
@@ -2692,7 +2657,7 @@ int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce
   uint64_t st = 0;
   H2_HIP(hipMemcpy(&st, B->slot[B->last_slot].stats, 8, hipMemcpyDeviceToHost));
   if (bucket_adds) *bucket_adds = st;
-  if (reduce_adds && B->small && g_small_path) {  // the quad trees: 255 additions per workgroup of 256 lanes, then over the partial sums
+  if (reduce_adds && B->last_small) {  // the quad trees: 255 additions per workgroup of 256 lanes, then over the partial sums
     *reduce_adds = (uint64_t)B->sG * (B->slanes - 1) + B->sG;
   } else if (reduce_adds) {
     // row + column tree sums touch every bucket twice; weighted sums and the final doublings are O(sqrt(nb))

@@ -139,7 +139,7 @@ class ProofReplay:
         self.counts["msm"] += 1
 
     def _msm_many(self, bufs, lagrange: bool, offsets=None):
-        """the commitments of one phase over one base set as ONE call (h2mi_msm_bn254_g1_batch_dev): up to 2^17 points per rank — an
+        """the commitments of one phase over one base set as ONE call (h2mi_msm_bn254_g1_phase_dev): up to 2^17 points per rank — an
         8-GPU rank's slice of a 2^20-row proof — their partition and accumulation kernels are launched once for the group"""
         import ctypes as C
 
@@ -148,7 +148,7 @@ class ProofReplay:
         h = self.params.g_lagrange_handle if lagrange else self.params.g_handle
         offsets = offsets or [0] * len(bufs)
         ptrs = (C.c_void_p * len(bufs))(*[b.ptr + (off + self.lo) * 32 for b, off in zip(bufs, offsets)])
-        check(lib.h2mi_msm_bn254_g1_batch_dev(h, ptrs, len(bufs), self.n_local, self.out_ptr + 96 * self._slot, None), "msm")
+        check(lib.h2mi_msm_bn254_g1_phase_dev(h, ptrs, len(bufs), self.n_local, self.out_ptr + 96 * self._slot, 0, None), "msm")
         self._slot += len(bufs)
         self.counts["msm"] += len(bufs)
 

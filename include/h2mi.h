@@ -88,7 +88,7 @@ int h2mi_sync(void); /* wait for all work queued on the library's streams */
  * h2mi_memcpy_d2h / h2mi_msm_flush — or when half of a handle's workspace slots are pending: two MSMs for base sets
  * above 2^17 points (four slots), four below (eight slots).  A prover calls h2mi_join where the transcript
  * needs the commitments of a phase.  MSMs on a caller-provided stream complete in order on that stream.
- * Base sets of at most 2^14 points defer their whole accumulate-and-finish launch the same way (h2mi_dbg_msm_small_path). */
+ * Base sets of at most 2^14 points defer their whole accumulate-and-finish launch the same way (H2MI_MSM_GENERAL below). */
 int h2mi_join(void);
 /* start the deferred bucket reductions of the MSMs queued so far NOW, on the library's reduction stream, without ordering
  * the library's stream behind them (h2mi_join still does that, later): a prover that has queued the commitments of a phase
@@ -139,41 +139,35 @@ int h2mi_msm_adhoc_builds(uint64_t* builds_out);
 /* device-resident form: scalars and the 96-byte result live in HBM; asynchronous on `stream`. */
 int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian,
                           h2mi_stream_t stream);
-/* the same MSM for a LONE commitment whose point the caller reads next (SHPLONK's two commitments: each is followed by a challenge):
- * partition, accumulation and bucket reduction run in order on one stream, nothing is deferred to the join — the library's three-stream
- * split overlaps CONSECUTIVE MSMs and costs a lone one ~50 us of stream hops.  Same result; sharded handles take the ordinary path. */
-int h2mi_msm_bn254_g1_inorder_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream);
-/* `count` MSMs of n scalars each over ONE registered base set — the commitments of a prover phase (create_proof commits a phase's
- * advice columns, then its grand products, then the quotient's pieces, each group before one challenge: reference
- * examples/standard_plonk.rs:41-49 through halo2_proofs' create_proof).  Result j goes to d_out_jacobian + 96 j; the results are the
- * ones `count` calls of h2mi_msm_bn254_g1_dev in the same order would produce.  For base sets of up to 2^17 points on the library
- * stream the partition and the accumulation of up to four MSMs run as ONE set of launches (the host could not issue a small MSM's eight
- * launches as fast as the device ran them: DESIGN.md 4.1 (x)); larger base sets, caller streams and sharded handles take the loop.
- * The scalars must stay untouched until work queued on `stream` after this call would run (as for the single form). */
-int h2mi_msm_bn254_g1_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
-                                h2mi_stream_t stream);
-/* the same, with the caller's promise that the columns are SPARSE — mostly zeros, or one value repeated almost everywhere (witness
- * columns of a padded circuit, permutation / lookup grand products): the kernels of such an MSM are short at every size, so the batched
- * launches are used above 2^17 points as well (narrow windows; 20-bit windows take the loop).  Results do not depend on the promise;
- * dense columns passed here only lose the overlap between one MSM's partition and the previous one's accumulation. */
-int h2mi_msm_bn254_g1_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian,
-                                       h2mi_stream_t stream);
-/* the general form of the three entries above: `flags` = H2MI_MSM_SPARSE (the sparse promise) | H2MI_MSM_INORDER (the group is all its
- * phase commits and its points are read back next: partition, accumulation AND bucket reductions of the group run on one stream, nothing is
- * deferred — where the batched launches are taken; a dense group above 2^17 points keeps the pipelined loop, whose overlap is worth more). */
+/* `count` MSMs of n scalars each over ONE registered base set — the commitments of a prover phase (create_proof commits a phase's advice
+ * columns, then its grand products, then the quotient's pieces, each group before one challenge: reference examples/standard_plonk.rs:41-49
+ * through halo2_proofs' create_proof).  Result j goes to d_out_jacobian + 96 j; the results are the ones `count` calls of
+ * h2mi_msm_bn254_g1_dev in the same order would produce.  For base sets of up to 2^17 points on the library stream the partition and the
+ * accumulation of up to four MSMs run as ONE set of launches (the host could not issue a small MSM's eight launches as fast as the device
+ * ran them: DESIGN.md 4.1); larger base sets, caller streams and sharded handles take the loop.  The scalars must stay untouched until work
+ * queued on `stream` after this call would run (as for the single form).  flags:
+ *   H2MI_MSM_SPARSE   the caller's promise that the columns are SPARSE — mostly zeros, or one value repeated almost everywhere (witness
+ *                     columns of a padded circuit, permutation / lookup grand products): the kernels of such an MSM are short at every
+ *                     size, so the batched launches are used above 2^17 points as well (narrow windows; 20-bit windows take the loop).
+ *                     Results do not depend on the promise; dense columns passed with it only lose the overlap between one MSM's partition
+ *                     and the previous one's accumulation.
+ *   H2MI_MSM_INORDER  the group is all its phase commits and its points are read back next (a lone commitment: count = 1): partition,
+ *                     accumulation AND bucket reductions run in order on one stream, nothing is deferred to the join — the library's
+ *                     three-stream split overlaps CONSECUTIVE MSMs and costs a lone one ~50 us of stream hops.  A dense group above 2^17
+ *                     points keeps the pipelined loop, whose overlap is worth more; sharded handles take the ordinary path.
+ *   H2MI_MSM_GENERAL  take the general (bucket) pipeline even for a base set that has the latency path's table.  Base sets of at most 2^14
+ *                     points take a latency path of their own (narrow windows against a table of every digit multiple — up to 2 GB per
+ *                     handle, skipped when it does not fit —, two short kernels: DESIGN.md 4.1), which wins a lone commitment and a phase
+ *                     of four; from 2^13 points the general pipeline wins once MSMs stream back to back.  Without this flag the library
+ *                     switches such a handle over by itself after four MSMs have been issued without a join (h2mi_join / h2mi_sync /
+ *                     h2mi_memcpy_d2h); a caller that knows it streams says so up front.  Results do not depend on the path. */
 #define H2MI_MSM_SPARSE 1u
 #define H2MI_MSM_INORDER 2u
+#define H2MI_MSM_GENERAL 4u
 int h2mi_msm_bn254_g1_phase_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, unsigned flags,
                                 h2mi_stream_t stream);
-/* test hook: 0 makes h2mi_msm_bn254_g1_batch_dev issue its MSMs one by one (parity tests, A/B); 1 (default) batches. */
-int h2mi_dbg_msm_batch(int on);
 /* 1: MSM results are normalised to Z = 1 on the device (reproducible bits); 0 (default): raw sum. */
 int h2mi_msm_set_canonical(int on);
-/* Base sets of at most 4096 points take a latency path of their own (narrow windows against a second table, three short
- * kernels, two of them batched over the MSMs of a prover phase: DESIGN.md 4.1 (ix)) — the sizes of the reference's own
- * example runs (examples/standard_plonk.rs:26: k = 5).  Test hook: 0 sends them through the general pipeline instead, so
- * parity tests can run both paths on one handle; 1 (default) restores the small path.  Flushes queued reductions. */
-int h2mi_dbg_msm_small_path(int on);
 /* number of bucket insertions (non-zero signed digits) the last MSM on this handle performed, and the
  * running-sum reduction adds — the numerator of "G1-adds/s" (SURVEY.md 8d).  Synchronises. */
 int h2mi_msm_last_stats(uint64_t handle, uint64_t* bucket_adds, uint64_t* reduce_adds);
@@ -439,15 +433,6 @@ int h2mi_profile_query(const char* prefix, double* total_ms, uint64_t* launches)
 /* every recorded launch in order, one text line each: "<kernel> <start ms after the first recorded launch> <duration ms>";
  * needed_out (may be NULL) receives the buffer size the full text needs; synchronises */
 int h2mi_profile_dump(char* buf, size_t cap, size_t* needed_out);
-
-/* ---- test hooks (elementwise device arithmetic, used by the parity tests only) ------------------- */
-int h2mi_dbg_field_op(int field /*0=Fq,1=Fr*/, int op /*0=mul,1=add,2=sub,3=sqr,4=inv (Fermat),5=from_mont,6=to_mont,7=neg,8=dbl,9=inv by division steps,10=inv by binary Euclid*/,
-                      const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
-/* op 0: out = P + Q (affine inputs, via XYZZ mixed add); 1: 2P; 2: P + Q via XYZZ full add; output Jacobian (12 limbs each) */
-int h2mi_dbg_g1_op(int op, const uint64_t* p_affine, const uint64_t* q_affine, uint64_t* out_jac, size_t n);
-/* the lane-cooperative point operations of the bucket reduction (csrc/g1_29_quad.cuh), four lanes per
- * element: op 0 = P[i] + Q[i] (XYZZ + XYZZ), op 1 = 2 P[i]; affine Montgomery in, Jacobian out */
-int h2mi_dbg_g1_quad_op(int op, const uint64_t* p, const uint64_t* q_or_null, uint64_t* out_jac, size_t n);
 
 #ifdef __cplusplus
 }

@@ -366,6 +366,16 @@ inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
   if (a.size() != ((size_t)1 << log_n)) throw Error(H2MI_EINVAL, "best_fft: a.len() != 1 << log_n");
   check(h2mi_ntt_bn254_fr((uint64_t*)a.data(), omega.l, log_n), "best_fft");
 }
+// shorthands of the phase entry (exports of their own until round 4): a lone in-order commitment, a batch, a sparse batch
+inline int msm_inorder_dev(uint64_t handle, const void* d_scalars, size_t n, void* d_out_jacobian, h2mi_stream_t stream = nullptr) {
+  return h2mi_msm_bn254_g1_phase_dev(handle, &d_scalars, 1, n, d_out_jacobian, H2MI_MSM_INORDER, stream);
+}
+inline int msm_batch_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream = nullptr) {
+  return h2mi_msm_bn254_g1_phase_dev(handle, d_scalars, count, n, d_out_jacobian, 0, stream);
+}
+inline int msm_batch_sparse_dev(uint64_t handle, const void* const* d_scalars, size_t count, size_t n, void* d_out_jacobian, h2mi_stream_t stream = nullptr) {
+  return h2mi_msm_bn254_g1_phase_dev(handle, d_scalars, count, n, d_out_jacobian, H2MI_MSM_SPARSE, stream);
+}
 struct DeviceVec {  // RAII device copy of a coefficient vector
   void* p = nullptr;
   size_t n = 0;

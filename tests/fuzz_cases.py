@@ -90,12 +90,16 @@ class Fuzzer:
             m = n if rng.random() < 0.6 else rng.randint(1, n)
             sc = np.ascontiguousarray(scalars(n, kind, seed + len(kind))[:m])
             want = cref.normalize(cref.msm(sc, bases[:m], 8))
-            for small in (1, 0):
-                lib.h2mi_dbg_msm_small_path(small)
-                assert lib.h2mi_msm_bn254_g1(h.value, None, sc.ctypes.data, m, out.ctypes.data) == 0
-                assert np.array_equal(cref.normalize(out), want), ("msm", seed0, n, m, kind, small, seed)
+            assert lib.h2mi_msm_bn254_g1(h.value, None, sc.ctypes.data, m, out.ctypes.data) == 0  # the path the library picks
+            assert np.array_equal(cref.normalize(out), want), ("msm", seed0, n, m, kind, "host", seed)
+            d_sc, d_o = DevBuf.from_numpy(sc), DevBuf(96)
+            one = (C.c_void_p * 1)(d_sc.ptr)
+            for flags in (4, 4 | 2, 0):  # H2MI_MSM_GENERAL (forced general pipeline), ... | H2MI_MSM_INORDER, the default again
+                assert lib.h2mi_msm_bn254_g1_phase_dev(h.value, one, 1, m, d_o.ptr, flags, None) == 0
+                assert np.array_equal(cref.normalize(d_o.to_numpy(shape=(12,))), want), ("msm", seed0, n, m, kind, flags, seed)
                 counts["msm"] += 1
-            lib.h2mi_dbg_msm_small_path(1)
+            d_sc.free()
+            d_o.free()
         # a batch queued on the library stream before one join
         q = rng.randint(2, 9)
         vecs = [np.ascontiguousarray(scalars(n, rng.choice(KINDS), seed + 100 + i)) for i in range(q)]
@@ -112,12 +116,10 @@ class Fuzzer:
         cut = rng.randint(1, q - 1)
         ptr_a = (C.c_void_p * cut)(*[d.ptr for d in dv[:cut]])
         ptr_b = (C.c_void_p * (q - cut))(*[d.ptr for d in dv[cut:]])
-        lib.h2mi_dbg_msm_small_path(rng.choice((0, 1)))
-        fa, fb = rng.choice((0, 1, 2, 3)), rng.choice((0, 1, 2, 3))  # H2MI_MSM_SPARSE | H2MI_MSM_INORDER
+        fa, fb = rng.randrange(8), rng.randrange(8)  # H2MI_MSM_SPARSE | H2MI_MSM_INORDER | H2MI_MSM_GENERAL
         assert lib.h2mi_msm_bn254_g1_phase_dev(h.value, ptr_a, cut, n, dout2.ptr, fa, None) == 0
         assert lib.h2mi_msm_bn254_g1_phase_dev(h.value, ptr_b, q - cut, n, dout2.ptr + 96 * cut, fb, None) == 0
         got2 = dout2.to_numpy(shape=(q, 12))
-        lib.h2mi_dbg_msm_small_path(1)
         for i in range(q):
             assert np.array_equal(cref.normalize(got2[i]), cref.normalize(got[i])), ("phase batch", seed0, n, i, cut, fa, fb, seed)
         counts["msm_phase_batches"] += 1

@@ -1,4 +1,4 @@
-"""N back-to-back device-resident MSMs of 2^k points then one sync, issued singly and in groups of G through h2mi_msm_bn254_g1_batch_dev
+"""N back-to-back device-resident MSMs of 2^k points then one sync, issued singly and in groups of G through h2mi_msm_bn254_g1_phase_dev
 (an 8-GPU rank's commitment stream: 2^17 slices of a 2^20 proof).  Usage: msm_b2b_batch.py K [N] [G]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ def grouped():
     for i0 in range(0, N, G):
         m = min(G, N - i0)
         ptrs = (C.c_void_p * m)(*[sc[(i0 + j) % 4].ptr for j in range(m)])
-        assert lib.h2mi_msm_bn254_g1_batch_dev(p.g_handle, ptrs, m, n, out.ptr + 96 * i0, None) == 0
+        assert lib.h2mi_msm_bn254_g1_phase_dev(p.g_handle, ptrs, m, n, out.ptr + 96 * i0, 0, None) == 0
 for name, run in (("single", single), (f"groups of {G}", grouped), ("single", single), (f"groups of {G}", grouped)):
     for _ in range(3):
         run(); lib.h2mi_sync()
