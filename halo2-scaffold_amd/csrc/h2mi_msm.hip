@@ -152,7 +152,9 @@ static bool g_canonical = false;
 // (H2MI_MSM_GENERAL on the phase entry), and without the flag a base set above SMALL_STREAM_N points switches to it after
 // SMALL_STREAM_AFTER MSMs have been issued without a join — a phase (<= 4 commitments, then the transcript needs them) never gets
 // there, a stream does after its first four.  Results do not depend on the path (tests/test_gpu_parity.py runs both against the oracle).
-constexpr size_t SMALL_STREAM_N = (size_t)1 << 12;
+// Measured (profiles/r05_msm_sweep.txt; latency / four MSMs + join / back to back, us; latency path pinned | general | this rule):
+//   2^13  151 / 356 / 85.1 | 266 / 546 / 87.1 | stays on the latency path      2^14  182 / 489 / 113.2 | 271 / 576 / 97.8 | 182 / 483 / 98.5
+constexpr size_t SMALL_STREAM_N = (size_t)1 << 13;
 constexpr uint32_t SMALL_STREAM_AFTER = 4;
 static uint64_t g_next_handle = 1;
 

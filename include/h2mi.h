@@ -158,7 +158,7 @@ int h2mi_msm_bn254_g1_dev(uint64_t handle, const void* d_scalars, size_t n, void
  *   H2MI_MSM_GENERAL  take the general (bucket) pipeline even for a base set that has the latency path's table.  Base sets of at most 2^14
  *                     points take a latency path of their own (narrow windows against a table of every digit multiple — up to 2 GB per
  *                     handle, skipped when it does not fit —, two short kernels: DESIGN.md 4.1), which wins a lone commitment and a phase
- *                     of four; from 2^13 points the general pipeline wins once MSMs stream back to back.  Without this flag the library
+ *                     of four; above 2^13 points the general pipeline wins once MSMs stream back to back.  Without this flag the library
  *                     switches such a handle over by itself after four MSMs have been issued without a join (h2mi_join / h2mi_sync /
  *                     h2mi_memcpy_d2h); a caller that knows it streams says so up front.  Results do not depend on the path. */
 #define H2MI_MSM_SPARSE 1u

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 [ -x tools/hbm_calib ] || hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o tools/hbm_calib
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-create-proof"  # the replay only: one kind of launch per kernel
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-create-proof --no-msm-only"  # the replay only (its registration aside: summarize_profiles.py separates those two launches)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $BENCH > $OUT/bench_fetch.json 2> $OUT/fetch.err
