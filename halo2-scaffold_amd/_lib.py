@@ -100,6 +100,7 @@ def _load():
         "h2mi_plonk_evaluate_h_flex_dev": ([vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "h2mi_g1_fixed_base_mul_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_fr_powers_dev": ([vp, sz, vp, vp], C.c_int),
+        "h2mi_fft_bn254_g1_dev": ([vp, vp, C.c_uint32, vp, vp, vp], C.c_int),
         "h2mi_profile_enable": ([C.c_int], C.c_int),
         "h2mi_profile_filter": ([C.c_char_p], C.c_int),
         "h2mi_profile_reset": ([], C.c_int),

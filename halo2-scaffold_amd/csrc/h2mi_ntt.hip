@@ -586,6 +586,7 @@ struct Plan {
   fe* loc[3] = {nullptr, nullptr, nullptr};
   fe* wmat[3] = {nullptr, nullptr, nullptr};  // tile-ordered inter-pass twiddles of the non-final passes (k_ntt_wmat_build)
   uint32_t wlogC[3] = {0, 0, 0};              // the tile geometry each was built for
+  size_t wmat_bytes = 0;                      // what the matrices hold of the cache budget (g_wmat_bytes)
   Built built;
   uint64_t last_use = 0;
 };
@@ -626,6 +627,10 @@ constexpr size_t POWTAB_MAX_ENTRIES = 64, POWTAB_KEEP_ENTRIES = 32;
 constexpr size_t PLAN_KEEP = 24;  // transform plans (one per (omega, size): a prover uses four to six) kept through an eviction
 constexpr size_t POWTAB_MAX_BYTES = (size_t)3 << 30, POWTAB_KEEP_BYTES = (size_t)3 << 29;
 static size_t g_powtab_bytes = 0;
+// the plans' tile-ordered twiddle matrices (32 MB at 2^20, 512 MB at 2^24) count against a budget of their own: a process that
+// transforms at many sizes would otherwise pile them up unseen by the evictions (round-4 ADVICE)
+constexpr size_t WMAT_MAX_BYTES = (size_t)8 << 30, WMAT_KEEP_BYTES = (size_t)4 << 30;
+static size_t g_wmat_bytes = 0;
 static uint64_t g_epoch = 1, g_evictions = 0;
 void tables_new_call() { g_epoch++; }
 fe* tmp_base() { return g_tmp; }
@@ -678,6 +683,8 @@ static void free_plan(Plan& pl) {
     if (pl.wmat[i]) H2_IGNORE(hipFree(pl.wmat[i]));
     pl.wmat[i] = nullptr;
   }
+  g_wmat_bytes -= std::min(g_wmat_bytes, pl.wmat_bytes);
+  pl.wmat_bytes = 0;
   pl.built.destroy();
 }
 
@@ -707,7 +714,7 @@ static int evict_tables() {
     }
   };
   drop_unreferenced();
-  if (g_powtabs.size() > POWTAB_KEEP_ENTRIES || g_powtab_bytes > POWTAB_KEEP_BYTES || g_plans.size() > PLAN_KEEP) {
+  if (g_powtabs.size() > POWTAB_KEEP_ENTRIES || g_powtab_bytes > POWTAB_KEEP_BYTES || g_plans.size() > PLAN_KEEP || g_wmat_bytes > WMAT_KEEP_BYTES) {
     // still over: the plans of domains no longer in use (oldest first), then the tables they held
     std::vector<std::pair<uint64_t, Key>> plans;
     for (auto& kv : g_plans)
@@ -718,7 +725,7 @@ static int evict_tables() {
       free_plan(it->second);
       g_plans.erase(it);
       drop_unreferenced();
-      if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES && g_plans.size() <= PLAN_KEEP) break;
+      if (g_powtabs.size() <= POWTAB_KEEP_ENTRIES && g_powtab_bytes <= POWTAB_KEEP_BYTES && g_plans.size() <= PLAN_KEEP && g_wmat_bytes <= WMAT_KEEP_BYTES) break;
     }
   }
   g_evictions++;
@@ -906,11 +913,27 @@ static int get_plan(const uint64_t omega[4], uint32_t log_n, hipStream_t s, Plan
     for (int p = 0; p + 1 < pl.P; p++) {
       const uint32_t m = pl.m[p], logS = log_seg - m;
       const uint32_t logC = std::min(m >= NTT_TILE_LOG ? 0u : NTT_TILE_LOG - m, logS);
-      if (hipMalloc(&pl.wmat[p], ((size_t)1 << log_seg) * 32) != hipSuccess) {
-        pl.wmat[p] = nullptr;
-        free_plan(pl);
-        return H2MI_ENOMEM;
+      // the matrices are an accelerator, not a requirement: over budget or out of memory, older plans go first, and if that does
+      // not help the pass keeps the two-level gather (ntt_dev reads wmat = nullptr as exactly that)
+      const size_t wbytes = ((size_t)1 << log_seg) * 32;
+      if (g_wmat_bytes + wbytes > WMAT_MAX_BYTES) {
+        int rce = evict_tables();
+        if (rce) { free_plan(pl); return rce; }
       }
+      if (hipMalloc(&pl.wmat[p], wbytes) != hipSuccess) {
+        (void)hipGetLastError();
+        pl.wmat[p] = nullptr;
+        int rce = evict_tables();
+        if (rce) { free_plan(pl); return rce; }
+        if (hipMalloc(&pl.wmat[p], wbytes) != hipSuccess) {
+          (void)hipGetLastError();
+          pl.wmat[p] = nullptr;
+          log_seg -= m;
+          continue;
+        }
+      }
+      pl.wmat_bytes += wbytes;
+      g_wmat_bytes += wbytes;
       pl.wlogC[p] = logC;
       H2_LAUNCH("k_ntt_wmat_build", k_ntt_wmat_build, ceil_div_u32((size_t)1 << log_seg, 256), 256, 0, s, (const fe*)pl.tw.lo, (const fe*)pl.tw.hi, pl.tw.h,
                 pl.tw.full ? 1u : 0u, pl.wmat[p], log_seg, m, logC, log_n - log_seg);

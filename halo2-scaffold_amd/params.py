@@ -130,6 +130,23 @@ class ParamsKZG:
         p._register()
         return p
 
+    @classmethod
+    def from_monomial(cls, k: int, g: np.ndarray, g2_bytes: bytes = None, s_g2_bytes: bytes = None) -> "ParamsKZG":
+        """the whole SRS from its monomial half, WITHOUT the secret — what ParamsKZG::setup does after its powers of s
+        (`best_fft(&mut g_lagrange_projective, root.invert(), k)`, then n^-1; poly/kzg/commitment.rs [RECALL]): the group-valued inverse
+        transform of g on the device (h2mi_fft_bn254_g1_dev).  For an SRS that arrives as points (a ceremony file, a fork's own
+        `setup`); `setup(k, s)` above takes the shortcut through the exponents that knowing s allows."""
+        p = cls(k)
+        assert len(g) == p.n
+        p.g2_bytes, p.s_g2_bytes = g2_bytes, s_g2_bytes
+        p._g_dev = DevBuf.from_numpy(np.ascontiguousarray(g, dtype=np.uint64))
+        p._gl_dev = DevBuf(p.n * 64)
+        w_inv = F.fr_to_mont_limbs(F.fr_inv(F.omega_for(k)))
+        n_inv = F.fr_to_mont_limbs(F.fr_inv(p.n))
+        check(lib.h2mi_fft_bn254_g1_dev(p._g_dev.ptr, p._gl_dev.ptr, k, w_inv.ctypes.data, n_inv.ctypes.data, None), "group fft")
+        p._register()
+        return p
+
     def _register(self):
         h = C.c_uint64()
         check(lib.h2mi_bases_register_dev(self._g_dev.ptr, self.n, C.byref(h)), "register g")

@@ -405,6 +405,14 @@ int h2mi_plonk_evaluate_h_flex_dev(const h2mi_flex_cosets* cosets, uint32_t k, u
 int h2mi_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, h2mi_stream_t stream);
 /* out[i] = base^i for i < n (the powers-of-s vector of ParamsKZG::setup), Montgomery in and out */
 int h2mi_fr_powers_dev(void* d_out, size_t n, const uint64_t base[4], h2mi_stream_t stream);
+/* halo2_proofs::arithmetic::best_fft for G = bn256::G1 — the group-valued transform ParamsKZG::setup runs over the monomial SRS to get
+ * the Lagrange one (reference examples/standard_plonk.rs:29; `best_fft(&mut g_lagrange_projective, root.invert(), k)` then a scaling by
+ * n^-1): out[i] = post_scale * sum_j omega^(i j) * in[j], natural order in and out.  Points are G1Affine on both sides (n x 64 B, (0, 0) =
+ * identity); in place allowed.  omega: a 2^log_n-th root of unity; post_scale (Montgomery) may be NULL.  Every butterfly multiplies a
+ * point by a 254-bit twiddle, so the cost is (n / 2) log n scalar multiplications (seconds at DEGREE 20 - 22, where the crate takes
+ * minutes): keygen-time work.  Uses 144 B x n of scratch for the call and synchronises `stream` before returning.  log_n <= 26. */
+int h2mi_fft_bn254_g1_dev(const void* d_affine_in, void* d_affine_out, uint32_t log_n, const uint64_t omega[4], const uint64_t* post_scale_or_null,
+                          h2mi_stream_t stream);
 
 /* ---- wire encodings: what create_proof writes to the transcript (reference call sites:
  * Blake2bWrite::init / finalize around create_proof, examples/standard_plonk.rs:40-50 and src/scaffold.rs:190-200,

@@ -1244,3 +1244,60 @@ def test_eval_polys_multi_and_powtab_prefetch_match_oracle(gpu, n):
         x.free()
     out.free()
     q.free()
+
+
+# ---- round 5: best_fft over G1 points (ParamsKZG::setup's Lagrange basis without the secret) -------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10])
+def test_group_fft_matches_the_transform_in_the_exponent(gpu, log_n):
+    """h2mi_fft_bn254_g1_dev against an independent route: for points a_j = e_j G with KNOWN discrete logarithms the group DFT is
+    the scalar DFT of the e_j times G — the oracle's integer NTT and the C restatement's generator multiplication.  Inputs include
+    the identity (e_j = 0), repeated points, P and -P next to each other (the complete-formula cases inside butterflies); forward,
+    inverse with the n^-1 scale, in place and out of place."""
+    from oracle import cref
+
+    from halo2_scaffold_amd import field as F
+    from halo2_scaffold_amd.device import DevBuf
+
+    n = 1 << log_n
+    e = o.unpack(o.random_field_limbs(n, 900 + log_n), o.R)
+    if n >= 8:
+        e[1] = 0
+        e[2] = e[3]
+        e[5] = (o.R - e[4]) % o.R
+    if n >= 2:
+        e[n - 1] = 0
+    pts = cref.g1_mul_gen(o.pack(e, o.R), 8)
+    w = F.omega_for(log_n)
+    d_in, d_out = DevBuf.from_numpy(pts), DevBuf(n * 64)
+    wl = F.fr_to_mont_limbs(w)
+    assert gpu.lib.h2mi_fft_bn254_g1_dev(d_in.ptr, d_out.ptr, log_n, wl.ctypes.data, None, None) == 0
+    want = cref.g1_mul_gen(o.pack(o.dft_naive(e, w) if n <= 64 else o.ntt(e, w), o.R), 8)
+    assert np.array_equal(d_out.to_numpy(shape=(n, 8)), want)
+    assert np.array_equal(d_in.to_numpy(shape=(n, 8)), pts)  # the input is left alone
+    # inverse with the fused n^-1, in place: back to the input
+    wil, nil = F.fr_to_mont_limbs(F.fr_inv(w)), F.fr_to_mont_limbs(F.fr_inv(n))
+    assert gpu.lib.h2mi_fft_bn254_g1_dev(d_out.ptr, d_out.ptr, log_n, wil.ctypes.data, nil.ctypes.data, None) == 0
+    assert np.array_equal(d_out.to_numpy(shape=(n, 8)), pts)
+    # argument checks
+    assert gpu.lib.h2mi_fft_bn254_g1_dev(None, d_out.ptr, log_n, wl.ctypes.data, None, None) == -1
+    assert gpu.lib.h2mi_fft_bn254_g1_dev(d_in.ptr, d_out.ptr, 27, wl.ctypes.data, None, None) == -6
+    d_in.free()
+    d_out.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [6, 16])
+def test_group_fft_of_the_monomial_srs_is_the_lagrange_srs(gpu, k):
+    """ParamsKZG::setup's second half (reference examples/standard_plonk.rs:29): the inverse group transform of g = (s^i G) scaled by
+    n^-1 is g_lagrange = (L_i(s) G) — here against the secret route's g_lagrange (fixed-base multiples of the iNTT of the powers of
+    s), two independent computations of the same 2^k points; commitments through either SRS agree."""
+    s = 0x5EC2E7 + 0x48324D49
+    ref = gpu.ParamsKZG.setup(k, s)
+    g, gl = ref.get_g(), ref.get_g_lagrange()
+    p = gpu.ParamsKZG.from_monomial(k, g)
+    assert np.array_equal(p.get_g_lagrange(), gl)
+    col = o.random_field_limbs(1 << k, 77)
+    assert o.unpack_jacobian(p.commit_lagrange(col)) == o.unpack_jacobian(ref.commit_lagrange(col))
+    p.release()
+    ref.release()
