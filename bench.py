@@ -259,7 +259,7 @@ def main(argv=None):
     # HBM traffic of the kernel comes from rocprofv3 PMC counters, which cannot be collected from inside this
     # process: the field carries the figure of the latest committed counter run of this same workload and says so
     traffic, traffic_source = None, None
-    for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and world == 1 and args.k == 20 and args.shape == "standard_plonk":
             try:

@@ -71,7 +71,9 @@ with open(f"profiles/{tag}_sq_counters.csv", "w") as f:
     for k in sorted(sq):
         f.write(k + f",{n[k]}," + ",".join(f"{sq[k][x] / max(n[k], 1):.0f}" for x in names) + "\n")
 # k_msm_accum launch by launch (round-4 VERDICT: the stats CSV's average mixes the replay's dense 2^20 MSMs with the registration's
-# all-ones MSMs): the kernel trace's own durations, classed by size — the replay's launches are the ones within 30 % of the median
+# all-ones MSMs): the kernel trace's own durations, classed by size.  Every launch has the same grid (a resident grid of 131072 threads), so
+# the class is read off the duration: the all-ones MSMs of the two registrations finish in < 0.1 ms (the dominant-value shift empties them),
+# every other launch is a dense 2^20 MSM of the replay — including the ones that share the SIMDs with transform passes and take 1.7 - 2.6 ms
 import glob
 import statistics
 
@@ -80,12 +82,15 @@ if tr:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tr[0])) if "k_msm_accum" in r["Kernel_Name"]]
     if durs:
         med = statistics.median(durs)
-        replay = [d for d in durs if 0.7 * med <= d <= 1.3 * med]
-        other = [d for d in durs if not 0.7 * med <= d <= 1.3 * med]
+        replay = [d for d in durs if d >= 0.5 * med]
+        other = [d for d in durs if d < 0.5 * med]
+        alone = [d for d in replay if d <= 1.3 * med]
         bench_line = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
         acc = {
             "source": f"rocprofv3 --kernel-trace over `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-create-proof --no-msm-only`, {tag}: every k_msm_accum launch",
             "replay_dense_launches": {"count": len(replay), "avg_ns": round(sum(replay) / len(replay)), "min_ns": min(replay), "max_ns": max(replay)},
+            "of_which_not_sharing_the_chip_with_transforms": {"count": len(alone), "avg_ns": round(sum(alone) / len(alone)),
+                                                              "what": "launches within 30 % of the median: the accumulation alone on the SIMDs"},
             "other_launches": {"count": len(other), "what": "the registration's all-ones MSMs (one per base set: the sum point of the dominant-value shift)",
                                "durations_ns": sorted(other)},
             "algorithmic_bytes_per_launch": 96 << 20,
