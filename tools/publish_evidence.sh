@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # copies what tools/final_evidence.sh TAG left under gpurun_out/ into profiles/TAG_* (run in the build container, repo root)
 set -euo pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 E=gpurun_out/ev_$TAG
 python3 tools/summarize_profiles.py $TAG > /dev/null
 cp $E/bench.json profiles/${TAG}_bench.json
@@ -17,7 +17,10 @@ open(f"profiles/{tag}_scaling_model_k20.json", "w").write(json.dumps(json.loads(
 PY
 for f in proof_timeline_k8 proof_timeline_k16 proof_timeline_k20 proof_timeline_cpp_host_k8 proof_timeline_cpp_host_k20; do cp $E/$f.txt profiles/${TAG}_$f.txt; done
 cp $E/poseidon_host_profile.txt profiles/${TAG}_poseidon_host_profile.txt
-{ echo "# MSM sweep, final build (tools/msm_sweep.py: general pipeline 2^18 .. 2^22; tools/msm_small_sweep.py: small path vs general pipeline 2^5 .. 2^17)"; cat $E/msm_sweep.txt; echo; grep -v amdgpu $E/msm_small_final.txt; } > profiles/${TAG}_msm_sweep.txt
+[ -f $E/g1fft_sweep.txt ] && cp $E/g1fft_sweep.txt profiles/${TAG}_g1fft_sweep.txt
+[ -f $E/fuzz.txt ] && cp $E/fuzz.txt profiles/${TAG}_fuzz.txt
+cp $E/ntt_sweep.txt profiles/${TAG}_ntt_sweep.txt
+{ echo "# MSM sweep, final build (tools/msm_sweep.py: general pipeline 2^18 .. 2^22; tools/msm_small_sweep.py 2^5 .. 2^17: 'default' = the path the library picks"; echo "# by itself (latency path up to 2^14 points; above 2^13 the general pipeline once four MSMs are queued without a join), 'general' = H2MI_MSM_GENERAL,"; echo "# 'small path' = the latency path pinned whatever the queue depth (libh2mi_ab.so, H2MI_MSM_NO_AUTO_STREAM=1))"; cat $E/msm_sweep.txt; echo; grep -v amdgpu $E/msm_small_final.txt; } > profiles/${TAG}_msm_sweep.txt
 python3 - "$TAG" <<'PY'
 import csv, json, sys
 tag = sys.argv[1]
