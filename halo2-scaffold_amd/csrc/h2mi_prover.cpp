@@ -1140,6 +1140,7 @@ int h2mi_prover_keygen(const h2mi_constraint_system* cs, uint64_t g_lagrange_han
                        unsigned flags, h2mi_pk_t* pk_out) {
   if (!cs || !pk_out || (cs->n_fixed && !fixed) || (n_copies && !copies) || (flags & ~(unsigned)H2MI_KEYGEN_VK_ONLY)) return H2MI_EINVAL;
   *pk_out = nullptr;
+  if (h2mi_device_count() == 0) return H2MI_ENODEV;  // no CPU fallback: the prover exists on a GPU or not at all
   return guarded([&] {
     std::unique_ptr<h2mi_pk_s> pk = keygen(*cs, g_lagrange_handle, fixed, copies, n_copies, flags);
     std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -1171,6 +1172,7 @@ int h2mi_prover_vk_commitments(h2mi_pk_t pk, uint64_t* fixed_out, uint64_t* perm
 int h2mi_prover_create(h2mi_pk_t pk, uint64_t g_handle, uint64_t g_lagrange_handle, size_t base_lo, size_t base_count, h2mi_prover_t* prover_out) {
   if (!prover_out) return H2MI_EINVAL;
   *prover_out = nullptr;
+  if (h2mi_device_count() == 0) return H2MI_ENODEV;
   if (!alive(g_live_pks, pk)) return H2MI_EHANDLE;
   return guarded([&] {
     std::unique_ptr<h2mi_prover_s> p = create_prover(pk, g_handle, g_lagrange_handle, base_lo, base_count);

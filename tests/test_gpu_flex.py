@@ -342,7 +342,9 @@ def test_multi_column_proofs_match_oracle_and_golden(gpu):
     GateThreadBuilder::config would (range LOOKUP_BITS 4 at DEGREE 5: 3 gate + 1 lookup-advice column; LOOKUP_BITS 3 at DEGREE 6:
     2 + 1; poseidon at DEGREE 11: 4 gate columns), the product's incremental layout equals the oracle's closed-form one cell for
     cell and constrain_equal for constrain_equal, keys and proof bytes equal the oracle's (live at DEGREE <= 6) and the committed
-    golden (tests/golden/flex_multi_proofs.json), and the oracle's verifier accepts / rejects as it should.  The quotient runs
+    golden (tests/golden/flex_multi_proofs.json), and the oracle's verifier accepts / rejects as it should.  This is an ORACLE
+    SELF-CHECK, not parity with the crate: the multi-column layout (break-point rule, constrain_equal order) is restated from memory
+    of halo2-base 0.3, which is not under /root/reference, and the golden was made by this repository's oracle.  The quotient runs
     through the general kernel (h2mi_plonk_evaluate_h_flex_dev): one gate per column, one lookup per lookup-advice column."""
     import json
     import os

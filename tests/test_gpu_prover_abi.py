@@ -223,3 +223,32 @@ def test_lookup_failure_code_and_identity_point(gpu):
     ws.release()
     keys.release()
     params.release()
+
+
+def test_keys_and_provers_release_their_device_memory(gpu):
+    """twenty rounds of keygen + prover + one proof + destroy + release at 2^12 rows leave the device's free memory where it was
+    (the library owns every vector of the prover: a leak would be the library's)"""
+    import torch
+
+    from halo2_scaffold_amd import flex
+
+    params = gpu.ParamsKZG.setup(12, 0x5EC2E7)
+    cs = flex.FlexGateCS(lookup=True)
+    asg = flex.range_closure(cs, 0xABCDEF, 8)
+
+    def round_trip():
+        keys = flex.FlexKeys(params, cs, asg)
+        ws = flex.FlexWorkspace(params, keys)
+        proof = flex.create_proof(params, keys, asg, 4, ws=ws)
+        ws.release()
+        keys.release()
+        return proof
+
+    first = round_trip()  # caches (power tables, plans, scratch) fill on the first round
+    gpu._lib.check(gpu.lib.h2mi_sync(), "sync")
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        assert round_trip() == first
+    gpu._lib.check(gpu.lib.h2mi_sync(), "sync")
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # the runtime's own pools may move by a few MB
+    params.release()

@@ -43,6 +43,32 @@ def test_no_cpu_fallback_without_gpu(h2):
     assert b"no CPU fallback" in h2.lib.h2mi_strerror(-2)
 
 
+def test_prover_abi_refuses_without_gpu(h2):
+    """level B (include/h2mi_prover.h) has no CPU fallback either: keygen and prover creation return H2MI_ENODEV before looking at
+    anything else, and a handle that was never issued is H2MI_EHANDLE for every phase."""
+    import ctypes as C
+
+    import torch
+
+    from halo2_scaffold_amd import circuits, engine, keygen
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_prover_abi.py")
+    cs = keygen.constraint_system(circuits.StandardPlonk, 5)
+    cells, keep = engine.pack_cells([{} for _ in range(5)])
+    out = C.c_void_p()
+    assert h2.lib.h2mi_prover_keygen(C.byref(cs), 1, cells, None, 0, 0, C.byref(out)) == -2 and not out.value
+    assert h2.lib.h2mi_prover_create(None, 1, 2, 0, 32, C.byref(out)) == -2
+    assert h2.lib.h2mi_prover_keygen(None, 1, cells, None, 0, 0, C.byref(out)) == -1  # argument checks come first
+    bogus = C.c_void_p(0x1234)
+    pts = np.zeros((8, 8), dtype=np.uint64)
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    assert h2.lib.h2mi_prover_advice(bogus, cells, None, 0, 1, pts.ctypes.data) == -5
+    assert h2.lib.h2mi_prover_quotient(bogus, one.ctypes.data, pts.ctypes.data) == -5
+    assert h2.lib.h2mi_prover_destroy(bogus) == -5 and h2.lib.h2mi_prover_pk_release(bogus) == -5
+    assert b"not satisfied" in h2.lib.h2mi_strerror(-7)
+
+
 def test_multi_device_mode_needs_devices(h2):
     """h2mi_init_devices (one process, n GPUs) fails like h2mi_init without a GPU and leaves the library uninitialised;
     the slice partition it applies is the one dist.slice_bounds states (contiguous, sizes differing by at most one)."""
