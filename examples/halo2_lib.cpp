@@ -56,11 +56,14 @@ int main(int argc, char** argv) {
   try {
     init();
     auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
-    const flex::FlexGateCS cs(lookup);
-    auto closure = [&](uint64_t v) {
-      if (shape == "poseidon") return flex::poseidon_hash_two_closure(cs, fr::from_u64(v), fr::from_u64(v + 1));
-      return lookup ? flex::range_closure(cs, v, lookup_bits) : flex::halo2_lib_closure(cs, fr::from_u64(v));
+    auto run = [&](const flex::FlexGateCS& c, uint64_t v) {
+      if (shape == "poseidon") return flex::poseidon_hash_two_closure(c, fr::from_u64(v), fr::from_u64(v + 1));
+      return lookup ? flex::range_closure(c, v, lookup_bits) : flex::halo2_lib_closure(c, fr::from_u64(v));
     };
+    // `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268): more than one gate column when the closure's cells overflow 2^k rows
+    const flex::FlexGateCS cs = flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); });
+    if (cs.num_advice > 1) std::printf("columns %u gate + %u lookup-advice\n", cs.num_advice, cs.num_lookup_advice);
+    auto closure = [&](uint64_t v) { return run(cs, v); };
     // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape
     auto pk = [&] { Timer t("Generating verifying and proving key"); return flex::keygen(params, cs, closure(0)); }();
     flex::Assignment asg = closure(x);

@@ -389,6 +389,16 @@ def test_multi_column_proofs_match_oracle_and_golden(gpu):
             ws.release()
         keys.release()
         params.release()
+        # the C++ host (include/h2mi_flex.hpp: its own Context / configure / break-point layout over the same prover ABI): same bytes
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+        r = subprocess.run([os.path.join(root, "examples", "halo2_lib"), shape, str(k), str(bits), str(x), hex(secret), str(seed)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1000:]
+        out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ", "columns ")))
+        assert out["columns"] == f"{cs.num_advice} gate + {cs.num_lookup_advice} lookup-advice"
+        assert out["vk"] == case["vk_bytes"] and out["proof"] == case["proof"], ("C++", shape, k)
     # the column count the crate's formula gives can be too small (a gate never straddles two columns): same failure as halo2-base
     cs = flex.configure(False, 4, lambda c: flex.halo2_lib_closure(c, 12))
     assert cs.num_advice == 3
