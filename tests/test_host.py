@@ -337,7 +337,7 @@ def test_cpp_host_single_element_inversion_matches_pow():
 
     src = os.path.join(ROOT, "tests", "host", "inv_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libinvhost.so")
-    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "include", "h2mi_plonk.hpp"),
+    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "h2mi_hostmath.hpp"),
             os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "inv_divsteps.cuh")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
@@ -371,3 +371,63 @@ def test_cpp_host_single_element_inversion_matches_pow():
         L.h2t_inv_mont(field, 1, M.ctypes.data, fermat.ctypes.data, len(M))
         assert np.array_equal(fast, fermat)
         assert o.unpack(fast, mod) == [0] + [pow(v, -1, mod) for v in vals[:3000]]
+
+
+def test_prover_host_helpers_match_oracle():
+    """what csrc/h2mi_prover.cpp computes on the CPU around its kernels (csrc/h2mi_hostmath.hpp), without a GPU: the copy
+    constraints' cycle structure (permutation/keygen.rs Assembly::copy: merge the smaller cycle into the larger, swap two mapping
+    entries) against oracle/plonk.py's dense Assembly on random constrain_equal sequences incl. repeats and self-copies;
+    G1::batch_normalize of a phase's Jacobian points (one inversion) incl. the identity; the counter-based blinding stream; the
+    canonical order SHPLONK sorts its rotation points by."""
+    import ctypes as C
+    import random
+
+    from oracle import plonk as P
+
+    src = os.path.join(ROOT, "tests", "host", "prover_host.cpp")
+    so = os.path.join(ROOT, "tests", "host", "libproverhost.so")
+    deps = [src, os.path.join(ROOT, "include", "h2mi.hpp"), os.path.join(ROOT, "halo2-scaffold_amd", "csrc", "h2mi_hostmath.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.h2t_assembly.argtypes, L.h2t_assembly.restype = [C.c_void_p, C.c_size_t, C.c_void_p], C.c_size_t
+    L.h2t_uniform_fr.argtypes = [C.c_uint64, C.c_size_t, C.c_uint64, C.c_void_p]
+    L.h2t_normalize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2t_canonical_less.argtypes, L.h2t_canonical_less.restype = [C.c_void_p, C.c_void_p], C.c_int
+    rng = random.Random(0xA55E)
+    for trial in range(60):
+        cols, n = rng.randint(1, 8), rng.choice([4, 16, 64])
+        m = rng.randint(0, 3 * n)
+        copies = []
+        for _ in range(m):
+            a, b = (rng.randrange(cols), rng.randrange(n)), (rng.randrange(cols), rng.randrange(n))
+            if rng.random() < 0.05:
+                b = a  # constrain_equal of a cell with itself
+            if copies and rng.random() < 0.1:
+                a, b = copies[rng.randrange(len(copies))]  # a repeated constraint
+            copies.append((a, b))
+        ref = P.Assembly(cols, n)
+        for a, b in copies:
+            ref.copy(a, b)
+        want = sorted((c, r) + ref.mapping[c][r] for c in range(cols) for r in range(n) if ref.mapping[c][r] != (c, r))
+        flat = np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], dtype=np.uint32).reshape(-1, 4)
+        out = np.zeros((2 * max(m, 1), 4), dtype=np.uint32)
+        k = L.h2t_assembly(flat.ctypes.data, m, out.ctypes.data)
+        assert [tuple(int(v) for v in row) for row in out[:k]] == want, trial
+    # the blinding stream: seed, count, start
+    for seed, count, start in ((1, 7, 0), (78, 18, 5), (0xFFFF_FFFF, 33, 1 << 20)):
+        got = np.zeros((count, 4), dtype=np.uint64)
+        L.h2t_uniform_fr(seed, count, start, got.ctypes.data)
+        assert np.array_equal(got, o.random_field_limbs(count, seed, start=start))
+    # batch_normalize: random Jacobian representatives, the identity in the middle and at the ends
+    pts = [None, o.g1_mul(5, o.G1_GEN), None, o.g1_mul(o.R - 1, o.G1_GEN), o.g1_mul(123456789, o.G1_GEN), None]
+    jac = np.stack([o.pack_jacobian(p, z=rng.randrange(2, o.Q)) if p is not None else o.pack_jacobian(None) for p in pts])
+    aff = np.zeros((len(pts), 8), dtype=np.uint64)
+    L.h2t_normalize(np.ascontiguousarray(jac).ctypes.data, len(pts), aff.ctypes.data)
+    assert o.unpack_points(aff) == pts
+    # Fr's Ord is by canonical value, not by the Montgomery limbs
+    vals = [0, 1, 2, o.R - 1, o.R // 2, 1 << 200, rng.randrange(o.R), rng.randrange(o.R)]
+    lim = o.pack(vals, o.R)
+    for i, a in enumerate(vals):
+        for j, b in enumerate(vals):
+            assert L.h2t_canonical_less(lim[i].ctypes.data, lim[j].ctypes.data) == (1 if a < b else 0)
