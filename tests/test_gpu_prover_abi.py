@@ -252,3 +252,51 @@ def test_keys_and_provers_release_their_device_memory(gpu):
     gpu._lib.check(gpu.lib.h2mi_sync(), "sync")
     assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # the runtime's own pools may move by a few MB
     params.release()
+
+
+def test_two_provers_from_two_host_threads(gpu):
+    """two prover objects (one per shape: StandardPlonk at 2^12 and the Range builder at 2^11) driven at the same time from two host
+    threads — ctypes releases the GIL inside every phase call, so the phases of the two proofs really interleave on the library's
+    streams, scratch vectors, table caches and MSM pipeline (calls may arrive concurrently).  Every proof must be the
+    one the same prover makes alone."""
+    import threading
+
+    from halo2_scaffold_amd import circuits, flex, keygen, prover
+
+    p1 = gpu.ParamsKZG.setup(12, 0x5EC2E7)
+    c = circuits.StandardPlonk(None)
+    pk = keygen.keygen_pk(p1, keygen.keygen_vk(p1, c), c)
+    ws1 = prover.ProverWorkspace(p1, pk)
+    p2 = gpu.ParamsKZG.setup(11, 0x5EC2E7)
+    cs = flex.FlexGateCS(lookup=True)
+    asgs = [flex.range_closure(cs, 0x1234567 + i, 6) for i in range(6)]
+    keys = flex.FlexKeys(p2, cs, asgs[0])
+    ws2 = flex.FlexWorkspace(p2, keys)
+    alone1 = [prover.create_proof(p1, pk, circuits.StandardPlonk(100 + i), 7 + i, ws=ws1) for i in range(6)]
+    alone2 = [flex.create_proof(p2, keys, asgs[i], 70 + i, ws=ws2) for i in range(6)]
+    got1, got2, errors = [], [], []
+
+    def run1():
+        try:
+            for rep in range(3):
+                for i in range(6):
+                    got1.append(prover.create_proof(p1, pk, circuits.StandardPlonk(100 + i), 7 + i, ws=ws1))
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    def run2():
+        try:
+            for rep in range(3):
+                for i in range(6):
+                    got2.append(flex.create_proof(p2, keys, asgs[i], 70 + i, ws=ws2))
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    t1, t2 = threading.Thread(target=run1), threading.Thread(target=run2)
+    t1.start(); t2.start()
+    t1.join(300); t2.join(300)
+    assert not t1.is_alive() and not t2.is_alive() and not errors, errors
+    assert got1 == alone1 * 3 and got2 == alone2 * 3
+    ws1.release(); ws2.release()
+    pk.release(); keys.release()
+    p1.release(); p2.release()
