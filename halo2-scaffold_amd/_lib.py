@@ -76,6 +76,7 @@ def _load():
         "h2mi_fr_fill_dev": ([vp, sz, vp, vp], C.c_int),
         "h2mi_fr_mul_dev": ([vp, vp, sz, vp, vp], C.c_int),
         "h2mi_fr_random_dev": ([vp, sz, C.c_uint64, C.c_uint64, vp], C.c_int),
+        "h2mi_fr_random_chacha_dev": ([vp, sz, vp, C.c_uint64, C.c_uint64, vp], C.c_int),
         "h2mi_ntt_bn254_fr": ([vp, vp, C.c_uint32], C.c_int),
         "h2mi_ntt_ext_bn254_fr": ([vp, C.c_uint32, vp, vp, vp], C.c_int),
         "h2mi_ntt_bn254_fr_dev": ([vp, C.c_uint32, vp, vp, vp, vp], C.c_int),
@@ -113,6 +114,7 @@ def _load():
         "h2mi_prover_create": ([vp, C.c_uint64, C.c_uint64, sz, sz, C.POINTER(vp)], C.c_int),
         "h2mi_prover_destroy": ([vp], C.c_int),
         "h2mi_prover_set_combiner": ([vp, vp, vp, vp, vp], C.c_int),
+        "h2mi_prover_set_rng_key": ([vp, vp], C.c_int),
         "h2mi_prover_get_counts": ([vp, vp], C.c_int),
         "h2mi_prover_advice": ([vp, vp, vp, sz, C.c_uint64, vp], C.c_int),
         "h2mi_prover_lookups": ([vp, vp, vp], C.c_int),

@@ -161,6 +161,41 @@ inline std::vector<Fr> uniform_fr(uint64_t seed, size_t count, uint64_t start = 
   return v;
 }
 
+// the same blinding sweep from a 256-bit key: element i of stream `stream` = Fr::from_u512 of ChaCha20 block i (RFC 7539 block function;
+// 64-bit block counter, 64-bit stream id: rand_chacha's layout) — what h2mi_fr_random_chacha_dev produces on the device
+inline void chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+  const uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                           (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t x[16];
+  for (int j = 0; j < 16; j++) x[j] = st[j];
+  auto rotl = [](uint32_t v, int c) { return (v << c) | (v >> (32 - c)); };
+  auto qr = [&](int a, int b, int c, int d) {
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+  };
+  for (int r = 0; r < 10; r++) {
+    qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+    qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+  }
+  for (int j = 0; j < 16; j++) out[j] = x[j] + st[j];
+}
+inline std::vector<Fr> chacha_fr(const uint8_t key[32], uint64_t stream, size_t count, uint64_t start = 0) {
+  uint32_t kw[8];
+  std::memcpy(kw, key, 32);
+  std::vector<Fr> v(count);
+  for (size_t i = 0; i < count; i++) {
+    uint32_t b[16];
+    chacha20_block(kw, start + i, stream, b);
+    Fr lo, hi;
+    std::memcpy(lo.l, b, 32);
+    std::memcpy(hi.l, b + 8, 32);
+    v[i] = fr::add(fr::mul(lo, fr::R2), fr::mul(fr::mul(hi, fr::R2), fr::R2));  // from_u512
+  }
+  return v;
+}
+
 // plonk/permutation/keygen.rs Assembly: cycles merged smaller-into-larger, then the two mapping entries swapped.  Cells are
 // (column within the permutation argument, row); identity entries are not stored, so the cost follows the number of constrained
 // cells, not n.

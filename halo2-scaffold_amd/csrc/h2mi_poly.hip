@@ -309,6 +309,43 @@ __global__ void __launch_bounds__(256) k_fr_random(fe* out, size_t n, uint64_t s
   fe_store(&out[i], fe_reduce_once<Fr>(x));
 }
 
+// ---- the same sweep from a 256-bit key: element i of stream `stream` = Fr::from_u512 of ChaCha20 block i (RFC 7539 block function,
+// 64-bit block counter in words 12 - 13, 64-bit stream id in words 14 - 15: the layout of rand_chacha's ChaCha20Rng, whose eight
+// next_u64 per Fr::random are exactly one block [RECALL halo2curves: Fr::random = from_u512 of eight next_u64]) --------------------
+struct ChaChaKey {
+  uint32_t w[8];
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+#define H2_QR(a, b, c, d)                        \
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);  \
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);  \
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);   \
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7)
+__global__ void __launch_bounds__(256) k_fr_random_chacha(fe* out, size_t n, ChaChaKey key, uint64_t stream, uint64_t start) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ctr = start + i;
+  uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6],
+                     key.w[7], (uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t x[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = st[j];
+  for (int r = 0; r < 10; r++) {
+    H2_QR(0, 4, 8, 12); H2_QR(1, 5, 9, 13); H2_QR(2, 6, 10, 14); H2_QR(3, 7, 11, 15);
+    H2_QR(0, 5, 10, 15); H2_QR(1, 6, 11, 12); H2_QR(2, 7, 8, 13); H2_QR(3, 4, 9, 14);
+  }
+  fe lo, hi;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    lo.v[j] = x[j] + st[j];
+    hi.v[j] = x[8 + j] + st[8 + j];
+  }
+  // from_u512: (lo + hi 2^256) mod r, in Montgomery form: lo R + hi R^2 (Montgomery products accept an unreduced 256-bit operand)
+  const fe r2 = fe_const<Fr>(Fr::R2);
+  fe_store(&out[i], fe_add<Fr>(fe_mul<Fr>(lo, r2), fe_mul<Fr>(fe_mul<Fr>(hi, r2), r2)));
+}
+#undef H2_QR
+
 }  // namespace h2
 
 using namespace h2;
@@ -572,6 +609,17 @@ int h2mi_fr_random_dev(void* d_out, size_t n, uint64_t seed, uint64_t start, h2m
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   hipStream_t s = pick_stream(stream);
   H2_LAUNCH("k_fr_random", k_fr_random, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, seed, start);
+  return H2MI_OK;
+}
+
+int h2mi_fr_random_chacha_dev(void* d_out, size_t n, const uint8_t key[32], uint64_t stream_id, uint64_t start, h2mi_stream_t stream) {
+  H2_REQUIRE_INIT();
+  if (!d_out || n == 0 || !key) return H2MI_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  hipStream_t s = pick_stream(stream);
+  ChaChaKey k;
+  memcpy(k.w, key, 32);  // little-endian words, as RFC 7539 reads the key
+  H2_LAUNCH("k_fr_random_chacha", k_fr_random_chacha, ceil_div_u32(n, 256), 256, 0, s, (fe*)d_out, n, k, stream_id, start);
   return H2MI_OK;
 }
 

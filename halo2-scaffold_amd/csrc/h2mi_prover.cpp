@@ -454,6 +454,10 @@ struct h2mi_prover_s {
   h2mi_stream_t lane[2] = {nullptr, nullptr}, side = nullptr;
   // state of the proof in flight
   Phase phase = IDLE;
+  // blinding source: counter-based SplitMix64 streams of `seed` (reproducible; tests, benchmarks, the goldens), or — once a key is
+  // set — ChaCha20 blocks under a 256-bit key, one block per scalar as Fr::random draws them, `seed` the per-proof nonce
+  bool keyed = false;
+  uint8_t key[32] = {0};
   uint64_t seed = 0;
   std::vector<Fr> instance_vals;
   bool advice_sparse = true;
@@ -502,6 +506,15 @@ struct h2mi_prover_s {
     std::memcpy(out, aff.data(), k * 64);
   }
   void forms(Forms& f, h2mi_stream_t stream) { to_poly_and_coset(pk->domain, *f.value, *f.poly, *f.coset, stream); }
+  // `count` blinding scalars for purpose 1 .. 5 (advice rows, permutation products, the random polynomial, permuted lookup columns,
+  // lookup products): the streams seed + purpose of the seeded generator, or ChaCha20 stream id (nonce << 3 | purpose) under the key
+  std::vector<Fr> blinding(uint32_t purpose, size_t count) const {
+    return keyed ? chacha_fr(key, (seed << 3) | purpose, count) : uniform_fr(seed + purpose, count);
+  }
+  void random_vector(uint32_t purpose, DeviceVec& out, size_t count) const {
+    if (keyed) check(h2mi_fr_random_chacha_dev(out.p, count, key, (seed << 3) | purpose, 0, nullptr), "random_poly");
+    else check(h2mi_fr_random_dev(out.p, count, seed + purpose, 0, nullptr), "random_poly");
+  }
 };
 
 namespace {
@@ -567,7 +580,7 @@ void phase_advice(h2mi_prover_s& p, const h2mi_column_cells* advice, const uint6
   const size_t n = pk.n;
   const uint32_t bf = cs.blinding_factors, u = pk.u, na = cs.n_advice;
   p.phase = IDLE;
-  if (seed >> 32) throw Error(H2MI_EINVAL, "seed must be below 2^32");
+  if (seed >> (p.keyed ? 61 : 32)) throw Error(H2MI_EINVAL, p.keyed ? "nonce must be below 2^61" : "seed must be below 2^32");
   if (n_inst && (!cs.n_instance || !instance)) throw Error(H2MI_EINVAL, "public inputs without an instance column");
   if (n_inst > u) throw Error(H2MI_ERANGE, "more public inputs than usable rows");
   p.seed = seed;
@@ -580,7 +593,7 @@ void phase_advice(h2mi_prover_s& p, const h2mi_column_cells* advice, const uint6
   }
   // witness cells + blinding rows.  Assigned cells and blinding rows of every column travel in ONE launch's arguments when the
   // columns are short (h2mi_fr_patch_cells_dev) instead of a dozen 32-byte copies in front of the phase's commitments
-  const std::vector<Fr> blind = uniform_fr(seed + 1, (size_t)na * (bf + 1));
+  const std::vector<Fr> blind = p.blinding(1, (size_t)na * (bf + 1));
   size_t assigned = 0;
   for (uint32_t j = 0; j < na; j++) {
     DeviceVec& colv = *p.advice[j].value;
@@ -624,7 +637,7 @@ void phase_lookups(h2mi_prover_s& p, uint64_t* points_out) {
   require_phase(p, ADVICE);
   p.phase = IDLE;
   if (L) {
-    const std::vector<Fr> lb = uniform_fr(p.seed + 4, (size_t)2 * (bf + 1) * L);
+    const std::vector<Fr> lb = p.blinding(4, (size_t)2 * (bf + 1) * L);
     PatchList pl;
     std::vector<const void*> cols;
     for (uint32_t l = 0; l < L; l++) {
@@ -670,7 +683,7 @@ void phase_products(h2mi_prover_s& p, const Fr& beta, const Fr& gamma, uint64_t*
   p.gamma = gamma;
   // the random polynomial's commitment is written after the grand products' but depends on nothing: queued first, the one dense
   // MSM of this phase accumulates beside their latency-bound scans.  Result slot: where the transcript expects it.
-  check(h2mi_fr_random_dev(p.random_poly->p, n, p.seed + 3, 0, nullptr), "random_poly");
+  p.random_vector(3, *p.random_poly, n);
   p.commit(false, p.col(*p.random_poly), n_sets + L);
   // permutation argument: every set in one device pass, over the copy constraints' support when that is sparse
   const bool perm_sparse = (uint64_t)pk.n_active * 8 <= (uint64_t)n_sets * u;
@@ -695,7 +708,7 @@ void phase_products(h2mi_prover_s& p, const Fr& beta, const Fr& gamma, uint64_t*
       check(h2mi_plonk_permutation_products_dev(vals.data(), sigs.data(), m, pk.chunk, cs.k, u, beta.l, gamma.l, (const uint64_t*)bd.data(),
                                                 pk.domain.get_omega().l, zptr.data(), nullptr),
             "permutation_products");
-    const std::vector<Fr> zblind = uniform_fr(p.seed + 2, (size_t)n_sets * bf);
+    const std::vector<Fr> zblind = p.blinding(2, (size_t)n_sets * bf);
     PatchList pl;
     for (uint32_t s = 0; s < n_sets; s++)
       for (uint32_t r = 0; r < bf; r++) pl.add(*p.z[s].value, u + 1 + r, zblind[(size_t)s * bf + r]);
@@ -720,7 +733,7 @@ void phase_products(h2mi_prover_s& p, const Fr& beta, const Fr& gamma, uint64_t*
     if (n_sets) p.commit_phase(true, zcols, 0, perm_sparse, false);
     size_t slot = n_sets;
     if (L) {
-      const std::vector<Fr> lzb = uniform_fr(p.seed + 5, (size_t)bf * L);
+      const std::vector<Fr> lzb = p.blinding(5, (size_t)bf * L);
       for (uint32_t l = 0; l < L; l++) {
         DeviceVec& lz = *p.lk[l].z.value;
         check(h2mi_plonk_lookup_product_dev(p.lookup_input(l).p, pk.fixed_values[cs.lookups[l].table_fixed]->p, p.lk[l].a.value->p, p.lk[l].s.value->p, cs.k,
@@ -1206,6 +1219,15 @@ int h2mi_prover_set_combiner(h2mi_prover_t prover, void* d_partial, void* d_comb
   prover->d_combined = d_combined;
   prover->combine = combine;
   prover->combine_ctx = ctx;
+  return H2MI_OK;
+}
+
+int h2mi_prover_set_rng_key(h2mi_prover_t prover, const uint8_t key[32]) {
+  if (!alive(g_live_provers, prover)) return H2MI_EHANDLE;
+  prover->keyed = key != nullptr;
+  if (key) std::memcpy(prover->key, key, 32);
+  else std::memset(prover->key, 0, 32);
+  prover->phase = IDLE;  // a proof in flight would mix two sources
   return H2MI_OK;
 }
 

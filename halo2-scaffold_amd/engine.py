@@ -225,6 +225,13 @@ class Prover:
             self._cb = _COMBINE_FN(_combine)
             check(lib.h2mi_prover_set_combiner(self.handle, combiner.partial_ptr, combiner.combined.ptr, self._cb, None), "set_combiner")
 
+    def set_rng_key(self, key: bytes = None) -> None:
+        """h2mi_prover_set_rng_key: blinding from ChaCha20 under a 256-bit key (the `seed` of later proofs is then the per-proof
+        nonce, below 2^61) instead of the reproducible 32-bit seeded streams; None returns to those"""
+        if key is not None and len(key) != 32:
+            raise ValueError("the key is 32 bytes")
+        check(lib.h2mi_prover_set_rng_key(self.handle, key), "set_rng_key")
+
     def views(self, kind: int, count: int) -> _Views:
         return _Views(lib.h2mi_prover_buffer, self.handle, kind, count)
 

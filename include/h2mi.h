@@ -257,6 +257,10 @@ int h2mi_fr_fill_dev(void* d_out, size_t n, const uint64_t value[4], h2mi_stream
  * so its bytes are not reproducible — SURVEY.md 0).  Counter-based SplitMix64: element i has limbs
  * splitmix64(seed << 32 | 4 (start + i) + j), j = 0..3, top limb masked to 62 bits, reduced once; seed < 2^32. */
 int h2mi_fr_random_dev(void* d_out, size_t n, uint64_t seed, uint64_t start, h2mi_stream_t stream);
+/* the same sweep from a 256-bit key, for proofs that have to hide their witness: element i = Fr::from_u512 of ChaCha20 block start + i
+ * (RFC 7539 block function; 64-bit block counter, 64-bit stream id `stream_id`: the layout of rand_chacha's ChaCha20Rng, whose eight
+ * next_u64 per Fr::random are one block [RECALL halo2curves]); key: 32 bytes, host memory.  h2mi_prover_set_rng_key (h2mi_prover.h) uses it. */
+int h2mi_fr_random_chacha_dev(void* d_out, size_t n, const uint8_t key[32], uint64_t stream_id, uint64_t start, h2mi_stream_t stream);
 
 /* ---- quotient numerator for the reference's StandardPlonk circuit -------------------------
  * halo2_proofs plonk/evaluation.rs `evaluate_h` + vanishing division, specialised to the circuit of reference

@@ -131,6 +131,16 @@ int h2mi_prover_destroy(h2mi_prover_t prover);
 typedef int (*h2mi_combine_fn)(void* ctx, size_t count);
 int h2mi_prover_set_combiner(h2mi_prover_t prover, void* d_partial, void* d_combined, h2mi_combine_fn combine, void* ctx);
 
+/* Where the blinding scalars come from (the crate takes them from its `rng` argument).  Default: counter-based SplitMix64 streams of the
+ * 32-bit `seed` given to h2mi_prover_advice — reproducible, what the goldens and benchmarks use, NOT hiding against anyone who can guess
+ * 32 bits.  With a key: every blinding scalar of the following proofs is Fr::from_u512 of one ChaCha20 block (RFC 7539 block function with
+ * a 64-bit block counter and a 64-bit stream id, the layout of rand_chacha's ChaCha20Rng; one block per scalar, as `Fr::random(rng)`
+ * consumes it) under this 256-bit key: block counter = the scalar's index, stream id = nonce << 3 | purpose (1 advice blinding rows,
+ * 2 permutation products, 3 the vanishing argument's random polynomial, 4 permuted lookup columns, 5 lookup products), nonce = the `seed`
+ * argument of h2mi_prover_advice (then below 2^61: a per-proof counter).  A fork fills the key from its rng once per prover.
+ * key = NULL returns to the seeded streams.  Abandons a proof in flight. */
+int h2mi_prover_set_rng_key(h2mi_prover_t prover, const uint8_t key[32]);
+
 /* ---- the phases, in create_proof's order.  Every phase must be called once per proof, in this order (H2MI_EINVAL otherwise);
  * h2mi_prover_advice starts a new proof at any time.  points_out receive affine points, 8 limbs each, in the order create_proof writes
  * them to the transcript; the identity comes back as (0, 0) (the crate's transcript refuses it).  Each call returns when its points /
@@ -141,7 +151,8 @@ int h2mi_prover_set_combiner(h2mi_prover_t prover, void* d_partial, void* d_comb
  * inputs of the instance column (count values, Montgomery; the caller hashes them into its transcript itself).  seed: stands where the
  * crate takes `rng` — every blinding scalar is drawn from counter-based SplitMix64 streams of this seed (h2mi_fr_random_dev's
  * generator: seed + 1 advice blinding rows, + 2 permutation products, + 3 the vanishing argument's random polynomial, + 4 permuted
- * lookup columns, + 5 lookup products); a fork passes rng.next_u64() >> 32 (seed < 2^32).
+ * lookup columns, + 5 lookup products; seed < 2^32), or — after h2mi_prover_set_rng_key — the per-proof nonce of the keyed ChaCha20
+ * streams (< 2^61).
  * points_out: n_advice commitments. */
 int h2mi_prover_advice(h2mi_prover_t prover, const h2mi_column_cells* advice, const uint64_t* instance, size_t n_instance_values, uint64_t seed,
                        uint64_t* points_out);

@@ -32,6 +32,11 @@ void h2t_normalize(const uint64_t* jac, size_t k, uint64_t* out) {
   const std::vector<h2mi::G1Affine> aff = h2mi::plonk::normalize_host_batch(pts);
   std::memcpy(out, aff.data(), k * 64);
 }
+// the keyed blinding stream (ChaCha20 block per scalar, Fr::from_u512): what h2mi_prover_set_rng_key draws from on the host side
+void h2t_chacha_fr(const uint8_t* key, uint64_t stream, size_t count, uint64_t start, uint64_t* out) {
+  const std::vector<h2mi::Fr> v = h2mi::plonk::chacha_fr(key, stream, count, start);
+  std::memcpy(out, v.data(), count * 32);
+}
 // canonical order of Fr (BTreeSet<Fr> in ProverSHPLONK): 1 when a < b
 int h2t_canonical_less(const uint64_t* a, const uint64_t* b) {
   h2mi::Fr x, y;

@@ -300,3 +300,50 @@ def test_two_provers_from_two_host_threads(gpu):
     ws1.release(); ws2.release()
     pk.release(); keys.release()
     p1.release(); p2.release()
+
+
+def test_keyed_blinding_stream_and_proofs(gpu):
+    """h2mi_fr_random_chacha_dev against an RFC-7539-checked Python ChaCha20 (one block per scalar, Fr::from_u512), and proofs made
+    with h2mi_prover_set_rng_key: accepted by the oracle verifiers (acceptance does not depend on the blinding), reproducible for
+    (key, nonce), different for another nonce or key, with 64-bit nonces allowed; without a key the seeded goldens are untouched."""
+    from oracle import bn254 as o
+    from oracle import prover as OP
+    from test_host import _chacha20_block
+
+    from halo2_scaffold_amd import circuits, keygen, prover
+    from halo2_scaffold_amd.device import DevBuf
+
+    key = bytes((11 * i + 5) & 0xFF for i in range(32))
+    n = 1000
+    d = DevBuf(n * 32)
+    for stream, start in ((3, 0), ((123456789 << 3) | 3, 1 << 34)):
+        assert gpu.lib.h2mi_fr_random_chacha_dev(d.ptr, n, key, stream, start, None) == 0
+        got = o.unpack(d.to_numpy(shape=(n, 4)), o.R)
+        assert got == [int.from_bytes(_chacha20_block(key, start + i, stream), "little") % o.R for i in range(n)]
+    assert gpu.lib.h2mi_fr_random_chacha_dev(d.ptr, n, None, 1, 0, None) == -1
+    d.free()
+    k, S = 8, 0x5EC2E7
+    params = gpu.ParamsKZG.setup(k, S)
+    c = circuits.StandardPlonk(None)
+    pk = keygen.keygen_pk(params, keygen.keygen_vk(params, c), c)
+    ws = prover.ProverWorkspace(params, pk)
+    seeded = prover.create_proof(params, pk, circuits.StandardPlonk(99), 3, ws=ws)
+    ws.prover.set_rng_key(key)
+    big_nonce = (1 << 60) + 12345
+    a = prover.create_proof(params, pk, circuits.StandardPlonk(99), big_nonce, ws=ws)
+    b = prover.create_proof(params, pk, circuits.StandardPlonk(99), big_nonce, ws=ws)
+    other_nonce = prover.create_proof(params, pk, circuits.StandardPlonk(99), big_nonce + 1, ws=ws)
+    ws.prover.set_rng_key(bytes(32))
+    other_key = prover.create_proof(params, pk, circuits.StandardPlonk(99), big_nonce, ws=ws)
+    vkey = OP.VerifierKey.closed_form(k, S)
+    assert a == b and len({seeded, a, other_nonce, other_key}) == 4
+    assert all(OP.verify_proof(vkey, p) for p in (seeded, a, other_nonce, other_key))
+    with pytest.raises(gpu.H2miError):
+        prover.create_proof(params, pk, circuits.StandardPlonk(99), 1 << 61, ws=ws)  # the nonce has 61 bits
+    ws.prover.set_rng_key(None)
+    assert prover.create_proof(params, pk, circuits.StandardPlonk(99), 3, ws=ws) == seeded
+    with pytest.raises(gpu.H2miError):
+        prover.create_proof(params, pk, circuits.StandardPlonk(99), 1 << 32, ws=ws)  # seeded streams: 32 bits
+    ws.release()
+    pk.release()
+    params.release()

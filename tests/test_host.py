@@ -373,6 +373,31 @@ def test_cpp_host_single_element_inversion_matches_pow():
         assert o.unpack(fast, mod) == [0] + [pow(v, -1, mod) for v in vals[:3000]]
 
 
+def _chacha20_block(key: bytes, counter: int, stream: int, ctr32_nonce96: bytes = None) -> bytes:
+    """one 64-byte ChaCha20 block, written from RFC 7539 2.3: 64-bit block counter + 64-bit stream id in words 12 .. 15 (the layout
+    rand_chacha uses), or — for the RFC's own test vector — a 32-bit counter and a 96-bit nonce"""
+    M = 0xFFFFFFFF
+    kw = [int.from_bytes(key[4 * i : 4 * i + 4], "little") for i in range(8)]
+    if ctr32_nonce96 is not None:
+        tail = [counter & M] + [int.from_bytes(ctr32_nonce96[4 * i : 4 * i + 4], "little") for i in range(3)]
+    else:
+        tail = [counter & M, (counter >> 32) & M, stream & M, (stream >> 32) & M]
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + kw + tail
+    x = list(st)
+    rotl = lambda v, c: ((v << c) & M) | (v >> (32 - c))
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return b"".join(((a + b) & M).to_bytes(4, "little") for a, b in zip(x, st))
+
+
 def test_prover_host_helpers_match_oracle():
     """what csrc/h2mi_prover.cpp computes on the CPU around its kernels (csrc/h2mi_hostmath.hpp), without a GPU: the copy
     constraints' cycle structure (permutation/keygen.rs Assembly::copy: merge the smaller cycle into the larger, swap two mapping
@@ -419,6 +444,15 @@ def test_prover_host_helpers_match_oracle():
         got = np.zeros((count, 4), dtype=np.uint64)
         L.h2t_uniform_fr(seed, count, start, got.ctypes.data)
         assert np.array_equal(got, o.random_field_limbs(count, seed, start=start))
+    # the keyed stream: ChaCha20 (checked here against the RFC 7539 2.3.2 block vector) one block per scalar, Fr::from_u512
+    ks = _chacha20_block(bytes(range(32)), 1, int.from_bytes(bytes([0, 0, 0, 9, 0, 0, 0, 0x4A, 0, 0, 0, 0])[4:], "little"), ctr32_nonce96=bytes([0, 0, 0, 9, 0, 0, 0, 0x4A, 0, 0, 0, 0]))
+    assert ks.hex().startswith("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e")
+    L.h2t_chacha_fr.argtypes = [C.c_char_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_void_p]
+    key = bytes((7 * i + 3) & 0xFF for i in range(32))
+    for stream, count, start in ((1, 9, 0), ((5 << 3) | 3, 40, 1 << 33), ((1 << 63) + 5, 3, 7)):
+        got = np.zeros((count, 4), dtype=np.uint64)
+        L.h2t_chacha_fr(key, stream, count, start, got.ctypes.data)
+        assert o.unpack(got, o.R) == [int.from_bytes(_chacha20_block(key, start + i, stream), "little") % o.R for i in range(count)]
     # batch_normalize: random Jacobian representatives, the identity in the middle and at the ends
     pts = [None, o.g1_mul(5, o.G1_GEN), None, o.g1_mul(o.R - 1, o.G1_GEN), o.g1_mul(123456789, o.G1_GEN), None]
     jac = np.stack([o.pack_jacobian(p, z=rng.randrange(2, o.Q)) if p is not None else o.pack_jacobian(None) for p in pts])
