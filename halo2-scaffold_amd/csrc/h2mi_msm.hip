@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
 // (blockIdx.y = MSM; round 4).  At 2^16 rows and below a prover phase's three or four commitments were issued at the HOST's pace: eight
 // launches and six event operations per MSM, ~77 us each on the compiled host, while the kernels themselves run 4 - 13 us (proof
 // timeline at 2^16: the three z commitments' partitions occupy 270 us of the phase one after the other).  The kernels are the
-// single-MSM bodies behind a descriptor; h2mi_msm_bn254_g1_batch_dev chooses this form up to HEAD_BATCH_MAX_N points — beyond, the
+// single-MSM bodies behind a descriptor; h2mi_msm_bn254_g1_phase_dev chooses this form up to HEAD_BATCH_MAX_N points — beyond, the
 // stage-by-stage pipelining of consecutive MSMs (partition of one beside the accumulation of another) is worth more than the launches.
 constexpr uint32_t HEAD_BATCH = 4;
 struct HeadDesc {
@@ -1800,7 +1800,7 @@ static int msm_small_batch(Bases* B, const void* const* d_scalars, size_t m, siz
 }
 
 // `inorder`: partition, accumulation and bucket reduction one after the other on `s`, nothing deferred and no stream hops — for a LONE
-// commitment whose point the caller reads next (h2mi_msm_bn254_g1_inorder_dev): the three-stream split buys overlap between consecutive
+// commitment whose point the caller reads next (h2mi_msm_bn254_g1_phase_dev with H2MI_MSM_INORDER): the three-stream split buys overlap between consecutive
 // MSMs and costs a lone one ~50 us of event hops (2^20: 1645 -> 1580 us, 2^16: 386 -> 336)
 static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipStream_t s, bool inorder, bool general) {
   B->last_small = take_small(B, general);
@@ -2001,7 +2001,7 @@ static int msm_small(Bases* B, const void* d_scalars, size_t n, void* d_out, hip
     if (rc) return rc;
   }
   // slot reuse: the digit bytes and partial sums are read by the slot's previous accumulate / final pair — and a slot last
-  // used by the general pipeline (h2mi_dbg_msm_small_path) still owes its head / accumulation events
+  // used by the general pipeline (H2MI_MSM_GENERAL, or the streaming rule of take_small) still owes its head / accumulation events
   if (S.tail_ever && (S.tail_pending || !pipelined || S.last_stream != s)) H2_HIP(hipStreamWaitEvent(s, S.tail_done, 0));
   if (S.head_pending) H2_HIP(hipStreamWaitEvent(s, S.head_done, 0));
   if (S.accum_pending) H2_HIP(hipStreamWaitEvent(s, S.accum_done, 0));
