@@ -1,0 +1,245 @@
+//! StandardPlonk at k = 5 (the reference's own example, examples/standard_plonk.rs:26-64) with the PROOF made by libh2mi.so's
+//! resident prover (include/h2mi_prover.h) and everything else — SRS, verifying key incl. its transcript_repr, transcript,
+//! verifier — the real crates'.  Prints "ACCEPTED" when `verify_proof` accepts the proof.
+//!     H2MI_LIB_DIR=$PWD/../../halo2-scaffold_amd cargo run --release
+//! Compiled by nobody so far (no Rust toolchain where this repository is built); written against halo2_proofs v2023_02_02.
+use halo2_proofs::{
+    circuit::Value,
+    halo2curves::{
+        bn256::{Bn256, Fr, G1Affine},
+        group::Curve,
+    },
+    plonk::{keygen_vk, verify_proof},
+    poly::{
+        commitment::{Blind, ParamsProver},
+        kzg::{
+            commitment::{KZGCommitmentScheme, ParamsKZG},
+            multiopen::VerifierSHPLONK,
+            strategy::SingleStrategy,
+        },
+        EvaluationDomain,
+    },
+    transcript::{
+        Blake2bRead, Blake2bWrite, Challenge255, EncodedChallenge, Transcript, TranscriptReadBuffer, TranscriptWrite, TranscriptWriterBuffer,
+    },
+};
+use halo2_scaffold::circuits::standard_plonk::StandardPlonk;
+use rand::SeedableRng;
+use rand_chacha::ChaCha20Rng;
+use std::os::raw::{c_int, c_uint, c_void};
+
+// ---- include/h2mi_prover.h, transcribed ------------------------------------------------------------------------------------------
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct Column {
+    kind: u32,
+    index: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct Query {
+    column: u32,
+    rotation: i32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct Lookup {
+    input: Column,
+    selector_fixed: i32,
+    table_fixed: u32,
+}
+#[repr(C)]
+struct ConstraintSystem {
+    k: u32,
+    n_advice: u32,
+    n_fixed: u32,
+    n_instance: u32,
+    degree: u32,
+    blinding_factors: u32,
+    gates: u32,
+    n_gates: u32,
+    gate_advice: [u32; 4],
+    gate_selector: [u32; 4],
+    n_perm: u32,
+    perm_columns: [Column; 8],
+    n_lookups: u32,
+    lookups: [Lookup; 2],
+    n_advice_queries: u32,
+    n_fixed_queries: u32,
+    advice_queries: [Query; 24],
+    fixed_queries: [Query; 24],
+}
+#[repr(C)]
+struct ColumnCells {
+    rows: *const u32,
+    values: *const u64,
+    count: usize,
+    flags: u32,
+}
+#[repr(C)]
+#[derive(Default)]
+struct Counts {
+    advice: u32,
+    lookups: u32,
+    products: u32,
+    quotient: u32,
+    evaluations: u32,
+}
+extern "C" {
+    fn h2mi_init(device: c_int) -> c_int;
+    fn h2mi_bases_register(bases: *const u64, n: usize, handle_out: *mut u64) -> c_int;
+    fn h2mi_prover_keygen(cs: *const ConstraintSystem, g_lagrange: u64, fixed: *const ColumnCells, copies: *const u32, n_copies: usize, flags: c_uint,
+                          pk_out: *mut *mut c_void) -> c_int;
+    fn h2mi_prover_vk_commitments(pk: *mut c_void, fixed_out: *mut u64, permutation_out: *mut u64) -> c_int;
+    fn h2mi_prover_create(pk: *mut c_void, g: u64, g_lagrange: u64, lo: usize, count: usize, prover_out: *mut *mut c_void) -> c_int;
+    fn h2mi_prover_set_rng_key(prover: *mut c_void, key: *const u8) -> c_int;
+    fn h2mi_prover_get_counts(prover: *mut c_void, out: *mut Counts) -> c_int;
+    fn h2mi_prover_advice(prover: *mut c_void, advice: *const ColumnCells, instance: *const u64, n_inst: usize, seed: u64, points_out: *mut u64) -> c_int;
+    fn h2mi_prover_products(prover: *mut c_void, beta: *const u64, gamma: *const u64, points_out: *mut u64) -> c_int;
+    fn h2mi_prover_quotient(prover: *mut c_void, y: *const u64, points_out: *mut u64) -> c_int;
+    fn h2mi_prover_evaluations(prover: *mut c_void, x: *const u64, evals_out: *mut u64) -> c_int;
+    fn h2mi_prover_shplonk_quotient(prover: *mut c_void, y: *const u64, v: *const u64, point_out: *mut u64) -> c_int;
+    fn h2mi_prover_shplonk_open(prover: *mut c_void, u: *const u64, point_out: *mut u64) -> c_int;
+}
+fn check(rc: c_int, what: &str) {
+    assert_eq!(rc, 0, "{} failed with code {}", what, rc);
+}
+fn limbs(x: &Fr) -> *const u64 {
+    x as *const Fr as *const u64 // Fr is four u64 Montgomery limbs in memory (interop/probe confirms)
+}
+
+fn main() {
+    let k = 5u32;
+    let n = 1usize << k;
+    // the scaffold's SRS (gen_srs: src/scaffold.rs:119,174,271) and the crate's verifying key
+    let params = ParamsKZG::<Bn256>::setup(k, ChaCha20Rng::from_seed(Default::default()));
+    let vk = keygen_vk(&params, &StandardPlonk { x: Value::<Fr>::unknown() }).expect("vk should not fail");
+
+    // the SRS into HBM: g as it is; g_lagrange recovered through commit_lagrange of the unit vectors (the field is crate-private)
+    check(unsafe { h2mi_init(0) }, "h2mi_init");
+    let g: Vec<G1Affine> = params.get_g().to_vec();
+    let domain = EvaluationDomain::<Fr>::new(3, k);
+    let g_lagrange: Vec<G1Affine> = (0..n)
+        .map(|i| {
+            let mut e = vec![Fr::zero(); n];
+            e[i] = Fr::one();
+            params.commit_lagrange(&domain.lagrange_from_vec(e), Blind::default()).to_affine()
+        })
+        .collect();
+    let (mut hg, mut hgl) = (0u64, 0u64);
+    check(unsafe { h2mi_bases_register(g.as_ptr() as *const u64, n, &mut hg) }, "register g");
+    check(unsafe { h2mi_bases_register(g_lagrange.as_ptr() as *const u64, n, &mut hgl) }, "register g_lagrange");
+
+    // StandardPlonkConfig::configure as numbers (src/circuits/standard_plonk.rs:29-48) ...
+    let mut cs: ConstraintSystem = unsafe { std::mem::zeroed() };
+    cs.k = k;
+    cs.n_advice = 3;
+    cs.n_fixed = 5;
+    cs.degree = 3;
+    cs.blinding_factors = 5;
+    cs.gates = 1; // H2MI_GATES_STANDARD_PLONK
+    cs.n_perm = 3;
+    for j in 0..3 {
+        cs.perm_columns[j] = Column { kind: 0, index: j as u32 };
+        cs.advice_queries[j] = Query { column: j as u32, rotation: 0 };
+    }
+    cs.n_advice_queries = 3;
+    cs.n_fixed_queries = 5;
+    for j in 0..5 {
+        cs.fixed_queries[j] = Query { column: j as u32, rotation: 0 };
+    }
+    // ... and what StandardPlonk::synthesize assigns (:79-112): fixed cells q_c = -1, q_ab = 1 on rows 1 and 2, constant = 72 on row 2;
+    // x's copies into a and b of rows 1 and 2, each constrain_equal(new cell, (a, 0))
+    let (one, minus_one, c72) = (Fr::one(), -Fr::one(), Fr::from(72));
+    let rows12 = [1u32, 2u32];
+    let row2 = [2u32];
+    let qc = [minus_one, minus_one];
+    let qab = [one, one];
+    let cst = [c72];
+    let empty = ColumnCells { rows: std::ptr::null(), values: std::ptr::null(), count: 0, flags: 0 };
+    let fixed = [
+        ColumnCells { ..unsafe { std::ptr::read(&empty) } },
+        ColumnCells { ..unsafe { std::ptr::read(&empty) } },
+        ColumnCells { rows: rows12.as_ptr(), values: qc.as_ptr() as *const u64, count: 2, flags: 0 },
+        ColumnCells { rows: rows12.as_ptr(), values: qab.as_ptr() as *const u64, count: 2, flags: 0 },
+        ColumnCells { rows: row2.as_ptr(), values: cst.as_ptr() as *const u64, count: 1, flags: 0 },
+    ];
+    let copies: [[u32; 4]; 4] = [[0, 1, 0, 0], [1, 1, 0, 0], [0, 2, 0, 0], [1, 2, 0, 0]];
+    let mut pk: *mut c_void = std::ptr::null_mut();
+    check(unsafe { h2mi_prover_keygen(&cs, hgl, fixed.as_ptr(), copies.as_ptr() as *const u32, copies.len(), 0, &mut pk) }, "keygen");
+    // the library's keygen against the crate's: the eight commitments of the verifying key
+    let mut fc = [G1Affine::default(); 5];
+    let mut pc = [G1Affine::default(); 3];
+    check(unsafe { h2mi_prover_vk_commitments(pk, fc.as_mut_ptr() as *mut u64, pc.as_mut_ptr() as *mut u64) }, "vk commitments");
+    assert_eq!(&fc[..], &vk.fixed_commitments()[..], "fixed commitments differ from keygen_vk's");
+    assert_eq!(&pc[..], &vk.permutation().commitments()[..], "permutation commitments differ from keygen_vk's");
+    println!("vk commitments equal the crate's");
+
+    // the proof: witness x = 0xc0ffee on rows 0..2 of a and b, x^2 and x^2 + 72 in c
+    let x = Fr::from(0xc0ffee);
+    let a = [x, x, x];
+    let b = [x, x];
+    let c = [x * x, x * x + c72];
+    let advice = [
+        ColumnCells { rows: std::ptr::null(), values: a.as_ptr() as *const u64, count: 3, flags: 0 },
+        ColumnCells { rows: rows12.as_ptr(), values: b.as_ptr() as *const u64, count: 2, flags: 0 },
+        ColumnCells { rows: rows12.as_ptr(), values: c.as_ptr() as *const u64, count: 2, flags: 0 },
+    ];
+    let mut prover: *mut c_void = std::ptr::null_mut();
+    check(unsafe { h2mi_prover_create(pk, hg, hgl, 0, n, &mut prover) }, "prover_create");
+    let key = [0x42u8; 32]; // a real caller fills this from its rng
+    check(unsafe { h2mi_prover_set_rng_key(prover, key.as_ptr()) }, "set_rng_key");
+    let mut counts = Counts::default();
+    check(unsafe { h2mi_prover_get_counts(prover, &mut counts) }, "counts");
+
+    let mut transcript = Blake2bWrite::<_, G1Affine, Challenge255<_>>::init(vec![]);
+    vk.hash_into(&mut transcript).expect("hash_into"); // the crate's own transcript_repr
+    let mut pts = [G1Affine::default(); 8];
+    let p = pts.as_mut_ptr() as *mut u64;
+    check(unsafe { h2mi_prover_advice(prover, advice.as_ptr(), std::ptr::null(), 0, 1, p) }, "advice");
+    for q in &pts[..counts.advice as usize] {
+        transcript.write_point(*q).unwrap();
+    }
+    let _theta: Fr = transcript.squeeze_challenge().get_scalar(); // drawn even without lookups
+    let beta: Fr = transcript.squeeze_challenge().get_scalar();
+    let gamma: Fr = transcript.squeeze_challenge().get_scalar();
+    check(unsafe { h2mi_prover_products(prover, limbs(&beta), limbs(&gamma), p) }, "products");
+    for q in &pts[..counts.products as usize] {
+        transcript.write_point(*q).unwrap();
+    }
+    let y: Fr = transcript.squeeze_challenge().get_scalar();
+    check(unsafe { h2mi_prover_quotient(prover, limbs(&y), p) }, "quotient");
+    for q in &pts[..counts.quotient as usize] {
+        transcript.write_point(*q).unwrap();
+    }
+    let xc: Fr = transcript.squeeze_challenge().get_scalar();
+    let mut evals = vec![Fr::zero(); counts.evaluations as usize];
+    check(unsafe { h2mi_prover_evaluations(prover, limbs(&xc), evals.as_mut_ptr() as *mut u64) }, "evaluations");
+    for e in &evals {
+        transcript.write_scalar(*e).unwrap();
+    }
+    let sy: Fr = transcript.squeeze_challenge().get_scalar();
+    let sv: Fr = transcript.squeeze_challenge().get_scalar();
+    check(unsafe { h2mi_prover_shplonk_quotient(prover, limbs(&sy), limbs(&sv), p) }, "shplonk quotient");
+    transcript.write_point(pts[0]).unwrap();
+    let su: Fr = transcript.squeeze_challenge().get_scalar();
+    check(unsafe { h2mi_prover_shplonk_open(prover, limbs(&su), p) }, "shplonk open");
+    transcript.write_point(pts[0]).unwrap();
+    let proof = transcript.finalize();
+    println!("proof: {} bytes", proof.len());
+
+    // the crate's verifier (examples/standard_plonk.rs:53-65)
+    let verifier_params = params.verifier_params();
+    let strategy = SingleStrategy::new(&params);
+    let mut reader = Blake2bRead::<_, _, Challenge255<_>>::init(&proof[..]);
+    let ok = verify_proof::<KZGCommitmentScheme<Bn256>, VerifierSHPLONK<'_, Bn256>, Challenge255<G1Affine>, Blake2bRead<&[u8], G1Affine, Challenge255<G1Affine>>, SingleStrategy<'_, Bn256>>(
+        verifier_params,
+        &vk,
+        strategy,
+        &[&[]],
+        &mut reader,
+    )
+    .is_ok();
+    println!("{}", if ok { "ACCEPTED by halo2_proofs::plonk::verify_proof" } else { "REJECTED by halo2_proofs::plonk::verify_proof" });
+    std::process::exit(if ok { 0 } else { 1 });
+}
