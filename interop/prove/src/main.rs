@@ -156,10 +156,10 @@ fn main() {
     let qc = [minus_one, minus_one];
     let qab = [one, one];
     let cst = [c72];
-    let empty = ColumnCells { rows: std::ptr::null(), values: std::ptr::null(), count: 0, flags: 0 };
+    let empty = || ColumnCells { rows: std::ptr::null(), values: std::ptr::null(), count: 0, flags: 0 };
     let fixed = [
-        ColumnCells { ..unsafe { std::ptr::read(&empty) } },
-        ColumnCells { ..unsafe { std::ptr::read(&empty) } },
+        empty(), // q_a
+        empty(), // q_b
         ColumnCells { rows: rows12.as_ptr(), values: qc.as_ptr() as *const u64, count: 2, flags: 0 },
         ColumnCells { rows: rows12.as_ptr(), values: qab.as_ptr() as *const u64, count: 2, flags: 0 },
         ColumnCells { rows: row2.as_ptr(), values: cst.as_ptr() as *const u64, count: 1, flags: 0 },
