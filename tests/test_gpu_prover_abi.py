@@ -347,3 +347,68 @@ def test_keyed_blinding_stream_and_proofs(gpu):
     ws.release()
     pk.release()
     params.release()
+
+
+def test_column_cells_every_upload_path(gpu):
+    """h2mi_column_cells reaches a device column by four routes (csrc/h2mi_prover.cpp fill_column): short runs in a patch launch, long
+    dense runs as one upload, long scattered runs staged over their span, canonical values converted on the host (short / scattered)
+    or on the device (long dense).  Each route, Montgomery and canonical, against the cells that went in — through keygen's fixed
+    columns and through the advice phase."""
+    import ctypes as C
+
+    from halo2_scaffold_amd import engine, flex
+
+    k = 14
+    n = 1 << k
+    params = gpu.ParamsKZG.setup(k, 0x5EC2E7)
+    cs = flex.FlexGateCS(lookup=False).abi(k)  # fixed 0 constants, 1 q_enable; one advice column; one instance column
+    u = n - 7
+    r = gpu.field.FR_MODULUS
+    val = lambda i: pow(3, i + 1, r)
+    scattered = {2 * i + 1: val(i) for i in range(5000)}          # 5000 cells over a span of 10000 rows: staged
+    dense_long = [val(1000 + i) for i in range(6000)]              # rows 0 .. 5999: one upload (+ device conversion when canonical)
+    short = {5: val(7), n - 1: val(8), 77: val(9)}                 # a handful anywhere (fixed columns have no blinding rows)
+
+    def column(view, count=n):
+        return [gpu.field.fr_from_mont_limbs(row) for row in view.to_numpy(shape=(count, 4), nbytes=count * 32)]
+
+    def expect(cells):
+        items = cells.items() if isinstance(cells, dict) else enumerate(cells)
+        col = [0] * n
+        for row, v in items:
+            col[row] = v
+        return col
+
+    # canonical values (what the Python host sends)
+    keys = engine.Keys(cs, params, [scattered, dense_long], [])
+    assert column(keys.views(engine.PKBUF_FIXED, 2)[0]) == expect(scattered)
+    assert column(keys.views(engine.PKBUF_FIXED, 2)[1]) == expect(dense_long)
+    keys.release()
+    keys = engine.Keys(cs, params, [short, {}], [])
+    assert column(keys.views(engine.PKBUF_FIXED, 2)[0]) == expect(short)
+    # Montgomery values (what a Rust / C++ caller sends): the same three routes through the raw structure
+    def mont_cells(cells):
+        items = sorted(cells.items()) if isinstance(cells, dict) else list(enumerate(cells))
+        rows = np.array([row for row, _ in items], dtype=np.uint32)
+        vals = np.ascontiguousarray(np.stack([gpu.field.fr_to_mont_limbs(v) for _, v in items]))
+        dense = not isinstance(cells, dict)
+        cc = engine.ColumnCells(None if dense else rows.ctypes.data, vals.ctypes.data, len(items), 0)
+        return cc, (rows, vals)
+
+    prover = engine.Prover(keys, params)
+    pts = np.zeros((8, 8), dtype=np.uint64)
+    for cells in (scattered, dense_long[:3000], {3: val(1), 9: val(2)}):
+        arr = (engine.ColumnCells * 1)()
+        arr[0], keep = mont_cells(cells)
+        assert gpu.lib.h2mi_prover_advice(prover.handle, arr, None, 0, 1, pts.ctypes.data) == 0
+        got = column(prover.views(engine.BUF_ADVICE, 1)[0], u)
+        assert got == expect(cells)[:u]
+    # a scattered run that reaches into the blinding rows is refused, whatever the route
+    arr = (engine.ColumnCells * 1)()
+    bad = dict(scattered)
+    bad[u] = 1
+    arr[0], keep = mont_cells(bad)
+    assert gpu.lib.h2mi_prover_advice(prover.handle, arr, None, 0, 1, pts.ctypes.data) == -6
+    prover.release()
+    keys.release()
+    params.release()
