@@ -465,3 +465,20 @@ def test_prover_host_helpers_match_oracle():
     for i, a in enumerate(vals):
         for j, b in enumerate(vals):
             assert L.h2t_canonical_less(lim[i].ctypes.data, lim[j].ctypes.data) == (1 if a < b else 0)
+
+
+def test_abi_headers_are_strict_c(tmp_path):
+    """the drop-in boundary is a C ABI: both headers compile as ISO C99 and C11 with -pedantic -Werror (no C++-isms, no torch types),
+    and the plain-C caller of the prover ABI builds against the library (it fails loudly without a GPU)."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "h2mi.h"\n#include "h2mi_prover.h"\nint main(void) { h2mi_constraint_system cs; h2mi_column_cells c; (void)cs; (void)c; '
+                   "return (int)sizeof(h2mi_prover_counts) - 20; }\n")
+    for std in ("c99", "c11"):
+        subprocess.check_call(["gcc", f"-std={std}", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                               "-o", str(tmp_path / "abi.o")])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s", "prover_abi"])
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([os.path.join(ROOT, "examples", "prover_abi"), "5"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr
