@@ -4,8 +4,9 @@
 // HBM; public inputs and proof bytes printed.  The proof bytes are checked by the test-suite against the oracle engine
 // and the Python host (tests/test_gpu_flex.py).
 //
-// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]   (poseidon hashes x and x + 1:
-//        examples/poseidon.rs `hash_two`)
+// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed [count [num_advice num_lookup_advice]]]]]]]
+//        (poseidon hashes x and x + 1: examples/poseidon.rs `hash_two`; count: range checks in one context, see flex::range_closure;
+//        num_advice / num_lookup_advice: the column counts set by hand instead of taken from builder.config)
 //        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
 #include <algorithm>
 #include <chrono>
@@ -48,6 +49,8 @@ int main(int argc, char** argv) {
   const uint64_t x = argc > 4 ? std::stoull(argv[4], nullptr, 0) : 12;
   const Fr s = fr_from_hex(argc > 5 ? argv[5] : "5ec2e7");
   const uint64_t seed = argc > 6 ? std::stoull(argv[6]) : 11;
+  const uint32_t count = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
+  const uint32_t set_advice = argc > 9 ? (uint32_t)std::atoi(argv[8]) : 0, set_lookup = argc > 9 ? (uint32_t)std::atoi(argv[9]) : 0;
   const bool lookup = shape == "range";
   if (!lookup && shape != "halo2_lib" && shape != "poseidon") {
     std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
@@ -58,10 +61,11 @@ int main(int argc, char** argv) {
     auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
     auto run = [&](const flex::FlexGateCS& c, uint64_t v) {
       if (shape == "poseidon") return flex::poseidon_hash_two_closure(c, fr::from_u64(v), fr::from_u64(v + 1));
-      return lookup ? flex::range_closure(c, v, lookup_bits) : flex::halo2_lib_closure(c, fr::from_u64(v));
+      return lookup ? flex::range_closure(c, v, lookup_bits, count) : flex::halo2_lib_closure(c, fr::from_u64(v));
     };
     // `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268): more than one gate column when the closure's cells overflow 2^k rows
-    const flex::FlexGateCS cs = flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); });
+    const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, 9)
+                                               : flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); });
     if (cs.num_advice > 1) std::printf("columns %u gate + %u lookup-advice\n", cs.num_advice, cs.num_lookup_advice);
     auto closure = [&](uint64_t v) { return run(cs, v); };
     // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape

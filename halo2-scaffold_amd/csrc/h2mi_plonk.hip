@@ -191,10 +191,11 @@ __global__ void __launch_bounds__(256) k_mulscan_apply(fe* local, const fe* offs
   fe_store(p, pack261(f29_mul<F9>(ld261(p), ld261(&offsets[j / MS_TILE]))));
 }
 
+// up to H2MI_FLEX_MAX_PERM columns by value: 3.1 KB of the 4 KB a launch's arguments may take
 struct PermArgs {
-  const fe* value[8];
-  const fe* sigma[8];
-  fe beta_delta[8];  // beta * delta^(column index), Mont256
+  const fe* value[H2MI_FLEX_MAX_PERM];
+  const fe* sigma[H2MI_FLEX_MAX_PERM];
+  fe beta_delta[H2MI_FLEX_MAX_PERM];  // beta * delta^(column index), Mont256
   fe beta, gamma;
   uint32_t m;
 };
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256) k_perm_numden_sets(PermArgs a, uint32_t c
   fe_store(&den[e], pack261(pd));
 }
 struct ZOut {
-  fe* z[8];
+  fe* z[H2MI_FLEX_MAX_PERM];
 };
 // z_set[i] = product of every ratio before (set, i) in the concatenated order: R[set * u + i - 1], one at the very start.
 // With an `active` list (sorted positions whose ratio can differ from one, see h2mi_plonk_permutation_products_sparse_dev)
@@ -457,17 +458,17 @@ __global__ void __launch_bounds__(256, 4) k_evaluate_h_range_occ4(RangeCosets c,
 // the selector form of the lookup input both kernels must produce the same h (tests/test_gpu_flex.py).
 struct FlexCosets {
   uint32_t n_gates, n_perm, chunk, n_lookups;
-  const fe* gate_a[4];
-  const fe* gate_q[4];
-  const fe* perm_value[8];
-  const fe* perm_sigma[8];
-  const fe* perm_z[8];
-  const fe* lk_in[2];
-  const fe* lk_in_b[2];  // optional second factor of the input expression (selector * advice)
-  const fe* lk_table[2];
-  const fe* lk_pin[2];
-  const fe* lk_ptab[2];
-  const fe* lk_z[2];
+  const fe* gate_a[H2MI_FLEX_MAX_GATES];
+  const fe* gate_q[H2MI_FLEX_MAX_GATES];
+  const fe* perm_value[H2MI_FLEX_MAX_PERM];
+  const fe* perm_sigma[H2MI_FLEX_MAX_PERM];
+  const fe* perm_z[H2MI_FLEX_MAX_PERM];
+  const fe* lk_in[H2MI_FLEX_MAX_LOOKUPS];
+  const fe* lk_in_b[H2MI_FLEX_MAX_LOOKUPS];  // optional second factor of the input expression (selector * advice)
+  const fe* lk_table[H2MI_FLEX_MAX_LOOKUPS];
+  const fe* lk_pin[H2MI_FLEX_MAX_LOOKUPS];
+  const fe* lk_ptab[H2MI_FLEX_MAX_LOOKUPS];
+  const fe* lk_z[H2MI_FLEX_MAX_LOOKUPS];
   const fe* l0;
   const fe* l_last;
   const fe* l_active;
@@ -661,7 +662,7 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
                                        const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows, const uint64_t omega[4],
                                        const void* d_start_or_null, void* d_z, void* d_last_or_null, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
-  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8) return H2MI_EINVAL;
+  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > H2MI_FLEX_MAX_PERM) return H2MI_EINVAL;
   if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   CallScope scope_;
@@ -711,7 +712,7 @@ static int perm_products(const void* const* d_values, const void* const* d_sigma
                          const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* beta_delta_pows, const uint64_t omega[4],
                          const uint32_t* d_active, uint32_t n_active, void* const* d_z, h2mi_stream_t stream) {
   H2_REQUIRE_INIT();
-  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > 8 || chunk_len == 0) return H2MI_EINVAL;
+  if (!d_values || !d_sigmas || !beta || !gamma || !beta_delta_pows || !omega || !d_z || m == 0 || m > H2MI_FLEX_MAX_PERM || chunk_len == 0) return H2MI_EINVAL;
   if (k == 0 || k > H2MI_MAX_LOG_N || usable_rows == 0 || usable_rows >= ((uint64_t)1 << k)) return H2MI_ERANGE;
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   CallScope scope_;
@@ -943,8 +944,9 @@ int h2mi_plonk_evaluate_h_flex_dev(const h2mi_flex_cosets* c, uint32_t k, uint32
   H2_REQUIRE_INIT();
   if (!c || !beta || !gamma || !y || !delta || !zeta || !extended_omega || !t_inv || !d_h_out) return H2MI_EINVAL;
   if (extended_k < k || extended_k - k > 4 || extended_k > H2MI_MAX_LOG_N) return H2MI_ERANGE;
-  if (c->n_gates == 0 || c->n_gates > 4 || c->n_perm > 8 || c->n_lookups > 2) return H2MI_EINVAL;
+  if (c->n_gates == 0 || c->n_gates > H2MI_FLEX_MAX_GATES || c->n_perm > H2MI_FLEX_MAX_PERM || c->n_lookups > H2MI_FLEX_MAX_LOOKUPS) return H2MI_EINVAL;
   if (c->n_perm && (c->chunk_len == 0 || c->chunk_len > 3)) return H2MI_EINVAL;
+  static_assert(sizeof(FlexCosets) + sizeof(FlexConsts) + 64 <= 4096, "the quotient kernel's arguments travel by value");
   FlexCosets fc;
   memset(&fc, 0, sizeof(fc));
   fc.n_gates = c->n_gates; fc.n_perm = c->n_perm; fc.chunk = c->chunk_len ? c->chunk_len : 1; fc.n_lookups = c->n_lookups;

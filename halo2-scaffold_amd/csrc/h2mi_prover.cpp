@@ -67,7 +67,7 @@ void fill_column(DeviceVec& d, size_t n, const h2mi_column_cells& c, size_t row_
   if (c.count == 0) return;
   if (!c.values) throw Error(H2MI_EINVAL, "column cells without values");
   if (!c.rows) {
-    if (c.count > row_limit) throw Error(H2MI_ERANGE, "assignment reaches into the blinding rows");
+    if (c.count > row_limit) throw Error(H2MI_ERANGE, "assignment reaches into the blinding rows (NotEnoughRowsAvailable)");
     if (c.count <= 16) {
       for (size_t i = 0; i < c.count; i++) pl.add(d, i, cell_value(c, i));
       return;
@@ -85,7 +85,7 @@ void fill_column(DeviceVec& d, size_t n, const h2mi_column_cells& c, size_t row_
     lo = std::min(lo, c.rows[i]);
     hi = std::max(hi, c.rows[i]);
   }
-  if (hi >= row_limit) throw Error(H2MI_ERANGE, "assignment reaches into the blinding rows");
+  if (hi >= row_limit) throw Error(H2MI_ERANGE, "assignment reaches into the blinding rows (NotEnoughRowsAvailable)");
   if (c.count <= 4096) {
     for (size_t i = 0; i < c.count; i++) pl.add(d, c.rows[i], cell_value(c, i));
     return;
@@ -121,13 +121,9 @@ void validate(const h2mi_constraint_system& cs) {
   if (cs.k == 0 || cs.k > H2MI_MAX_LOG_N) throw Error(H2MI_ERANGE, "constraint system: k");
   if (cs.degree < 3 || cs.degree > 9) bad("degree");
   if (((uint64_t)1 << cs.k) <= (uint64_t)cs.blinding_factors + 2) throw Error(H2MI_ERANGE, "constraint system: no usable rows");
-  if (cs.n_advice == 0 || cs.n_advice > 8 || cs.n_fixed > 16 || cs.n_instance > 1) bad("column counts");
+  if (cs.n_advice == 0 || cs.n_advice > H2MI_MAX_ADVICE || cs.n_fixed > H2MI_MAX_FIXED || cs.n_instance > 1) bad("column counts");
   if (cs.n_perm > H2MI_MAX_PERM || cs.n_lookups > H2MI_MAX_LOOKUPS) bad("permutation / lookup counts");
   if (cs.n_advice_queries > H2MI_MAX_QUERIES || cs.n_fixed_queries > H2MI_MAX_QUERIES) bad("query counts");
-  {  // a phase's commitments land in eight 96-byte result slots
-    const uint32_t sets = cs.n_perm ? (cs.n_perm + cs.degree - 3) / (cs.degree - 2) : 0;
-    if (sets + cs.n_lookups + 1 > 8 || cs.degree - 1 > 8) bad("more than eight commitments in one phase");
-  }
   for (uint32_t j = 0; j < cs.n_perm; j++) {
     const h2mi_column& c = cs.perm_columns[j];
     const uint32_t lim = c.kind == H2MI_COL_ADVICE ? cs.n_advice : c.kind == H2MI_COL_FIXED ? cs.n_fixed : c.kind == H2MI_COL_INSTANCE ? cs.n_instance : 0;
@@ -253,10 +249,12 @@ std::unique_ptr<h2mi_pk_s> keygen(const h2mi_constraint_system& cs, uint64_t g_l
     if (base_n < n) throw Error(H2MI_ERANGE, "keygen: the Lagrange SRS is shorter than 2^k");
   }
   PatchList pl;
-  // fixed columns as synthesize() assigns them (the whole column is the circuit's: no blinding rows)
+  // fixed columns as synthesize() assigns them.  keygen's Assembly refuses a fixed cell or a copy constraint outside the usable rows
+  // (Error::NotEnoughRowsAvailable [RECALL plonk/keygen.rs assign_fixed / copy]): the permutation argument's product does not run over
+  // the blinding rows, so a cycle through one would not be enforced and the proof would not verify
   for (uint32_t c = 0; c < cs.n_fixed; c++) {
     Dev d = vec(n);
-    fill_column(*d, n, fixed[c], n, pl);
+    fill_column(*d, n, fixed[c], u, pl);
     pk.fixed_values.push_back(std::move(d));
   }
   pl.flush();
@@ -265,7 +263,7 @@ std::unique_ptr<h2mi_pk_s> keygen(const h2mi_constraint_system& cs, uint64_t g_l
   for (size_t i = 0; i < n_copies; i++) {
     const uint32_t* c = copies + 4 * i;
     if (c[0] >= m || c[2] >= m) throw Error(H2MI_EINVAL, "copy constraint on a column without equality enabled");
-    if (c[1] >= n || c[3] >= n) throw Error(H2MI_ERANGE, "copy constraint beyond the last row");
+    if (c[1] >= u || c[3] >= u) throw Error(H2MI_ERANGE, "copy constraint beyond the usable rows (NotEnoughRowsAvailable)");
     asm_.copy(Cell(c[0], c[1]), Cell(c[2], c[3]));
   }
   if (m) {
@@ -380,10 +378,24 @@ Fr vanishing_at(const std::vector<Fr>& roots, const Fr& z) {
   return acc;
 }
 bool contains(const std::vector<Fr>& v, const Fr& x) { return std::find(v.begin(), v.end(), x) != v.end(); }
+// out = sum_k scalars[k] polys[k]; beyond one launch's 24 operands the sum continues in place (out re-enters with weight one: the
+// kernel reads and writes row i in one thread, and every partial sum is the canonical value, so the split changes no bit)
 void lincomb(const std::vector<const DeviceVec*>& polys, const std::vector<Fr>& scalars, size_t n, DeviceVec& out, h2mi_stream_t stream = nullptr) {
-  std::vector<const void*> ptrs;
-  for (auto* p : polys) ptrs.push_back(p->p);
-  check(h2mi_fr_lincomb_dev(ptrs.data(), (const uint64_t*)scalars.data(), polys.size(), n, out.p, stream), "lincomb");
+  constexpr size_t MAX = 24;
+  for (size_t k0 = 0; k0 < polys.size();) {
+    std::vector<const void*> ptrs;
+    std::vector<Fr> sc;
+    if (k0) {
+      ptrs.push_back(out.p);
+      sc.push_back(fr::ONE);
+    }
+    while (k0 < polys.size() && ptrs.size() < MAX) {
+      ptrs.push_back(polys[k0]->p);
+      sc.push_back(scalars[k0]);
+      k0++;
+    }
+    check(h2mi_fr_lincomb_dev(ptrs.data(), (const uint64_t*)sc.data(), ptrs.size(), n, out.p, stream), "lincomb");
+  }
 }
 void add_head(DeviceVec& poly, const std::vector<Fr>& head, h2mi_stream_t stream = nullptr) {
   check(h2mi_fr_add_head_dev(poly.p, (const uint64_t*)head.data(), head.size(), stream), "add_head");
@@ -519,6 +531,12 @@ struct h2mi_prover_s {
 
 namespace {
 
+// commitments of the largest phase: the result slots a prover (and a combiner's two buffers) must hold
+uint32_t max_phase_points(const h2mi_pk_s& pk) {
+  const h2mi_constraint_system& cs = pk.cs;
+  return std::max({cs.n_advice, 2 * cs.n_lookups, pk.n_sets + cs.n_lookups + 1, cs.degree - 1, 8u});
+}
+
 std::unique_ptr<h2mi_prover_s> create_prover(h2mi_pk_s* pk, uint64_t g, uint64_t gl, size_t lo, size_t cnt) {
   if (pk->vk_only) throw Error(H2MI_EINVAL, "prover_create: the key was built with H2MI_KEYGEN_VK_ONLY");
   if (cnt == 0 || lo + cnt > pk->n) throw Error(H2MI_ERANGE, "prover_create: base slice");
@@ -553,7 +571,7 @@ std::unique_ptr<h2mi_prover_s> create_prover(h2mi_pk_s* pk, uint64_t g, uint64_t
   p.random_poly = vec(n);
   p.h = vec(ext);
   p.h_poly = vec(n);
-  p.points = vec(24);  // 8 x 96 B
+  p.points = vec(3 * (size_t)max_phase_points(*pk));  // 96 B per commitment of the largest phase
   for (int i = 0; i < 3; i++) {
     p.nx[i] = vec(n);
     p.tmp[i] = vec(n);
@@ -1043,7 +1061,6 @@ void phase_shplonk_quotient(h2mi_prover_s& p, const Fr& y, const Fr& v, uint64_t
     for (size_t j = 1; j < ypow.size(); j++) ypow[j] = fr::mul(ypow[j - 1], y);
     std::vector<const DeviceVec*> polys;
     for (auto& mb : rs.members) polys.push_back(mb.first);
-    if (polys.size() > 24) throw Error(H2MI_ERANGE, "shplonk: more than 24 polynomials in one rotation set");
     lincomb(polys, ypow, n, *p.s[i], stream);
     std::vector<Fr> rsum(rs.points.size(), fr_zero());
     const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points);

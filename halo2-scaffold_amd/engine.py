@@ -22,7 +22,7 @@ GATES_STANDARD_PLONK, GATES_FLEX_VERTICAL = 1, 2
 CELLS_CANONICAL = 1
 KEYGEN_VK_ONLY = 1
 EUNSAT = -7
-MAX_GATES, MAX_PERM, MAX_LOOKUPS, MAX_QUERIES = 4, 8, 2, 24
+MAX_GATES, MAX_PERM, MAX_LOOKUPS, MAX_QUERIES = 32, 64, 8, 192  # H2MI_MAX_* (include/h2mi_prover.h)
 
 # h2mi_prover_buffer kinds
 (BUF_ADVICE, BUF_ADVICE_POLY, BUF_ADVICE_COSET, BUF_INSTANCE, BUF_PERM_Z, BUF_PERM_Z_POLY, BUF_PERM_Z_COSET, BUF_LOOKUP_PERMUTED_INPUT,
@@ -195,7 +195,7 @@ class Prover:
     """one h2mi_prover_t: the device buffers, streams and phase state of one create_proof at a time, reused from proof to proof
     (the reference's drivers prove repeatedly against one pk / SRS, e.g. examples/linear_regression.rs:126-195).
     params: the whole SRS, or one rank's slice of it (ParamsKZG.register_slice) together with `combiner`, a dist.PhaseCombiner
-    with >= 8 slots: every commitment is then this rank's partial point, combined across ranks whenever a phase reads its
+    with a slot per commitment of the largest phase (8 covers the reference's shapes): every commitment is then this rank's partial point, combined across ranks whenever a phase reads its
     points back (the library calls back into combiner.combine)."""
 
     def __init__(self, keys: Keys, params, combiner=None):
@@ -206,7 +206,7 @@ class Prover:
         keys._provers.add(self)
         self.counts = _Counts()
         check(lib.h2mi_prover_get_counts(self.handle, C.byref(self.counts)), "prover counts")
-        self._points = np.zeros((8, 8), dtype=np.uint64)
+        self._points = np.zeros((max(self.counts.advice, self.counts.lookups, self.counts.products, self.counts.quotient, 8), 8), dtype=np.uint64)
         self._evals = np.zeros((self.counts.evaluations, 4), dtype=np.uint64)
         self._cb = None
         self._cb_error = None

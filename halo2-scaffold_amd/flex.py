@@ -77,7 +77,7 @@ class FlexGateCS:
         2 + 1 + 1 = 4, permutation sets of two, three h pieces; keygen appends one fixed column per selector (gates of different
         columns share rows: compress_selectors cannot merge them); the scaffold adds the instance column last."""
         A, Lc = self.num_advice, self.num_lookup_advice
-        assert 2 <= A <= 4 and Lc <= 2, "the device quotient kernel takes up to four gate columns and two lookup-advice columns"
+        assert 2 <= A <= engine.MAX_GATES and Lc <= engine.MAX_LOOKUPS, "the prover ABI takes up to 32 gate columns and 8 lookup-advice columns"
         assert (Lc >= 1) == bool(self.lookup), "the Range builder needs a lookup-advice column, the Gate builder has none"
         assert self.k is not None, "the multi-column layout needs k (rows per column = 2^k - minimum_rows)"
         self.n_advice = A + Lc
@@ -280,15 +280,23 @@ def halo2_lib_closure(cs: FlexGateCS, x: int) -> Assignment:
     return asg
 
 
-def range_closure(cs: FlexGateCS, x: int, lookup_bits: int) -> Assignment:
+RANGE_MANY_STEP = 0x9E3779B97F4A7C15
+
+
+def range_closure(cs: FlexGateCS, x: int, lookup_bits: int, count: int = 1) -> Assignment:
     """reference examples/range.rs:10-34: make_public = [x]; range_check(x, 64); x + x.  The table column is what
-    RangeConfig::load_lookup_table assigns: 0 .. 2^LOOKUP_BITS - 1 (src/scaffold.rs:462)."""
+    RangeConfig::load_lookup_table assigns: 0 .. 2^LOOKUP_BITS - 1 (src/scaffold.rs:462).  count > 1: the same body for
+    x, x + step, x + 2 step, ... (mod 2^64) in ONE context, every value public — a circuit that fills several gate and
+    lookup-advice columns while the limb bases, shared by all the checks, still fit the one constants column."""
     asg = Assignment(cs)
     ctx = Context(asg)
-    xc = ctx.load_witness(x)
-    ctx.range_check(xc, 64, lookup_bits)
-    ctx.add(xc, xc)
-    ctx.finish([xc])
+    public = []
+    for i in range(count):
+        xc = ctx.load_witness((x + i * RANGE_MANY_STEP) & ((1 << 64) - 1))
+        ctx.range_check(xc, 64, lookup_bits)
+        ctx.add(xc, xc)
+        public.append(xc)
+    ctx.finish(public)
     asg.fixed[cs.col_table] = None  # dense: filled by keygen from `table_values`
     asg.table_values = list(range(1 << lookup_bits))
     return asg

@@ -61,7 +61,7 @@ def permutation_product(k: int, values, sigmas, column_indices, beta: int, gamma
     (`sigmas`); `column_indices[j]` is column j's position in the argument (its identity image is
     delta^index * omega^row).  The blinding rows of d_z are left as the caller set them."""
     m = len(values)
-    assert m == len(sigmas) == len(column_indices) and 1 <= m <= 8
+    assert m == len(sigmas) == len(column_indices) and 1 <= m <= 64
     r = F.FR_MODULUS
     vp = (C.c_void_p * m)(*[b.ptr for b in values])
     sp = (C.c_void_p * m)(*[b.ptr for b in sigmas])
@@ -95,7 +95,7 @@ def permutation_products(k: int, values, sigmas, chunk_len: int, beta: int, gamm
     (ActiveRows from keygen) the products are computed over the constrained positions only — same values."""
     m = len(values)
     sets = -(-m // chunk_len)
-    assert m == len(sigmas) and 1 <= m <= 8 and len(d_zs) == sets
+    assert m == len(sigmas) and 1 <= m <= 64 and len(d_zs) == sets
     r = F.FR_MODULUS
     vp = (C.c_void_p * m)(*[b.ptr for b in values])
     sp = (C.c_void_p * m)(*[b.ptr for b in sigmas])
@@ -199,20 +199,21 @@ def evaluate_h_range(domain: EvaluationDomain, a: DevBuf, lookup_advice: DevBuf,
 
 class _FlexCosets(C.Structure):
     """include/h2mi.h h2mi_flex_cosets"""
-    _fields_ = [("n_gates", C.c_uint32), ("gate_a", C.c_void_p * 4), ("gate_q", C.c_void_p * 4), ("n_perm", C.c_uint32), ("chunk_len", C.c_uint32),
-                ("perm_value", C.c_void_p * 8), ("perm_sigma", C.c_void_p * 8), ("perm_z", C.c_void_p * 8), ("n_lookups", C.c_uint32),
-                ("lookup_input", C.c_void_p * 2), ("lookup_input_b", C.c_void_p * 2), ("lookup_table", C.c_void_p * 2),
-                ("lookup_permuted_input", C.c_void_p * 2), ("lookup_permuted_table", C.c_void_p * 2), ("lookup_z", C.c_void_p * 2),
+    G, P, L = 32, 64, 8  # H2MI_FLEX_MAX_GATES / _PERM / _LOOKUPS
+    _fields_ = [("n_gates", C.c_uint32), ("gate_a", C.c_void_p * G), ("gate_q", C.c_void_p * G), ("n_perm", C.c_uint32), ("chunk_len", C.c_uint32),
+                ("perm_value", C.c_void_p * P), ("perm_sigma", C.c_void_p * P), ("perm_z", C.c_void_p * P), ("n_lookups", C.c_uint32),
+                ("lookup_input", C.c_void_p * L), ("lookup_input_b", C.c_void_p * L), ("lookup_table", C.c_void_p * L),
+                ("lookup_permuted_input", C.c_void_p * L), ("lookup_permuted_table", C.c_void_p * L), ("lookup_z", C.c_void_p * L),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active", C.c_void_p)]
 
 
 def evaluate_h_flex(domain: EvaluationDomain, gates, perm_values, perm_sigmas, perm_zs, chunk_len: int, lookups, l0: DevBuf, l_last: DevBuf,
                     l_active: DevBuf, beta: int, gamma: int, y: int, out: DevBuf, blinding_factors: int = BLINDING_FACTORS) -> None:
     """h(X) on the extended coset for the GENERAL halo2-base shapes (h2mi_plonk_evaluate_h_flex_dev): `gates` = [(advice coset, selector
-    coset)] (<= 4 vertical gates), the permutation argument over <= 8 columns, `lookups` = [(input coset, second input factor or None,
-    table coset, permuted input, permuted table, product)] (<= 2) — what builder.config() configures when one column overflows."""
+    coset)] (<= 32 vertical gates), the permutation argument over <= 64 columns, `lookups` = [(input coset, second input factor or None,
+    table coset, permuted input, permuted table, product)] (<= 8) — what builder.config() configures when one column overflows."""
     m = len(perm_values)
-    assert 1 <= len(gates) <= 4 and m <= 8 and len(perm_sigmas) == m and len(perm_zs) == (-(-m // chunk_len) if m else 0) and len(lookups) <= 2
+    assert 1 <= len(gates) <= _FlexCosets.G and m <= _FlexCosets.P and len(perm_sigmas) == m and len(perm_zs) == (-(-m // chunk_len) if m else 0) and len(lookups) <= _FlexCosets.L
     cs = _FlexCosets()
     cs.n_gates = len(gates)
     for g, (a, q) in enumerate(gates):

@@ -283,7 +283,7 @@ int h2mi_plonk_evaluate_h_standard_dev(const h2mi_standard_plonk_cosets* cosets,
                                        const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
                                        void* d_h_out, h2mi_stream_t stream);
 
-/* the permutation argument's grand-product column for one chunk of m <= 8 columns (plonk/permutation/prover.rs,
+/* the permutation argument's grand-product column for one chunk of m <= 64 columns (plonk/permutation/prover.rs,
  * the z vectors are produced where they are consumed): z[0] = start (one if NULL),
  *   z[i+1] = z[i] * prod_j (v_j[i] + beta delta^(c_j) omega^i + gamma) / prod_j (v_j[i] + beta sigma_j[i] + gamma),  i < usable_rows;
  * rows usable_rows+1 .. 2^k-1 of d_z (the blinding rows) are left untouched; z[usable_rows] also goes to d_last
@@ -295,7 +295,7 @@ int h2mi_plonk_permutation_product_dev(const void* const* d_values, const void* 
                                        const uint64_t* beta_delta_pows /* m*4 */, const uint64_t omega[4],
                                        const void* d_start_or_null, void* d_z, void* d_last_or_null, h2mi_stream_t stream);
 
-/* every set of the permutation argument in one pass: m <= 8 columns in argument order, chunked by chunk_len
+/* every set of the permutation argument in one pass: m <= 64 (H2MI_FLEX_MAX_PERM) columns in argument order, chunked by chunk_len
  * (= cs.degree() - 2) into ceil(m / chunk_len) sets; d_z[s] receives rows 0 .. usable_rows of set s, each set
  * starting at the previous set's last value (plonk/permutation/prover.rs chains them through `last_z`); blinding
  * rows untouched.  One scan over the concatenated sets instead of one call (twelve launches) per set. */
@@ -371,29 +371,33 @@ int h2mi_plonk_evaluate_h_range_dev(const h2mi_range_cosets* cosets, uint32_t k,
                                     const uint64_t zeta[4], const uint64_t extended_omega[4], const uint64_t* t_inv /* 2^(extended_k-k) x 4 */,
                                     void* d_h_out, h2mi_stream_t stream);
 
-/* The general form of the halo2-base constraint systems (round 4): what `builder.config(k, Some(minimum_rows))`
- * (src/scaffold.rs:268) configures when the cells overflow ONE advice column — n_gates <= 4 gate advice columns, each with its
- * own selector and vertical gate; the permutation argument over n_perm <= 8 columns (constants, the gate columns, the
- * lookup-advice columns, the instance column) in chunks of chunk_len = cs.degree() - 2; n_lookups <= 2 single-expression lookups
+/* The general form of the halo2-base constraint systems (round 4; the column limits below from round 5): what
+ * `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268) configures when the cells overflow ONE advice column — n_gates <=
+ * H2MI_FLEX_MAX_GATES gate advice columns, each with its own selector and vertical gate; the permutation argument over n_perm <=
+ * H2MI_FLEX_MAX_PERM columns (constants, the gate columns, the lookup-advice columns, the instance column) in chunks of chunk_len =
+ * cs.degree() - 2; n_lookups <= H2MI_FLEX_MAX_LOOKUPS single-expression lookups
  * whose input is a lookup-advice column (lookup_input_b NULL) or the product of two columns (the single-column selector form).
  * Terms in evaluate_h's order: gates, permutation, lookups.  All vectors are extended-coset evaluations; t_inv as above.
  * Slower per point than the specialised entry above (every operand is converted to the multiplier's radix on load), and written
  * independently of its level bookkeeping: for a shape both accept the two must agree (tests/test_gpu_flex.py). */
+#define H2MI_FLEX_MAX_GATES 32
+#define H2MI_FLEX_MAX_PERM 64
+#define H2MI_FLEX_MAX_LOOKUPS 8
 typedef struct {
   uint32_t n_gates;
-  const void* gate_a[4];
-  const void* gate_q[4];
+  const void* gate_a[H2MI_FLEX_MAX_GATES];
+  const void* gate_q[H2MI_FLEX_MAX_GATES];
   uint32_t n_perm, chunk_len;
-  const void* perm_value[8];
-  const void* perm_sigma[8];
-  const void* perm_z[8];            /* ceil(n_perm / chunk_len) grand products */
+  const void* perm_value[H2MI_FLEX_MAX_PERM];
+  const void* perm_sigma[H2MI_FLEX_MAX_PERM];
+  const void* perm_z[H2MI_FLEX_MAX_PERM]; /* ceil(n_perm / chunk_len) grand products */
   uint32_t n_lookups;
-  const void* lookup_input[2];
-  const void* lookup_input_b[2];    /* NULL, or a second factor of the input expression */
-  const void* lookup_table[2];
-  const void* lookup_permuted_input[2];
-  const void* lookup_permuted_table[2];
-  const void* lookup_z[2];
+  const void* lookup_input[H2MI_FLEX_MAX_LOOKUPS];
+  const void* lookup_input_b[H2MI_FLEX_MAX_LOOKUPS]; /* NULL, or a second factor of the input expression */
+  const void* lookup_table[H2MI_FLEX_MAX_LOOKUPS];
+  const void* lookup_permuted_input[H2MI_FLEX_MAX_LOOKUPS];
+  const void* lookup_permuted_table[H2MI_FLEX_MAX_LOOKUPS];
+  const void* lookup_z[H2MI_FLEX_MAX_LOOKUPS];
   const void* l0;
   const void* l_last;
   const void* l_active;

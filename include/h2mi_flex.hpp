@@ -72,7 +72,7 @@ struct FlexGateCS {
     minimum_rows = minimum_rows_;
     if (gate_columns <= 1) return;
     const uint32_t A = gate_columns, Lc = lookup_columns;
-    if (A > 4 || Lc > 2 || (Lc >= 1) != lookup) throw Error(H2MI_EINVAL, "FlexGateCS: up to four gate columns and two lookup-advice columns");
+    if (A > H2MI_MAX_GATES || Lc > H2MI_MAX_LOOKUPS || (Lc >= 1) != lookup) throw Error(H2MI_EINVAL, "FlexGateCS: up to 32 gate columns and 8 lookup-advice columns");
     num_advice = A;
     num_lookup_advice = Lc;
     n_advice = A + Lc;
@@ -309,13 +309,19 @@ inline Assignment halo2_lib_closure(const FlexGateCS& cs, const Fr& x) {
   return asg;
 }
 // reference examples/range.rs:10-34: make_public = [x]; range_check(x, 64); x + x.  Table: 0 .. 2^LOOKUP_BITS - 1
-inline Assignment range_closure(const FlexGateCS& cs, uint64_t x, uint32_t lookup_bits) {
+// count > 1: the same body for x, x + step, x + 2 step, ... (mod 2^64) in one context, every value public: fills several gate and
+// lookup-advice columns while the limb bases, shared by all the checks, still fit the one constants column
+inline Assignment range_closure(const FlexGateCS& cs, uint64_t x, uint32_t lookup_bits, uint32_t count = 1) {
   Assignment asg(cs);
   Context ctx(asg);
-  const uint32_t xc = ctx.load_witness(fr::from_u64(x));
-  ctx.range_check(xc, 64, lookup_bits);
-  ctx.add(xc, xc);
-  ctx.finish({xc});
+  std::vector<uint32_t> pub;
+  for (uint32_t i = 0; i < count; i++) {
+    const uint32_t xc = ctx.load_witness(fr::from_u64(x + (uint64_t)i * 0x9E3779B97F4A7C15ull));
+    ctx.range_check(xc, 64, lookup_bits);
+    ctx.add(xc, xc);
+    pub.push_back(xc);
+  }
+  ctx.finish(pub);
   asg.table_values.resize((size_t)1 << lookup_bits);
   for (size_t i = 0; i < asg.table_values.size(); i++) asg.table_values[i] = i;
   return asg;

@@ -216,7 +216,7 @@ inline void drive_proof(ProverWorkspace& ws, const std::vector<h2mi_column_cells
                         transcript::Blake2bWrite& tr) {
   h2mi_prover_t p = ws.prover;
   const h2mi_prover_counts& c = ws.counts;
-  std::vector<G1Affine> pts(8);
+  std::vector<G1Affine> pts(std::max({c.advice, c.lookups, c.products, c.quotient, 1u}));
   auto write_points = [&](size_t k) {
     for (size_t i = 0; i < k; i++) tr.write_point(pts[i]);  // throws on the identity, as the crate's transcript does
   };

@@ -28,8 +28,10 @@
  * The constraint system is DATA (h2mi_constraint_system).  Shapes accepted are the ones the reference proves:
  *   H2MI_GATES_STANDARD_PLONK  src/circuits/standard_plonk.rs:29-48 — q_a a + q_b b + q_c c + q_ab a b + constant
  *   H2MI_GATES_FLEX_VERTICAL   halo2-base's FlexGate through scaffold::prove (src/scaffold.rs:246-366, 379-485):
- *                              per gate column q (a + a(wX) a(w^2 X) - a(w^3 X)); up to 4 gate columns, up to 2
- *                              single-expression lookups (a lookup-advice column, or q_lookup * a), one instance column
+ *                              per gate column q (a + a(wX) a(w^2 X) - a(w^3 X)); up to H2MI_MAX_GATES (32) gate columns, up to
+ *                              H2MI_MAX_LOOKUPS (8) single-expression lookups (a lookup-advice column, or q_lookup * a), one instance
+ *                              column, up to H2MI_MAX_PERM (64) equality-enabled columns: every column count
+ *                              `builder.config(k, Some(minimum_rows))` takes for a circuit that fills a few dozen columns
  * Every function returns H2MI_OK or a negative H2MI_E* code (h2mi.h); no exception crosses the boundary.  Field elements
  * and points use the layouts of h2mi.h (4 / 8 uint64 limbs, Montgomery form).  A prover object is used by one thread at a time.
  */
@@ -57,10 +59,12 @@ typedef struct {
 #define H2MI_GATES_STANDARD_PLONK 1u
 #define H2MI_GATES_FLEX_VERTICAL 2u
 
-#define H2MI_MAX_GATES 4
-#define H2MI_MAX_PERM 8
-#define H2MI_MAX_LOOKUPS 2
-#define H2MI_MAX_QUERIES 24
+#define H2MI_MAX_GATES H2MI_FLEX_MAX_GATES     /* 32 */
+#define H2MI_MAX_PERM H2MI_FLEX_MAX_PERM       /* 64 */
+#define H2MI_MAX_LOOKUPS H2MI_FLEX_MAX_LOOKUPS /* 8 */
+#define H2MI_MAX_ADVICE 64
+#define H2MI_MAX_FIXED 64
+#define H2MI_MAX_QUERIES 192
 
 typedef struct {
   h2mi_column input;        /* the lookup's input column (advice) */
@@ -71,7 +75,7 @@ typedef struct {
 /* ConstraintSystem<Fr> after configure(): the numbers create_proof reads off `pk.vk.cs` */
 typedef struct {
   uint32_t k;                 /* rows = 2^k */
-  uint32_t n_advice, n_fixed;
+  uint32_t n_advice, n_fixed; /* at most H2MI_MAX_ADVICE / H2MI_MAX_FIXED */
   uint32_t n_instance;        /* 0 or 1 instance columns */
   uint32_t degree;            /* cs.degree(): extended domain 2^ceil(log2((degree - 1) n)), degree - 1 h pieces, permutation chunks of degree - 2 */
   uint32_t blinding_factors;  /* cs.blinding_factors() */
@@ -108,6 +112,7 @@ typedef struct h2mi_prover_s* h2mi_prover_t; /* the buffers, streams and phase s
  * right row) per constrain_equal call, in call order, columns as indices into cs->perm_columns (permutation/keygen.rs Assembly::copy;
  * the order decides the sigma polynomials).  g_lagrange_handle: the FULL Lagrange SRS (h2mi_bases_register*) of 2^k points — keygen
  * commits the fixed and sigma columns against it.  flags: H2MI_KEYGEN_VK_ONLY builds only what keygen_vk returns (the commitments).
+ * H2MI_ERANGE: a fixed cell or a copy constraint on a row at or beyond 2^k - blinding_factors - 1 (the crate's NotEnoughRowsAvailable).
  * The pk holds: fixed / sigma columns in Lagrange, coefficient and extended-coset form, l_0 / l_last / l_active cosets, the support
  * of the copy constraints, each lookup table's sorted distinct values. */
 #define H2MI_KEYGEN_VK_ONLY 1u
@@ -123,7 +128,9 @@ int h2mi_prover_vk_commitments(h2mi_pk_t pk, uint64_t* fixed_out /* n_fixed x 8 
  * one-process-per-GPU deployment: every commitment is then this rank's PARTIAL point and a combiner must be set. */
 int h2mi_prover_create(h2mi_pk_t pk, uint64_t g_handle, uint64_t g_lagrange_handle, size_t base_lo, size_t base_count, h2mi_prover_t* prover_out);
 int h2mi_prover_destroy(h2mi_prover_t prover);
-/* sliced SRS: the phase's commitments are written as 96-byte Jacobian partial points to d_partial + 96 slot (slot < 8); when a phase
+/* sliced SRS: the phase's commitments are written as 96-byte Jacobian partial points to d_partial + 96 slot (slot < the largest of
+ * h2mi_prover_counts' advice / lookups / products / quotient — the size both buffers must have, in points; 8 covers the reference's
+ * StandardPlonk and one-column halo2-lib shapes); when a phase
  * reads its points back the library joins its MSM pipeline, calls combine(ctx, count) — which must leave the sums over all ranks of
  * slots 0 .. count - 1 at d_combined + 96 slot, ordered on the library's stream (h2mi_library_stream) or complete on return: an RCCL
  * all-gather + h2mi_g1_fold_groups_dev — and reads d_combined.  A nonzero return from combine fails the phase with H2MI_EHIP.

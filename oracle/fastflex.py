@@ -45,6 +45,7 @@ class Keys:
 
     def __init__(self, cs, k, s, asg_fixed, copies):
         self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
+        FX.check_rows_available(cs, k, asg_fixed, copies)
         n = self.n
         self.dom = FastDomain(k, cs.degree)
         self.u = n - (cs.blinding_factors + 1)

@@ -337,6 +337,56 @@ def _range_table(x, lookup_bits):
     return t
 
 
+RANGE_MANY_STEP = 0x9E3779B97F4A7C15
+
+
+def range_many_values(x, count):
+    """the witnesses of the `count`-fold range closure: x, x + step, x + 2 step, ... modulo 2^64"""
+    return [(x + i * RANGE_MANY_STEP) & ((1 << 64) - 1) for i in range(count)]
+
+
+def _range_many_table(xs, lookup_bits):
+    """examples/range.rs's body once per value — load_witness(x_i); range_check(x_i, 64); x_i + x_i — in one context, every x_i public:
+    the circuit that fills SEVERAL lookup-advice columns while its constants (the limb bases, shared by all the checks) still fit
+    one fixed column.  Same instruction tables as _range_table, at running row offsets; -> (table, public rows)."""
+    k = -(-64 // lookup_bits)
+    t = _Table()
+    publics = []
+    for x in xs:
+        assert 0 <= x < 1 << 64
+        limb = lambda i: (x >> (lookup_bits * i)) & ((1 << lookup_bits) - 1)
+        partial = lambda i: x & ((1 << (lookup_bits * (i + 1))) - 1)
+        r0 = t.put([(W_, x)])
+        publics.append(r0)
+        cells = [(W_, limb(0))]
+        for i in range(1, k):
+            cells += [(W_, limb(i)), (K_, 1 << (lookup_bits * i)), (W_, partial(i))]
+        base = t.put(cells, [3 * j for j in range(k - 1)])
+        limb_row = lambda i: base + (0 if i == 0 else 3 * i - 2)
+        acc_row = base + (3 * (k - 1) if k > 1 else 0)
+        assert len(t.rows) == acc_row + 1 and t.value(acc_row) == x
+        t.events.append((r0, acc_row))
+        t.lookups += [limb_row(i) for i in range(k)]
+        rem = 64 % lookup_bits
+        top = limb_row(k - 1)
+        if rem == 1:
+            t.put([(K_, 0), (E_, top), (E_, top), (E_, top)], [0])
+        elif rem > 1:
+            shift = 1 << (lookup_bits - rem)
+            q0 = t.put([(K_, 0), (E_, top), (K_, shift), (W_, limb(k - 1) * shift)], [0])
+            t.lookups.append(q0 + 3)
+        t.put([(E_, r0), (E_, r0), (K_, 1), (W_, 2 * x)], [0])
+    return t, publics
+
+
+def range_many_assignment_multi(cs, x, lookup_bits, k, count, minimum_rows=9):
+    """`count` range checks (range_many_values) over cs.num_advice gate columns and cs.num_lookup_advice lookup-advice columns"""
+    t, publics = _range_many_table(range_many_values(x, count), lookup_bits)
+    asg = multi_column_assignment(t, cs, publics, k, minimum_rows)
+    asg.fixed[cs.col_table] = {i: i for i in range(1 << lookup_bits)}
+    return asg
+
+
 def halo2_lib_assignment_multi(cs, x, k, minimum_rows=9):
     """the halo2_lib closure over cs.num_advice columns (a DEGREE at which its 17 cells overflow one)"""
     return multi_column_assignment(_halo2_lib_table(x), cs, [0, 8], k, minimum_rows)
@@ -391,6 +441,7 @@ class VerifierKeys:
     permutation column j to DELTA^j s (sum_i w^i L_i(X) = X), corrected at the cells the copy constraints move."""
 
     def __init__(self, cs, k, s, asg_fixed, copies):
+        check_rows_available(cs, k, asg_fixed, copies)
         self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
         n = self.n
         self.dom = o.Domain(k, cs.degree)
@@ -413,9 +464,23 @@ class VerifierKeys:
         self.transcript_repr = _vk_transcript_repr(k, cs.degree, self.fixed_commitments + self.permutation_commitments)
 
 
+def check_rows_available(cs, k, asg_fixed, copies):
+    """keygen's Assembly (plonk/keygen.rs assign_fixed / copy) [RECALL]: a fixed cell or a copy constraint on a row outside the usable
+    rows is Error::NotEnoughRowsAvailable — the blinding rows belong to no column, and the permutation argument's product does not
+    run over them (a cycle through such a row would simply not be enforced: the proof would fail to verify)."""
+    u = (1 << k) - (cs.blinding_factors + 1)
+    for c, cells in enumerate(asg_fixed):
+        if cells and max(cells) >= u:
+            raise ValueError(f"NotEnoughRowsAvailable: fixed column {c} is assigned on row {max(cells)}, usable rows end at {u}")
+    for left, right in copies:
+        if left[2] >= u or right[2] >= u:
+            raise ValueError(f"NotEnoughRowsAvailable: copy constraint {left} == {right} beyond the usable rows ({u})")
+
+
 class Keys:
     def __init__(self, cs, k, s, asg_fixed, copies):
         self.cs, self.k, self.n, self.s = cs, k, 1 << k, s
+        check_rows_available(cs, k, asg_fixed, copies)
         n = self.n
         self.dom = o.Domain(k, cs.degree)
         self.u = n - (cs.blinding_factors + 1)

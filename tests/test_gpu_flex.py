@@ -406,6 +406,70 @@ def test_multi_column_proofs_match_oracle_and_golden(gpu):
         flex.halo2_lib_closure(cs, 12)
 
 
+def test_wide_column_counts_match_golden(gpu):
+    """round 5: the prover ABI's column limits (32 gate columns, 8 lookup-advice columns, 64 permutation columns, 192 queries) —
+    poseidon at DEGREE 8 / 9 (31 / 15 gate columns through `flex.configure`), 8 and 24 range checks in one context at DEGREE 6 / 7
+    (8 + 3 and 11 + 4 columns), 10 range checks over 11 + 8 columns set by hand (eight lookup arguments).  Keys and proof bytes equal
+    the committed golden (tests/golden/flex_wide_proofs.json, made by the oracle's vector engine and re-verified on the CPU by
+    tests/test_oracle_fast.py); the oracle's verifier accepts the device proof and refuses another public input; the C++ host
+    (its own Context / configure over the same prover ABI) prints the same bytes.  A configuration whose constants overflow the
+    constants column's usable rows is refused by keygen with H2MI_ERANGE — halo2's NotEnoughRowsAvailable — instead of yielding a
+    proof that cannot verify.  ORACLE SELF-CHECK like the test above: the layouts are restated from memory of halo2-base."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from halo2_scaffold_amd import flex, poseidon
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_flex_wide_golden as MW
+
+    g = json.load(open(os.path.join(root, "tests", "golden", "flex_wide_proofs.json")))
+    secret = int(g["srs_secret"], 16)
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    for case in g["cases"]:
+        shape, k, bits, x, seed, count = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16), case["seed"], case["count"]
+        closure = ((lambda cs: flex.range_closure(cs, x, bits, count)) if shape == "range" else (lambda cs: poseidon.hash_two_closure(cs, x, x + 1)))
+        if case["explicit"]:
+            cs = flex.FlexGateCS(True, case["num_advice"], case["num_lookup_advice"], k=k)
+        else:
+            cs = flex.configure(shape == "range", k, closure)
+        assert (cs.num_advice, cs.num_lookup_advice) == (case["num_advice"], case["num_lookup_advice"])
+        asg = closure(cs)
+        flex.mock(asg)
+        assert asg.instance == [int(v, 16) for v in case["instance"]]
+        params = gpu.ParamsKZG.setup(k, secret)
+        keys = flex.FlexKeys(params, cs, asg)
+        assert keys.vk_bytes().hex() == case["vk_bytes"], (shape, k)
+        ws = flex.FlexWorkspace(params, keys)
+        proof = flex.create_proof(params, keys, asg, seed, ws=ws)
+        assert proof.hex() == case["proof"], (shape, k, cs.num_advice, cs.num_lookup_advice)
+        assert flex.create_proof(params, keys, asg, seed, ws=ws) == proof  # the workspace is reusable at these widths too
+        ocs, oasg = MW.build(shape, k, bits, x, count, (cs.num_advice, cs.num_lookup_advice) if case["explicit"] else None)
+        vk = FX.VerifierKeys(ocs, k, secret, oasg.fixed, oasg.copies)
+        assert FX.verify(vk, proof, oasg.instance) and not FX.verify(vk, proof, [[v ^ 1 for v in oasg.instance[0]]])
+        ws.release()
+        keys.release()
+        params.release()
+        argv = [os.path.join(root, "examples", "halo2_lib"), shape, str(k), str(bits), str(x), hex(secret), str(seed), str(max(count, 1))]
+        if case["explicit"]:
+            argv += [str(cs.num_advice), str(cs.num_lookup_advice)]
+        r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1000:]
+        out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ", "columns ")))
+        assert out["columns"] == f"{cs.num_advice} gate + {cs.num_lookup_advice} lookup-advice"
+        assert out["vk"] == case["vk_bytes"] and out["proof"] == case["proof"], ("C++", shape, k)
+    # 32 limb bases (LOOKUP_BITS 2) do not fit the 25 usable rows of a DEGREE-5 constants column
+    cs = flex.FlexGateCS(True, 5, 2, k=5)
+    asg = flex.range_closure(cs, 0xDEADBEEFCAFE1234, 2)
+    params = gpu.ParamsKZG.setup(5, secret)
+    with pytest.raises(RuntimeError, match="(?i)range|rows"):
+        flex.FlexKeys(params, cs, asg)
+    params.release()
+
+
 def test_general_quotient_kernel_agrees_with_the_specialised_one(gpu):
     """k_evaluate_h_flex (every operand converted to the multiplier's radix, Horner in y as the oracle writes it) and
     k_evaluate_h_range (level bookkeeping, shared reductions) are two independent implementations of the same function of their

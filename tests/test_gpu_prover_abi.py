@@ -184,12 +184,16 @@ def test_constraint_system_validation(gpu):
     a.lookups[0].selector_fixed = 9
     with pytest.raises(gpu.H2miError):
         engine.Keys(a, params, [{} for _ in range(4)], [])
-    a = flex.FlexGateCS(lookup=False).abi(6)
-    a.n_perm = 8
-    for j in range(8):
-        a.perm_columns[j] = engine.Column(engine.ADVICE, 0)
-    with pytest.raises(gpu.H2miError):
-        engine.Keys(a, params, [{}, {}], [])  # eight permutation sets + the random polynomial: nine commitments in one phase
+    for field, value in (("n_perm", engine.MAX_PERM + 1), ("n_gates", engine.MAX_GATES + 1), ("n_lookups", engine.MAX_LOOKUPS + 1),
+                         ("n_advice_queries", engine.MAX_QUERIES + 1), ("n_advice", 65), ("n_fixed", 65)):
+        a = flex.FlexGateCS(lookup=False).abi(6)
+        setattr(a, field, value)  # one past what the fixed-size arrays of h2mi_constraint_system hold
+        with pytest.raises(gpu.H2miError):
+            engine.Keys(a, params, [{}, {}], [])
+    # a fixed cell or a copy constraint on a blinding row: halo2's NotEnoughRowsAvailable
+    u = 64 - (good.blinding_factors + 1)
+    assert code(good, fixed=[{u: 1}, {}, {}, {}, {}]) == -6 and code(good, fixed=[{u - 1: 1}, {}, {}, {}, {}]) == 0
+    assert code(good, cp=[(0, u, 0, 0)]) == -6 and code(good, cp=[(0, u - 1, 0, 0)]) == 0
     del asg
     params.release()
 
@@ -367,7 +371,7 @@ def test_column_cells_every_upload_path(gpu):
     val = lambda i: pow(3, i + 1, r)
     scattered = {2 * i + 1: val(i) for i in range(5000)}          # 5000 cells over a span of 10000 rows: staged
     dense_long = [val(1000 + i) for i in range(6000)]              # rows 0 .. 5999: one upload (+ device conversion when canonical)
-    short = {5: val(7), n - 1: val(8), 77: val(9)}                 # a handful anywhere (fixed columns have no blinding rows)
+    short = {5: val(7), u - 1: val(8), 77: val(9)}                 # a handful anywhere on the usable rows
 
     def column(view, count=n):
         return [gpu.field.fr_from_mont_limbs(row) for row in view.to_numpy(shape=(count, 4), nbytes=count * 32)]
@@ -386,6 +390,8 @@ def test_column_cells_every_upload_path(gpu):
     keys.release()
     keys = engine.Keys(cs, params, [short, {}], [])
     assert column(keys.views(engine.PKBUF_FIXED, 2)[0]) == expect(short)
+    with pytest.raises(gpu.H2miError):  # keygen's Assembly refuses fixed cells beyond the usable rows (NotEnoughRowsAvailable)
+        engine.Keys(cs, params, [{n - 1: val(8)}, {}], [])
     # Montgomery values (what a Rust / C++ caller sends): the same three routes through the raw structure
     def mont_cells(cells):
         items = sorted(cells.items()) if isinstance(cells, dict) else list(enumerate(cells))

@@ -81,7 +81,7 @@ def main():
     if dist is not None:
         lo, hi = slice_bounds(1 << args.k, rank, world)
         params = full.register_slice(lo, hi)
-        combiner = PhaseCombiner(8, backend, torch.device("cuda", local_rank))
+        combiner = PhaseCombiner(80, backend, torch.device("cuda", local_rank))
     ws = flex.FlexWorkspace(params, keys, combiner=combiner)
 
     def barrier():
