@@ -52,7 +52,7 @@ class Fuzzer:
         """h2: the loaded product package (initialised on a GPU)"""
         self.h2, self.seed0 = h2, seed
         self.rng = random.Random(seed)
-        self.counts = {"msm": 0, "msm_batches": 0, "msm_phase_batches": 0, "ntt": 0, "proof": 0, "flex": 0}
+        self.counts = {"msm": 0, "msm_batches": 0, "msm_phase_batches": 0, "ntt": 0, "proof": 0, "flex": 0, "flex_wide": 0, "flex_refused": 0}
         self._big_bases = {}
 
     def run(self, budget_s: float, progress=None) -> dict:
@@ -197,32 +197,47 @@ class Fuzzer:
         h2, rng, counts, seed0 = self.h2, self.rng, self.counts, self.seed0
         from halo2_scaffold_amd import flex
 
-        bits = rng.choice([3, 4, 5, 6, 7])
+        bits = rng.choice([2, 3, 4, 5, 6, 7])  # 2: 32 limb bases, more than a DEGREE-5 constants column's usable rows
         k = rng.choice([5, 6, 7, 8])
+        count = rng.choice([1, 1, 1, 2, 3, 5, 8, 12])  # range checks in one context: the wide shapes (several gate / lookup-advice columns)
         if (1 << bits) >= (1 << k) - 7:
             return
         x = rng.randrange(1 << 64)
-        closure = lambda cs: flex.range_closure(cs, x, bits)
+        closure = lambda cs: flex.range_closure(cs, x, bits, count)
         try:
             cs = flex.configure(True, k, closure)
             asg = closure(cs)
-        except (ValueError, AssertionError) as e:  # more columns than the crate's formula takes, or than the device kernel supports: as in halo2-base
-            if "NOT ENOUGH" in str(e) or "device quotient kernel" in str(e):
+        except (ValueError, AssertionError) as e:  # more columns than the crate's formula takes, or than the prover ABI holds: as in halo2-base
+            if "NOT ENOUGH" in str(e) or "prover ABI takes" in str(e):
                 return
             raise
         flex.mock(asg)
-        params = h2.ParamsKZG.setup(k, S)
-        keys = flex.FlexKeys(params, cs, asg)
-        proof = flex.create_proof(params, keys, asg, rng.randrange(1 << 30))
         if cs.num_advice > 1:
             ocs = FX.flex_multi_cs(True, cs.num_advice, cs.num_lookup_advice)
-            oasg = FX.range_assignment_multi(ocs, x, bits, k)
+            oasg = FX.range_many_assignment_multi(ocs, x, bits, k, count)
         else:
             ocs = FX.flex_gate_cs(True)
-            oasg = FX.range_assignment(ocs, x, bits, 1 << k)
-        vk = FX.VerifierKeys(ocs, k, S, oasg.fixed, oasg.copies)
-        assert FX.verify(vk, proof, [asg.instance]), ("flex", seed0, k, bits, x, cs.num_advice)
+            t, publics = FX._range_many_table(FX.range_many_values(x, count), bits)
+            oasg = t.assignment(ocs, publics)
+            oasg.fixed[ocs.col_table] = {i: i for i in range(1 << bits)}
+        params = h2.ParamsKZG.setup(k, S)
+        try:
+            vk = FX.VerifierKeys(ocs, k, S, oasg.fixed, oasg.copies)
+        except ValueError as e:  # the constants overflow the usable rows: the device keygen must refuse it too (NotEnoughRowsAvailable)
+            assert "NotEnoughRowsAvailable" in str(e)
+            try:
+                flex.FlexKeys(params, cs, asg).release()
+                raise AssertionError(("keygen accepted cells beyond the usable rows", seed0, k, bits, count))
+            except h2.H2miError as err:
+                assert err.code == -6
+            params.release()
+            counts["flex_refused"] = counts.get("flex_refused", 0) + 1
+            return
+        keys = flex.FlexKeys(params, cs, asg)
+        proof = flex.create_proof(params, keys, asg, rng.randrange(1 << 30))
+        assert FX.verify(vk, proof, [asg.instance]), ("flex", seed0, k, bits, x, count, cs.num_advice, cs.num_lookup_advice)
         keys.release()
         params.release()
         counts["flex"] += 1
-
+        if cs.num_advice > 1:
+            counts["flex_wide"] = counts.get("flex_wide", 0) + 1
