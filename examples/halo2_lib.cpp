@@ -4,7 +4,7 @@
 // HBM; public inputs and proof bytes printed.  The proof bytes are checked by the test-suite against the oracle engine
 // and the Python host (tests/test_gpu_flex.py).
 //
-// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed [count [num_advice num_lookup_advice]]]]]]]
+// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed [count [num_advice num_lookup_advice [num_fixed]]]]]]]]
 //        (poseidon hashes x and x + 1: examples/poseidon.rs `hash_two`; count: range checks in one context, see flex::range_closure;
 //        num_advice / num_lookup_advice: the column counts set by hand instead of taken from builder.config)
 //        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
   const uint64_t seed = argc > 6 ? std::stoull(argv[6]) : 11;
   const uint32_t count = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
   const uint32_t set_advice = argc > 9 ? (uint32_t)std::atoi(argv[8]) : 0, set_lookup = argc > 9 ? (uint32_t)std::atoi(argv[9]) : 0;
+  const uint32_t set_fixed = argc > 10 ? (uint32_t)std::max(1, std::atoi(argv[10])) : 1;
   const bool lookup = shape == "range";
   if (!lookup && shape != "halo2_lib" && shape != "poseidon") {
     std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
@@ -64,7 +65,7 @@ int main(int argc, char** argv) {
       return lookup ? flex::range_closure(c, v, lookup_bits, count) : flex::halo2_lib_closure(c, fr::from_u64(v));
     };
     // `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268): more than one gate column when the closure's cells overflow 2^k rows
-    const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, 9)
+    const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, 9, set_fixed)
                                                : flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); });
     if (cs.num_advice > 1) std::printf("columns %u gate + %u lookup-advice\n", cs.num_advice, cs.num_lookup_advice);
     auto closure = [&](uint64_t v) { return run(cs, v); };

@@ -43,14 +43,14 @@ class FlexGateCS:
       Range: fixed 0 table, 1 constants, 2 q_lookup, 3 q_enable     degree 2 + 2 + 1 = 5: sets of three, 4 h pieces
     Queries in creation order (enable_equality queries its column at Rotation::cur)."""
 
-    def __init__(self, lookup: bool, num_advice: int = 1, num_lookup_advice: int = 0, k: int = None, minimum_rows: int = 9):
+    def __init__(self, lookup: bool, num_advice: int = 1, num_lookup_advice: int = 0, k: int = None, minimum_rows: int = 9, num_fixed: int = 1):
         self.lookup = lookup
-        self.num_advice, self.num_lookup_advice = num_advice, num_lookup_advice
+        self.num_advice, self.num_lookup_advice, self.num_fixed = num_advice, num_lookup_advice, num_fixed
         self.k, self.minimum_rows = k, minimum_rows  # the multi-column layout needs the row budget 2^k - minimum_rows
         if num_advice > 1:
             self._init_multi()
             return
-        assert num_lookup_advice == 0
+        assert num_lookup_advice == 0 and num_fixed == 1  # at most 2^k - minimum_rows cells: their constants fit one column
         self.n_advice = 1
         if lookup:
             self.col_table, self.col_const, self.col_qlookup, self.col_q = 0, 1, 2, 3
@@ -75,19 +75,22 @@ class FlexGateCS:
         table column first and — there being more than one gate column — no q_lookup but num_lookup_advice lookup-advice columns
         (advice, equality-enabled, after the gate columns), one lookup argument each with the column itself as input: degree
         2 + 1 + 1 = 4, permutation sets of two, three h pieces; keygen appends one fixed column per selector (gates of different
-        columns share rows: compress_selectors cannot merge them); the scaffold adds the instance column last."""
-        A, Lc = self.num_advice, self.num_lookup_advice
+        columns share rows: compress_selectors cannot merge them); the scaffold adds the instance column last.  num_fixed constants
+        columns (config: ceil(distinct constants / 2^k)), allocated where the single one was; assign_constants deals the distinct
+        constants out round-robin (constant i: column i mod num_fixed, row i div num_fixed)."""
+        A, Lc, Fc = self.num_advice, self.num_lookup_advice, self.num_fixed
         assert 2 <= A <= engine.MAX_GATES and Lc <= engine.MAX_LOOKUPS, "the prover ABI takes up to 32 gate columns and 8 lookup-advice columns"
         assert (Lc >= 1) == bool(self.lookup), "the Range builder needs a lookup-advice column, the Gate builder has none"
         assert self.k is not None, "the multi-column layout needs k (rows per column = 2^k - minimum_rows)"
         self.n_advice = A + Lc
         self.col_table, self.col_const = (0, 1) if self.lookup else (None, 0)
         self.col_qlookup = None
-        self.col_qs = [self.col_const + 1 + j for j in range(A)]
+        self.col_consts = [self.col_const + i for i in range(Fc)]
+        self.col_qs = [self.col_const + Fc + j for j in range(A)]
         self.col_q = None
-        self.n_fixed = self.col_const + 1 + A
-        self.fixed_queries = [(self.col_const, 0)] + ([(self.col_table, 0)] if self.lookup else []) + [(c, 0) for c in self.col_qs]
-        self.perm_columns = [(FIXED, self.col_const)] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
+        self.n_fixed = self.col_const + Fc + A
+        self.fixed_queries = [(c, 0) for c in self.col_consts] + ([(self.col_table, 0)] if self.lookup else []) + [(c, 0) for c in self.col_qs]
+        self.perm_columns = [(FIXED, c) for c in self.col_consts] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
         self.advice_queries = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
         self.degree = 4 if self.lookup else 3
         self.blinding_factors = 6
@@ -117,7 +120,8 @@ def configure(lookup: bool, k: int, closure, minimum_rows: int = 9) -> FlexGateC
     if num_advice == 1:
         return FlexGateCS(lookup, k=k, minimum_rows=minimum_rows)
     looked_up = len(asg.fixed[probe.col_qlookup]) if lookup else 0
-    return FlexGateCS(lookup, num_advice, max(1, -(-looked_up // max_rows)) if lookup else 0, k=k, minimum_rows=minimum_rows)
+    num_fixed = max(1, -(-len(asg.fixed[probe.col_const]) // (1 << k)))  # `(total_fixed + (1 << k) - 1) >> k` over the distinct constants
+    return FlexGateCS(lookup, num_advice, max(1, -(-looked_up // max_rows)) if lookup else 0, k=k, minimum_rows=minimum_rows, num_fixed=num_fixed)
 
 
 class Assignment:
@@ -256,12 +260,12 @@ class Context:
             asg.copies.append((cell(i), (ADVICE, A + lcol, lrow)))
             lrow += 1
         asg.copies += [(cell(new), cell(src)) for new, src in self.eqs]
-        consts = {}
+        consts, Fc = {}, cs.num_fixed
         for r, v in self.const_cells:
             if v not in consts:
                 consts[v] = len(consts)
-                asg.fixed[cs.col_const][consts[v]] = v
-            asg.copies.append((cell(r), (FIXED, cs.col_const, consts[v])))
+                asg.fixed[cs.col_consts[consts[v] % Fc]][consts[v] // Fc] = v
+            asg.copies.append((cell(r), (FIXED, cs.col_consts[consts[v] % Fc], consts[v] // Fc)))
         for i, r in enumerate(public_rows):
             asg.instance.append(self.cells[r])
             asg.copies.append((cell(r), (INSTANCE, 0, i)))

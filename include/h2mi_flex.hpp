@@ -39,6 +39,7 @@ typedef std::pair<uint32_t, int32_t> Query;  // (column, rotation)
 struct FlexGateCS {
   bool lookup;
   uint32_t num_advice = 1, num_lookup_advice = 0;  // gate columns; lookup-advice columns (only with several gate columns)
+  uint32_t num_fixed = 1;                          // constants columns: the distinct constants are dealt out round-robin over them
   uint32_t k = 0, minimum_rows = 9;                // the multi-column layout needs the row budget 2^k - minimum_rows
   uint32_t n_advice = 1, n_fixed;
   int col_table = -1, col_const, col_qlookup = -1;
@@ -67,10 +68,13 @@ struct FlexGateCS {
   // several gate columns (what `builder.config(k, Some(minimum_rows))`, src/scaffold.rs:268, configures when the cells overflow
   // 2^k - minimum_rows rows [RECALL halo2-base 0.3]): per gate column an advice column with its own selector and vertical gate; the
   // Range builder then looks up dedicated lookup-advice columns instead of q_lookup * a: degree 4, permutation sets of two
-  FlexGateCS(bool with_lookup, uint32_t gate_columns, uint32_t lookup_columns, uint32_t k_, uint32_t minimum_rows_ = 9) : FlexGateCS(with_lookup) {
+  // constants_columns: config's ceil(distinct constants / 2^k), allocated where the single constants column was
+  FlexGateCS(bool with_lookup, uint32_t gate_columns, uint32_t lookup_columns, uint32_t k_, uint32_t minimum_rows_ = 9, uint32_t constants_columns = 1)
+      : FlexGateCS(with_lookup) {
     k = k_;
     minimum_rows = minimum_rows_;
     if (gate_columns <= 1) return;
+    num_fixed = std::max(1u, constants_columns);
     const uint32_t A = gate_columns, Lc = lookup_columns;
     if (A > H2MI_MAX_GATES || Lc > H2MI_MAX_LOOKUPS || (Lc >= 1) != lookup) throw Error(H2MI_EINVAL, "FlexGateCS: up to 32 gate columns and 8 lookup-advice columns");
     num_advice = A;
@@ -80,12 +84,14 @@ struct FlexGateCS {
     col_const = lookup ? 1 : 0;
     col_qlookup = -1;
     col_qs.clear();
-    for (uint32_t j = 0; j < A; j++) col_qs.push_back((uint32_t)col_const + 1 + j);
-    n_fixed = (uint32_t)col_const + 1 + A;
-    fixed_queries = {{(uint32_t)col_const, 0}};
+    for (uint32_t j = 0; j < A; j++) col_qs.push_back((uint32_t)col_const + num_fixed + j);
+    n_fixed = (uint32_t)col_const + num_fixed + A;
+    fixed_queries.clear();
+    for (uint32_t c = 0; c < num_fixed; c++) fixed_queries.push_back({(uint32_t)col_const + c, 0});
     if (lookup) fixed_queries.push_back({(uint32_t)col_table, 0});
     for (uint32_t q : col_qs) fixed_queries.push_back({q, 0});
-    perm_columns = {{FIXED, (uint32_t)col_const}};
+    perm_columns.clear();
+    for (uint32_t c = 0; c < num_fixed; c++) perm_columns.push_back({FIXED, (uint32_t)col_const + c});
     for (uint32_t j = 0; j < A + Lc; j++) perm_columns.push_back({ADVICE, j});
     perm_columns.push_back({INSTANCE, 0});
     advice_queries.clear();
@@ -272,11 +278,12 @@ class Context {
     std::vector<Fr> consts;  // one fixed cell per distinct value, in order of first use
     for (const auto& rc : const_cells_) {
       size_t idx = std::find(consts.begin(), consts.end(), rc.second) - consts.begin();
+      const uint32_t ccol = (uint32_t)cs.col_const + (uint32_t)(idx % cs.num_fixed), crow = (uint32_t)(idx / cs.num_fixed);
       if (idx == consts.size()) {
         consts.push_back(rc.second);
-        asg_.fixed[cs.col_const][(uint32_t)idx] = rc.second;
+        asg_.fixed[ccol][crow] = rc.second;
       }
-      asg_.copies.push_back({cell(rc.first), {FIXED, (uint32_t)cs.col_const, (uint32_t)idx}});
+      asg_.copies.push_back({cell(rc.first), {FIXED, ccol, crow}});
     }
     if (A == 1 && cs.lookup)
       for (uint32_t r : lookup_cells_) asg_.fixed[cs.col_qlookup][r] = fr::ONE;
@@ -483,7 +490,8 @@ inline FlexGateCS configure(bool lookup, uint32_t k, Closure closure, uint32_t m
   const uint32_t num_advice = (uint32_t)std::max<size_t>(1, (asg.n_cells + max_rows - 1) / max_rows);
   if (num_advice == 1) return FlexGateCS(lookup, 1, 0, k, minimum_rows);
   const uint32_t num_lookup = lookup ? (uint32_t)std::max<size_t>(1, (asg.n_lookup_cells + max_rows - 1) / max_rows) : 0;
-  return FlexGateCS(lookup, num_advice, num_lookup, k, minimum_rows);
+  const size_t total_fixed = asg.fixed[probe.col_const].size();  // distinct constants: `(total_fixed + (1 << k) - 1) >> k` columns
+  return FlexGateCS(lookup, num_advice, num_lookup, k, minimum_rows, (uint32_t)std::max<size_t>(1, (total_fixed + ((size_t)1 << k) - 1) >> k));
 }
 
 // ---- keys -----------------------------------------------------------------------------------------------------------

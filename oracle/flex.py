@@ -88,7 +88,7 @@ def flex_gate_cs(lookup: bool):
     return cs
 
 
-def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0):
+def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0, num_fixed: int = 1):
     """halo2-base's builders when the cells do NOT fit one column: `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268)
     then configures num_advice = ceil(cells / (2^k - minimum_rows)) gate columns and, for the Range builder, num_lookup_advice =
     ceil(cells_to_lookup / (2^k - minimum_rows)) lookup-advice columns [RECALL halo2-base 0.3 gates/builder.rs, flex_gate.rs, range.rs]:
@@ -99,21 +99,26 @@ def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0):
         (input = the column, degree 1; table = the table column): constraint-system degree 2 + 1 + 1 = 4, permutation chunks of two;
       * keygen appends one fixed column per simple selector (the gates of different columns are enabled on the same rows, so
         compress_selectors cannot merge them), after the user's fixed columns;
-      * the scaffold adds the instance column last.
+      * the scaffold adds the instance column last;
+      * num_fixed = ceil(distinct constants / 2^k) constants columns (each enable_equality, allocated one after the other where the
+        single one was); assign_constants deals the distinct constants out round-robin: constant i to column i mod num_fixed, row
+        i div num_fixed.
     num_advice = 1 is flex_gate_cs (the q_lookup form): not built here."""
-    assert num_advice >= 2 and (lookup or num_lookup_advice == 0) and (not lookup or num_lookup_advice >= 1)
+    assert num_advice >= 2 and (lookup or num_lookup_advice == 0) and (not lookup or num_lookup_advice >= 1) and num_fixed >= 1
     A, Lc = num_advice, num_lookup_advice
     TABLE, CONST = (0, 1) if lookup else (None, 0)
-    q0 = CONST + 1
+    CONSTS = list(range(CONST, CONST + num_fixed))
+    q0 = CONST + num_fixed
     gate_of = lambda j: (lambda q: q(FIXED, q0 + j, 0) * (q(ADVICE, j, 0) + q(ADVICE, j, 1) * q(ADVICE, j, 2) - q(ADVICE, j, 3)) % R)
     gates = [gate_of(j) for j in range(A)]
-    perm = [(FIXED, CONST)] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
+    perm = [(FIXED, c) for c in CONSTS] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
     adv_q = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
-    fix_q = [(CONST, 0)] + ([(TABLE, 0)] if lookup else []) + [(q0 + j, 0) for j in range(A)]
+    fix_q = [(c, 0) for c in CONSTS] + ([(TABLE, 0)] if lookup else []) + [(q0 + j, 0) for j in range(A)]
     lookups = [([(ADVICE, A + l)], (FIXED, TABLE)) for l in range(Lc)]
-    cs = ConstraintSystem(f"{'range' if lookup else 'flex_gate'}_{A}x{Lc}", A + Lc, q0 + A, 1, gates, perm, lookups, adv_q, fix_q, [(0, 0)],
-                          4 if lookup else 3, 6)
+    cs = ConstraintSystem(f"{'range' if lookup else 'flex_gate'}_{A}x{Lc}" + (f"x{num_fixed}" if num_fixed > 1 else ""), A + Lc, q0 + A, 1, gates, perm,
+                          lookups, adv_q, fix_q, [(0, 0)], 4 if lookup else 3, 6)
     cs.col_const, cs.col_table, cs.col_qlookup = CONST, TABLE, None
+    cs.col_consts, cs.num_fixed = CONSTS, num_fixed
     cs.col_q = [q0 + j for j in range(A)]
     cs.num_advice, cs.num_lookup_advice = A, Lc
     return cs
@@ -123,6 +128,13 @@ def multi_column_counts(n_cells: int, n_lookup_cells: int, k: int, minimum_rows:
     """GateThreadBuilder::config: columns needed for this many cells at 2^k rows -> (num_advice, num_lookup_advice)"""
     max_rows = (1 << k) - minimum_rows
     return -(-n_cells // max_rows), -(-n_lookup_cells // max_rows)
+
+
+def num_fixed_columns(t, k: int) -> int:
+    """GateThreadBuilder::config: `num_fixed = (total_fixed + (1 << k) - 1) >> k` over the DISTINCT constants — all 2^k rows counted,
+    not the usable ones, so 26 .. 32 constants at DEGREE 5 get one column and keygen then fails (NotEnoughRowsAvailable) [RECALL]"""
+    total_fixed = len({v for kind, v in t.rows if kind == K_})
+    return max(1, -(-total_fixed // (1 << k)))
 
 
 class Assignment:
@@ -250,11 +262,13 @@ def multi_column_assignment(t: _Table, cs, public_rows, k: int, minimum_rows: in
     for r, (kind, v) in enumerate(t.rows):
         if kind == K_:
             first_use.setdefault(v, len(first_use))
+    F_ = len(cs.col_consts)
+    const_cell = lambda slot: (FIXED, cs.col_consts[slot % F_], slot // F_)  # dealt out round-robin over the constants columns
     for v, slot in first_use.items():
-        asg.fixed[cs.col_const][slot] = v
+        asg.fixed[const_cell(slot)[1]][const_cell(slot)[2]] = v
     asg.copies = copies_break + copies_lookup
     asg.copies += [(where(new), where(src)) for new, src in t.events]
-    asg.copies += [(where(r), (FIXED, cs.col_const, first_use[v])) for r, (kind, v) in enumerate(t.rows) if kind == K_]
+    asg.copies += [(where(r), const_cell(first_use[v])) for r, (kind, v) in enumerate(t.rows) if kind == K_]
     for i, r in enumerate(public_rows):
         asg.instance[0].append(t.value(r))
         asg.copies.append((where(r), (INSTANCE, 0, i)))

@@ -212,17 +212,21 @@ class Fuzzer:
                 return
             raise
         flex.mock(asg)
-        if cs.num_advice > 1:
-            ocs = FX.flex_multi_cs(True, cs.num_advice, cs.num_lookup_advice)
-            oasg = FX.range_many_assignment_multi(ocs, x, bits, k, count)
-        else:
-            ocs = FX.flex_gate_cs(True)
-            t, publics = FX._range_many_table(FX.range_many_values(x, count), bits)
-            oasg = t.assignment(ocs, publics)
-            oasg.fixed[ocs.col_table] = {i: i for i in range(1 << bits)}
         params = h2.ParamsKZG.setup(k, S)
+
+        def oracle_side(cs):
+            if cs.num_advice > 1:
+                ocs = FX.flex_multi_cs(True, cs.num_advice, cs.num_lookup_advice, cs.num_fixed)
+                oasg = FX.range_many_assignment_multi(ocs, x, bits, k, count)
+            else:
+                ocs = FX.flex_gate_cs(True)
+                t, publics = FX._range_many_table(FX.range_many_values(x, count), bits)
+                oasg = t.assignment(ocs, publics)
+                oasg.fixed[ocs.col_table] = {i: i for i in range(1 << bits)}
+            return FX.VerifierKeys(ocs, k, S, oasg.fixed, oasg.copies)
+
         try:
-            vk = FX.VerifierKeys(ocs, k, S, oasg.fixed, oasg.copies)
+            vk = oracle_side(cs)
         except ValueError as e:  # the constants overflow the usable rows: the device keygen must refuse it too (NotEnoughRowsAvailable)
             assert "NotEnoughRowsAvailable" in str(e)
             try:
@@ -230,14 +234,20 @@ class Fuzzer:
                 raise AssertionError(("keygen accepted cells beyond the usable rows", seed0, k, bits, count))
             except h2.H2miError as err:
                 assert err.code == -6
-            params.release()
-            counts["flex_refused"] = counts.get("flex_refused", 0) + 1
-            return
+            counts["flex_refused"] += 1
+            if cs.num_advice == 1:
+                params.release()
+                return
+            # the same circuit with a second constants column set by hand (config's ceil(constants / 2^k) said one): it must prove
+            cs = flex.FlexGateCS(True, cs.num_advice, cs.num_lookup_advice, k=k, num_fixed=2)
+            asg = closure(cs)
+            flex.mock(asg)
+            vk = oracle_side(cs)
         keys = flex.FlexKeys(params, cs, asg)
         proof = flex.create_proof(params, keys, asg, rng.randrange(1 << 30))
-        assert FX.verify(vk, proof, [asg.instance]), ("flex", seed0, k, bits, x, count, cs.num_advice, cs.num_lookup_advice)
+        assert FX.verify(vk, proof, [asg.instance]), ("flex", seed0, k, bits, x, count, cs.num_advice, cs.num_lookup_advice, cs.num_fixed)
         keys.release()
         params.release()
         counts["flex"] += 1
         if cs.num_advice > 1:
-            counts["flex_wide"] = counts.get("flex_wide", 0) + 1
+            counts["flex_wide"] += 1

@@ -11,7 +11,9 @@ circuit whose cells fill dozens of columns at the chosen DEGREE, and what a call
   shared so that the constants still fit one fixed column), LOOKUP_BITS 4: 8 checks at DEGREE 6 (8 gate + 3 lookup-advice columns),
   24 checks at DEGREE 7 (11 + 4), 10 checks at DEGREE 6 with 11 + 8 columns set explicitly (eight lookup arguments, five of them
   over empty columns).  A configuration whose constants overflow the usable rows of the one constants column is refused by keygen
-  (halo2's NotEnoughRowsAvailable), e.g. LOOKUP_BITS 2 at DEGREE 5.
+  (halo2's NotEnoughRowsAvailable), e.g. LOOKUP_BITS 2 at DEGREE 5: 32 limb bases for 25 usable rows, where config's
+  ceil(constants / 2^k) still says one column; with num_fixed = 2 set by hand (the last case: 5 + 2 columns, two constants columns,
+  the constants dealt out round-robin) it proves.
 Usage: python tests/golden/make_flex_wide_golden.py
 """
 import json
@@ -26,18 +28,19 @@ from oracle import fastflex as FF  # noqa: E402
 from oracle import flex as FX  # noqa: E402
 
 SRS_SECRET = MM.SRS_SECRET
-# (shape, k, lookup bits, x, seed, range checks, explicit (num_advice, num_lookup_advice) or None)
+# (shape, k, lookup bits, x, seed, range checks, explicit (num_advice, num_lookup_advice[, num_fixed]) or None)
 CASES = [("poseidon", 8, 0, 0xFEEDFACE, 17, 0, None), ("poseidon", 9, 0, 0xABCDEF, 23, 0, None),
          ("range", 6, 4, 0xDEADBEEFCAFE1234, 31, 8, None), ("range", 6, 4, 0x0123456789ABCDEF, 41, 10, (11, 8)),
-         ("range", 7, 4, 0x0F1E2D3C4B5A6978, 43, 24, None)]
+         ("range", 7, 4, 0x0F1E2D3C4B5A6978, 43, 24, None), ("range", 5, 2, 0xDEADBEEFCAFE1234, 47, 1, (5, 2, 2))]
 
 
 def build(shape, k, bits, x, count, explicit):
     if shape != "range":
         return MM.build(shape, k, bits, x)
     t, _ = FX._range_many_table(FX.range_many_values(x, count), bits)
-    A, Lc = explicit if explicit else FX.multi_column_counts(len(t.rows), len(t.lookups), k)
-    cs = FX.flex_multi_cs(True, A, Lc)
+    A, Lc = explicit[:2] if explicit else FX.multi_column_counts(len(t.rows), len(t.lookups), k)
+    Fc = explicit[2] if explicit and len(explicit) > 2 else FX.num_fixed_columns(t, k)
+    cs = FX.flex_multi_cs(True, A, Lc, Fc)
     return cs, FX.range_many_assignment_multi(cs, x, bits, k, count)
 
 
@@ -53,7 +56,7 @@ def main():
             bkeys = FX.Keys(cs, k, SRS_SECRET, asg.fixed, asg.copies)
             assert FX.prove(bkeys, asg, seed)["proof"] == r["proof"] and bkeys.vk_bytes() == keys.vk_bytes()
         out["cases"].append({"shape": shape, "k": k, "lookup_bits": bits, "x": "0x%x" % x, "seed": seed, "count": count, "explicit": explicit is not None,
-                             "num_advice": cs.num_advice, "num_lookup_advice": cs.num_lookup_advice,
+                             "num_advice": cs.num_advice, "num_lookup_advice": cs.num_lookup_advice, "num_fixed": cs.num_fixed,
                              "instance": ["0x%x" % v for v in asg.instance[0]], "vk_bytes": keys.vk_bytes().hex(), "proof": r["proof"].hex()})
         print(shape, k, bits, cs.num_advice, cs.num_lookup_advice, len(r["proof"]), flush=True)
     with open(os.path.join(HERE, "flex_wide_proofs.json"), "w") as f:

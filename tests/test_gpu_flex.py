@@ -409,7 +409,8 @@ def test_multi_column_proofs_match_oracle_and_golden(gpu):
 def test_wide_column_counts_match_golden(gpu):
     """round 5: the prover ABI's column limits (32 gate columns, 8 lookup-advice columns, 64 permutation columns, 192 queries) —
     poseidon at DEGREE 8 / 9 (31 / 15 gate columns through `flex.configure`), 8 and 24 range checks in one context at DEGREE 6 / 7
-    (8 + 3 and 11 + 4 columns), 10 range checks over 11 + 8 columns set by hand (eight lookup arguments).  Keys and proof bytes equal
+    (8 + 3 and 11 + 4 columns), 10 range checks over 11 + 8 columns set by hand (eight lookup arguments), one over 5 + 2 columns with
+    TWO constants columns (the constants dealt out round-robin).  Keys and proof bytes equal
     the committed golden (tests/golden/flex_wide_proofs.json, made by the oracle's vector engine and re-verified on the CPU by
     tests/test_oracle_fast.py); the oracle's verifier accepts the device proof and refuses another public input; the C++ host
     (its own Context / configure over the same prover ABI) prints the same bytes.  A configuration whose constants overflow the
@@ -433,10 +434,10 @@ def test_wide_column_counts_match_golden(gpu):
         shape, k, bits, x, seed, count = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16), case["seed"], case["count"]
         closure = ((lambda cs: flex.range_closure(cs, x, bits, count)) if shape == "range" else (lambda cs: poseidon.hash_two_closure(cs, x, x + 1)))
         if case["explicit"]:
-            cs = flex.FlexGateCS(True, case["num_advice"], case["num_lookup_advice"], k=k)
+            cs = flex.FlexGateCS(True, case["num_advice"], case["num_lookup_advice"], k=k, num_fixed=case["num_fixed"])
         else:
             cs = flex.configure(shape == "range", k, closure)
-        assert (cs.num_advice, cs.num_lookup_advice) == (case["num_advice"], case["num_lookup_advice"])
+        assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (case["num_advice"], case["num_lookup_advice"], case["num_fixed"])
         asg = closure(cs)
         flex.mock(asg)
         assert asg.instance == [int(v, 16) for v in case["instance"]]
@@ -447,7 +448,7 @@ def test_wide_column_counts_match_golden(gpu):
         proof = flex.create_proof(params, keys, asg, seed, ws=ws)
         assert proof.hex() == case["proof"], (shape, k, cs.num_advice, cs.num_lookup_advice)
         assert flex.create_proof(params, keys, asg, seed, ws=ws) == proof  # the workspace is reusable at these widths too
-        ocs, oasg = MW.build(shape, k, bits, x, count, (cs.num_advice, cs.num_lookup_advice) if case["explicit"] else None)
+        ocs, oasg = MW.build(shape, k, bits, x, count, (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) if case["explicit"] else None)
         vk = FX.VerifierKeys(ocs, k, secret, oasg.fixed, oasg.copies)
         assert FX.verify(vk, proof, oasg.instance) and not FX.verify(vk, proof, [[v ^ 1 for v in oasg.instance[0]]])
         ws.release()
@@ -455,14 +456,16 @@ def test_wide_column_counts_match_golden(gpu):
         params.release()
         argv = [os.path.join(root, "examples", "halo2_lib"), shape, str(k), str(bits), str(x), hex(secret), str(seed), str(max(count, 1))]
         if case["explicit"]:
-            argv += [str(cs.num_advice), str(cs.num_lookup_advice)]
+            argv += [str(cs.num_advice), str(cs.num_lookup_advice), str(cs.num_fixed)]
         r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1000:]
         out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ", "columns ")))
         assert out["columns"] == f"{cs.num_advice} gate + {cs.num_lookup_advice} lookup-advice"
         assert out["vk"] == case["vk_bytes"] and out["proof"] == case["proof"], ("C++", shape, k)
-    # 32 limb bases (LOOKUP_BITS 2) do not fit the 25 usable rows of a DEGREE-5 constants column
-    cs = flex.FlexGateCS(True, 5, 2, k=5)
+    # 32 limb bases (LOOKUP_BITS 2) do not fit the 25 usable rows of a DEGREE-5 constants column, and config's ceil(32 / 2^5) says one
+    # column (the golden's last case sets two by hand)
+    cs = flex.configure(True, 5, lambda c: flex.range_closure(c, 0xDEADBEEFCAFE1234, 2))
+    assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (5, 2, 1)
     asg = flex.range_closure(cs, 0xDEADBEEFCAFE1234, 2)
     params = gpu.ParamsKZG.setup(5, secret)
     with pytest.raises(RuntimeError, match="(?i)range|rows"):

@@ -156,11 +156,12 @@ def test_wide_golden_fixture_is_self_consistent():
     secret = int(g["srs_secret"], 16)
     shapes = {(c["num_advice"], c["num_lookup_advice"]) for c in g["cases"]}
     assert max(a for a, _ in shapes) >= 31 and max(l for _, l in shapes) == 8  # the limits of include/h2mi_prover.h are exercised
+    assert any(c["num_fixed"] == 2 for c in g["cases"])  # and two constants columns
     for case in g["cases"]:
         shape, k, bits, x = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16)
-        explicit = (case["num_advice"], case["num_lookup_advice"]) if case["explicit"] else None
+        explicit = (case["num_advice"], case["num_lookup_advice"], case["num_fixed"]) if case["explicit"] else None
         cs, asg = MW.build(shape, k, bits, x, case["count"], explicit)
-        assert (cs.num_advice, cs.num_lookup_advice) == (case["num_advice"], case["num_lookup_advice"])
+        assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (case["num_advice"], case["num_lookup_advice"], case["num_fixed"])
         assert ["0x%x" % v for v in asg.instance[0]] == case["instance"]
         proof = bytes.fromhex(case["proof"])
         vk = FX.VerifierKeys(cs, k, secret, asg.fixed, asg.copies)
@@ -169,7 +170,7 @@ def test_wide_golden_fixture_is_self_consistent():
         bad = bytearray(proof)
         bad[len(bad) // 2] ^= 1
         assert not FX.verify(vk, bytes(bad), asg.instance)
-        if shape == "range" and k == 6:
+        if shape == "range" and k <= 6:
             keys = FF.Keys(cs, k, secret, asg.fixed, asg.copies)
             assert FF.prove(keys, asg, case["seed"])["proof"] == proof
 
