@@ -23,7 +23,13 @@ use halo2_proofs::{
     },
     transcript::{Blake2bWrite, Challenge255, EncodedChallenge, Transcript, TranscriptWrite, TranscriptWriterBuffer},
 };
+use halo2_base::{
+    gates::{GateChip, GateInstructions, RangeChip, RangeInstructions},
+    AssignedValue, Context,
+    QuantumCell::{Constant, Existing, Witness},
+};
 use halo2_scaffold::circuits::standard_plonk::StandardPlonk;
+use halo2_scaffold::scaffold::gen_key;
 use rand::SeedableRng;
 use rand_chacha::ChaCha20Rng;
 
@@ -52,6 +58,48 @@ fn point(p: &G1Affine) -> String {
 }
 fn list(v: Vec<String>) -> String {
     format!("[{}]", v.iter().map(|s| format!("\"{}\"", s)).collect::<Vec<_>>().join(", "))
+}
+
+/// the instruction sequence of the reference's examples/halo2_lib.rs:14-60 (x^2 + 72 three ways; x and the first result public)
+fn halo2_lib_body(ctx: &mut Context<Fr>, x: Fr, make_public: &mut Vec<AssignedValue<Fr>>) {
+    let x = ctx.load_witness(x);
+    make_public.push(x);
+    let gate = GateChip::<Fr>::default();
+    let x_sq = gate.mul(ctx, x, x);
+    let c = Fr::from(72);
+    let out = gate.add(ctx, x_sq, Constant(c));
+    make_public.push(out);
+    let val = *x.value() * x.value() + c;
+    ctx.assign_region_last([Constant(c), Existing(x), Existing(x), Witness(val)], [0]);
+    gate.mul_add(ctx, x, x, Constant(c));
+}
+/// the instruction sequence of examples/range.rs:10-34 (x public; range_check(x, 64); x + x)
+fn range_body(ctx: &mut Context<Fr>, x: Fr, make_public: &mut Vec<AssignedValue<Fr>>) {
+    let lookup_bits = std::env::var("LOOKUP_BITS").unwrap().parse().unwrap();
+    let x = ctx.load_witness(x);
+    make_public.push(x);
+    let range = RangeChip::default(lookup_bits);
+    range.range_check(ctx, x, 64);
+    range.gate().add(ctx, x, x);
+}
+
+/// keygen through the reference's scaffold::gen_key at DEGREE / LOOKUP_BITS -> (fixed commitments, permutation commitments, break
+/// points of phase 0, the FLEX_GATE_CONFIG_PARAMS builder.config left in the environment)
+fn keygen_case(degree: &str, lookup_bits: Option<&str>) -> (String, String, String, String) {
+    std::env::set_var("DEGREE", degree);
+    match lookup_bits {
+        Some(b) => std::env::set_var("LOOKUP_BITS", b),
+        None => std::env::remove_var("LOOKUP_BITS"),
+    }
+    let (pk, break_points) =
+        if lookup_bits.is_some() { gen_key(range_body, Fr::from(0xdeadbeefcafe1234u64)) } else { gen_key(halo2_lib_body, Fr::from(12)) };
+    let vk = pk.get_vk();
+    (
+        list(vk.fixed_commitments().iter().map(point).collect()),
+        list(vk.permutation().commitments().iter().map(point).collect()),
+        format!("{:?}", break_points[0]),
+        std::env::var("FLEX_GATE_CONFIG_PARAMS").unwrap_or_default(),
+    )
 }
 
 fn main() {
@@ -144,11 +192,30 @@ fn main() {
     let proof = transcript.finalize();
     put("proof5_len", format!("{}", proof.len()));
 
+    // ---- the halo2-lib builders through the reference's own scaffold::gen_key (src/scaffold.rs:95-155; it reads DEGREE / LOOKUP_BITS
+    // from the environment, takes the column counts from builder.config(k, Some(9)) and the SRS from gen_srs(k) — the same
+    // fixed-seed SRS as above, cached under ./params): the verifying key's commitments pin halo2-base's layout conventions, the
+    // break points the rule that ends a gate column.  The closures are the reference's two examples.
+    let (f, p, b, c1) = keygen_case("5", None);
+    put("halo2lib_k5_fixed_commitments", f);
+    put("halo2lib_k5_permutation_commitments", p);
+    put("halo2lib_k5_break_points_phase0", b);
+    let (f, p, b, c2) = keygen_case("7", Some("4"));
+    put("range_k7_bits4_fixed_commitments", f);
+    put("range_k7_bits4_permutation_commitments", p);
+    put("range_k7_bits4_break_points_phase0", b);
+    let (f, p, b, c3) = keygen_case("5", Some("4"));
+    put("range_k5_bits4_fixed_commitments", f);
+    put("range_k5_bits4_permutation_commitments", p);
+    put("range_k5_bits4_break_points_phase0", b);
+    let flex_config = vec![format!("\"halo2lib_k5\": {:?}", c1), format!("\"range_k7_bits4\": {:?}", c2), format!("\"range_k5_bits4\": {:?}", c3)];
+
     // informational: no expectation exists for these
     let info = format!(
-        "{{\"vk5_pinned_debug\": {:?}, \"proof5_hex\": \"{}\"}}",
+        "{{\"vk5_pinned_debug\": {:?}, \"proof5_hex\": \"{}\", \"flex_gate_config_params\": {{{}}}}}",
         pinned,
-        hex(&proof)
+        hex(&proof),
+        flex_config.join(", ")
     );
     put("informational", info);
 

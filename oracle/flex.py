@@ -211,6 +211,21 @@ class _Table:
         return asg
 
 
+def break_point_rows(t: _Table, k: int, minimum_rows: int = 9):
+    """the rows at which halo2-base's assign_threads leaves a gate column (`break_points[0]`, what scaffold::gen_key returns next to
+    the proving key, src/scaffold.rs:95-155) [RECALL]: the row offset of every cell that is assigned a second time at row 0 of the
+    next column — the same scan as multi_column_assignment's break indices, reported per column instead of per cell"""
+    max_rows = (1 << k) - minimum_rows
+    gate_start = set(t.gates)
+    rows, first = [], 0
+    for i in range(len(t.rows)):
+        r = i - first
+        if (i in gate_start and r + 4 > max_rows) or r >= max_rows - 1:
+            rows.append(r)
+            first = i
+    return rows
+
+
 def multi_column_assignment(t: _Table, cs, public_rows, k: int, minimum_rows: int = 9):
     """the flat cell list of a closure laid over cs.num_advice gate columns as halo2-base's assign_all does [RECALL builder.rs]:
     cells go down the current column; after placing a cell at row r the column is full when r >= max_rows - 1, or when the cell

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import bn254 as o  # noqa: E402
 from oracle import formats as fmt  # noqa: E402
+from oracle import flex as FX  # noqa: E402
 from oracle import prover as OP  # noqa: E402
 
 R, Q = o.R, o.Q
@@ -88,6 +89,27 @@ def expectations() -> dict:
     e["vk5_fixed_commitments"] = [fmt.g1_to_bytes(p).hex() for p in pk.fixed_commitments]
     e["vk5_permutation_commitments"] = [fmt.g1_to_bytes(p).hex() for p in pk.permutation_commitments]
     e["proof5_len"] = 992
+    # ---- the halo2-lib builders through the reference's own scaffold::gen_key (src/scaffold.rs:95-155): what pins halo2-base's
+    # layout conventions (column order, selector columns, constants in first-use order, constrain_equal order, the break-point rule)
+    pts = lambda cms: [fmt.g1_to_bytes(p).hex() for p in cms]
+    cs = FX.flex_gate_cs(False)  # examples/halo2_lib.rs at DEGREE 5: 17 cells, one gate column
+    asg = FX.halo2_lib_assignment(cs, 12)
+    vk = FX.VerifierKeys(cs, 5, s, asg.fixed, asg.copies)
+    e["halo2lib_k5_fixed_commitments"], e["halo2lib_k5_permutation_commitments"] = pts(vk.fixed_commitments), pts(vk.permutation_commitments)
+    e["halo2lib_k5_break_points_phase0"] = []
+    x = 0xDEADBEEFCAFE1234
+    cs = FX.flex_gate_cs(True)  # examples/range.rs at DEGREE 7, LOOKUP_BITS 4: one gate column, the q_lookup form
+    asg = FX.range_assignment(cs, x, 4, 1 << 7)
+    vk = FX.VerifierKeys(cs, 7, s, asg.fixed, asg.copies)
+    e["range_k7_bits4_fixed_commitments"], e["range_k7_bits4_permutation_commitments"] = pts(vk.fixed_commitments), pts(vk.permutation_commitments)
+    e["range_k7_bits4_break_points_phase0"] = []
+    t = FX._range_table(x, 4)  # the same at DEGREE 5: 51 cells over 23-row columns, three gate columns + one lookup-advice column
+    A, Lc = FX.multi_column_counts(len(t.rows), len(t.lookups), 5)
+    cs = FX.flex_multi_cs(True, A, Lc, FX.num_fixed_columns(t, 5))
+    asg = FX.range_assignment_multi(cs, x, 4, 5)
+    vk = FX.VerifierKeys(cs, 5, s, asg.fixed, asg.copies)
+    e["range_k5_bits4_fixed_commitments"], e["range_k5_bits4_permutation_commitments"] = pts(vk.fixed_commitments), pts(vk.permutation_commitments)
+    e["range_k5_bits4_break_points_phase0"] = FX.break_point_rows(t, 5)
     return e
 
 
@@ -101,6 +123,10 @@ NOTES = {
         "transcript_*": "Blake2b personalisation / prefix bytes / Challenge255 reduction (halo2-scaffold_amd/transcript.py, include/h2mi_transcript.hpp)",
         "srs5_*": "gen_srs: rng seed, Fr::random's use of the keystream, or the Lagrange basis (halo2-scaffold_amd/params.py gen_srs_secret)",
         "vk5_*": "the circuit's fixed cells / copy-constraint order / sigma construction (oracle/plonk.py, csrc/h2mi_prover.cpp keygen)",
+        "halo2lib_* / range_*": "halo2-base's layout as restated in oracle/flex.py (and halo2-scaffold_amd/flex.py, include/h2mi_flex.hpp): the number of "
+                                "commitments = the column counts and their order; *_fixed_commitments = selector columns, constants in first-use order, the "
+                                "table; *_permutation_commitments = enable_equality order and the order of constrain_equal calls; *_break_points = the rule "
+                                "that ends a gate column (a differing list length means a different column count from builder.config)",
     },
 }
 
