@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
     if (const char* np = std::getenv("H2MI_PROOFS")) {  // steady state: N more proofs through the same workspace (bench.py reads the line)
       const int count = std::max(1, std::atoi(np));  // 0 or a non-number: one proof, never a division by zero
       check(h2mi_sync(), "sync");
+      ws.time_phases = std::getenv("H2MI_PHASES") != nullptr;  // untraced host-side phase clock (ProverWorkspace::phase_us)
       const auto t0 = Clock::now();
       for (int i = 0; i < count; i++) {
         auto transcript = transcript::Blake2bWrite::init();
@@ -90,6 +91,9 @@ int main(int argc, char** argv) {
         transcript.finalize();
       }
       std::printf("steady_ms_per_proof %.4f over %d proofs\n", std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / count, count);
+      if (ws.time_phases)
+        std::printf("phase_us advice %.1f lookups %.1f products %.1f quotient %.1f evaluations %.1f shplonk_1 %.1f shplonk_2 %.1f\n", ws.phase_us[0] / count,
+                    ws.phase_us[1] / count, ws.phase_us[2] / count, ws.phase_us[3] / count, ws.phase_us[4] / count, ws.phase_us[5] / count, ws.phase_us[6] / count);
     }
     std::printf("vk %s\n", hex(pk->vk.to_bytes()).c_str());
     for (const Fr& v : asg.instance) {

@@ -89,6 +89,31 @@ H2_HD void xyzz29_madd(xyzz29& acc, const f29& x2, const f29& y2) {
   acc.zzz = f29_mul<F>(acc.zzz, ppp);
 }
 
+// ---- batched-affine pair addition (round 5 experiment: see "pair-affine accumulation" in h2mi_msm.hip) ------------------------------
+// Two table points of one bucket are added in AFFINE coordinates, the inversion of x2 - x1 shared by every pair of the launch
+// (Montgomery's trick, hierarchically): 5 multiplications + 1 squaring per pair instead of a second mixed addition (8M + 2S).
+// d = x2 - x1 + 2p for canonical x's: normalized, 0 < value < 3p, nonzero modulo p whenever x1 != x2
+H2_HD f29 affine29_pair_diff(const f29& x1, const f29& x2) { return f29_normalize(f29_sub(x2, x1, Fq29::K2)); }
+// (x3, y3) = (x1, s1 y1) + (x2, s2 y2) with dinv = 1 / (x2 - x1) (normalized, < 1.1p); x, y canonical table coordinates, neg = the
+// entry's sign bit.  Out: x3 normalized < 5.1p, y3 lazy (limbs < 1.5 * 2^30) < 3.1p — within what xyzz29_madd takes as (x2, y2):
+//   dy  = s2 y2 - s1 y1                    < 4p (normalized)
+//   lam = dy * dinv                        < 1 + eps * 4 * 1.1
+//   x3  = lam^2 - (x1 + x2) + 4p           < 5.02      (the 2^31-biased 4p: the subtrahend is a lazy sum)
+//   t   = x1 - x3 + 6p                     < 7.02      (lazy operand, as T in xyzz29_madd)
+//   y3  = t * lam - s1 y1                  < 1.05 + 2p (s1 = +: minus the canonical y1 with the 2p bias; s1 = -: plus y1)
+H2_HD void affine29_pair_add(const f29& x1, const f29& y1, bool neg1, const f29& x2, const f29& y2, bool neg2, const f29& dinv, f29& x3, f29& y3) {
+  using F = Fq29;
+  f29 dy;
+  if (neg1 == neg2) dy = neg2 ? f29_sub(y1, y2, F::K2) : f29_sub(y2, y1, F::K2);
+  else dy = neg2 ? f29_sub(f29_zero(), f29_add(y1, y2), F::KW4) : f29_add(y1, y2);
+  const f29 lam = f29_mul<F>(f29_normalize(dy), dinv);
+  const f29 ll = f29_sqr<F>(lam);
+  x3 = f29_normalize(f29_sub(ll, f29_add(x1, x2), F::KW4));
+  const f29 t = f29_sub(x1, x3, F::K6);
+  const f29 m = f29_mul<F>(t, lam);
+  y3 = neg1 ? f29_add(m, y1) : f29_sub(m, y1, F::K2);
+}
+
 // 2 * p (XYZZ, dbl-2008-s-1).  Invariant in / out: X < 6, Y < 4, ZZ, ZZZ < 1.5 (units of p), normalized.
 //   U = 2Y < 8    V = U^2 < 1.38    W = U*V < 1.07    S = X*V < 1.05    M = 3X^2 < 3.64
 //   X3 = M^2 - 2S + 4p < 5.1    T = S - X3 + 6p < 7.1    Y3 = (M*T + W*(4p - Y)) / 2^261 < 1.2    ZZ3, ZZZ3 < 1.02

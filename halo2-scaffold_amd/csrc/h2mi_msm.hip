@@ -102,6 +102,9 @@ struct Slot {
   uint32_t* scnt = nullptr;
   bool small_deferred = false;  // the deferred work of this slot is the small path's accumulate + final pair
   uint32_t small_n = 0;         // points of that MSM
+  // pair-affine accumulation (H2MI_MSM_PA, used by the -DH2MI_AB library only): products before each pair [PA_MAX_PAIRS][9][pa_T], chunk totals [9][pa_T]
+  uint32_t *pa_spill = nullptr, *pa_tot = nullptr;
+  uint32_t pa_T = 0;
 };
 // slots per handle = MSMs that can be in flight between two joins before a flush is forced
 // Eight for base sets up to 2^17 (round 3): with four, every fifth back-to-back MSM waited for the reduction batch of the four
@@ -781,6 +784,206 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* entries, cons
   msm_accum_body(entries, off, toff, nb, s0_dev, table, part);
 }
 
+// ---- pair-affine accumulation (round 5 experiment; selected with H2MI_MSM_PA in the -DH2MI_AB library only) ------------------------
+// The accumulation spends 1467 multiply-adds per entry on a mixed XYZZ addition.  Two table points of the same bucket can instead be
+// added in AFFINE coordinates first — 5 multiplications and a squaring (936 multiply-adds) once the inverse of x2 - x1 is known — and
+// only their sum enters the accumulator: 2403 instead of 2934 multiply-adds per pair (-18 %).  The inverses are shared by EVERY pair of
+// the launch (Montgomery's trick in two levels), which takes three kernels:
+//   k_msm_pa_forward   per chunk (the accumulation's chunks): running product of the pairs' x2 - x1, the product BEFORE each pair
+//                      spilled (36 B per pair, lane-contiguous), the chunk's total written out.  Gathers every table point's x.
+//   k_msm_pa_invert    the inverses of the chunk totals: per workgroup 1024 totals, prefix / suffix products, ONE division-step inversion
+//   k_msm_pa_backward  the accumulation itself, walking its chunk BACKWARDS (the order in which Montgomery's trick releases the
+//                      inverses): pair sum in affine coordinates, then one mixed addition; same partial sums, same layout as
+//                      k_msm_accum (partials are numbered in array order, so walking down decrements the index)
+// Pairs are (start + 2j, start + 2j + 1) of a chunk; a pair that straddles a bucket boundary, holds an identity or two points with
+// the same x (P + P, P - P) is not combined: both kernels decide that from the same data and the backward pass adds such entries one
+// by one, exactly as k_msm_accum does.
+// Price: every table point is gathered twice and 72 B per pair are spilled and read back — 2.6 GB instead of 0.9 GB per 2^20 MSM.
+// MEASURED (profiles/r05_pair_affine_ab.txt, tools/pa_ab.py): a loss everywhere.  2^20: forward 0.46 ms + inversions 0.09 ms, and the
+// backward pass itself takes 1.31 ms against k_msm_accum's 1.11 ms although it issues 18 % fewer multiply-adds — two gathers and a
+// spill read per pair at 256 VGPRs leave the latency uncovered; back to back 1.76 against 1.27 ms per MSM, alone 2.34 against 1.62.
+// Kept in the A/B library (make ab) as the measured form of the estimate in HISTORY.md; the product does not contain it.
+#ifdef H2MI_AB
+constexpr uint32_t PA_MAX_PAIRS = S0_MAX / 2;
+__device__ __forceinline__ bool words_equal8(const uint32_t* a, const uint32_t* b) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d |= a[i] ^ b[i];
+  return d == 0;
+}
+__device__ __forceinline__ bool words_zero8(const uint32_t* a) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d |= a[i];
+  return d == 0;
+}
+// can the two table points be added by the affine formula?  (decided identically by the forward and the backward pass)
+__device__ __forceinline__ bool pa_pair_ok(const tab_entry& p0, const tab_entry& p1) {
+  return !words_zero8(p0.x.v) && !words_zero8(p1.x.v) && !words_equal8(p0.x.v, p1.x.v);
+}
+__device__ __forceinline__ void pa_store(uint32_t* base, uint32_t T, uint32_t t, const f29& a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) base[(size_t)i * T + t] = a.v[i];
+}
+__device__ __forceinline__ f29 pa_load(const uint32_t* base, uint32_t T, uint32_t t) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = base[(size_t)i * T + t];
+  return r;
+}
+__global__ void __launch_bounds__(256) k_msm_pa_forward(const uint32_t* entries, const uint32_t* off, uint32_t nb, const uint32_t* s0_dev,
+                                                         const uint8_t* table, uint32_t T, uint32_t* spill, uint32_t* tot) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const uint32_t total = off[nb];
+  const uint32_t s0 = *s0_dev;
+  f29 prod = f29_const<Fq29>(Fq29::ONE);
+  if ((uint64_t)t * s0 < total && s0 <= 2 * PA_MAX_PAIRS) {
+    const uint32_t start = t * s0;
+    const uint32_t end = min(start + s0, total);
+    uint32_t b = find_bucket(off, nb, start);
+    uint32_t bend = off[b + 1];
+    tab_entry n0, n1;
+    if (start + 1 < end) {
+      n0 = tab_load(table, entries[start] & 0x7fffffffu);
+      n1 = tab_load(table, entries[start + 1] & 0x7fffffffu);
+    }
+    for (uint32_t k = start, j = 0; k + 1 < end; k += 2, j++) {
+      const tab_entry p0 = n0, p1 = n1;
+      if (k + 3 < end) {  // the next pair's points travel while this pair's product is formed
+        n0 = tab_load(table, entries[k + 2] & 0x7fffffffu);
+        n1 = tab_load(table, entries[k + 3] & 0x7fffffffu);
+      }
+      while (k >= bend) {
+        b++;
+        bend = off[b + 1];
+      }
+      if (k + 1 >= bend || !pa_pair_ok(p0, p1)) continue;
+      pa_store(spill + (size_t)j * 9 * T, T, t, prod);
+      prod = f29_mul<Fq29>(prod, affine29_pair_diff(tab_x(p0), tab_x(p1)));
+    }
+  }
+  pa_store(tot, T, t, prod);
+}
+// tot[t] <- 1 / tot[t] for t < T: 1024 values per workgroup of 256 threads
+__global__ void __launch_bounds__(256) k_msm_pa_invert(uint32_t* tot, uint32_t T) {
+  __shared__ f29 pre[256], suf[256];
+  __shared__ f29 winv;
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * 1024;
+  f29 v[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t idx = base + i * 256 + tid;
+    v[i] = idx < T ? pa_load(tot, T, idx) : f29_const<Fq29>(Fq29::ONE);
+    q[i] = i ? f29_mul<Fq29>(q[i - 1], v[i]) : v[i];
+  }
+  pre[tid] = q[3];
+  suf[tid] = q[3];
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive prefix products in pre, inclusive suffix products in suf
+    f29 a, c;
+    if (tid >= d) a = pre[tid - d];
+    if (tid + d < 256) c = suf[tid + d];
+    __syncthreads();
+    if (tid >= d) pre[tid] = f29_mul<Fq29>(pre[tid], a);
+    if (tid + d < 256) suf[tid] = f29_mul<Fq29>(suf[tid], c);
+    __syncthreads();
+  }
+  if (tid < 64) {  // every lane of the first wavefront on the same value: uniform branches.  (W 2^261) read as Montgomery-2^256 is
+                   // (32 W) 2^256; its inverse times 2^10 is W^-1 2^261
+    fe w;
+    f29_pack(f29_reduce_canonical<Fq29>(pre[255]), w.v);
+    fe inv = fe_inv_ds<Fq>(w);
+    for (int i = 0; i < 10; i++) inv = fe_dbl<Fq>(inv);
+    if (tid == 0) winv = f29_unpack(inv.v);
+  }
+  __syncthreads();
+  f29 r = winv;  // -> 1 / q[3] of this thread: the workgroup's inverse times everyone else's totals
+  if (tid) r = f29_mul<Fq29>(r, pre[tid - 1]);
+  if (tid < 255) r = f29_mul<Fq29>(r, suf[tid + 1]);
+#pragma unroll
+  for (int i = 3; i >= 0; i--) {
+    const uint32_t idx = base + i * 256 + tid;
+    const f29 inv_i = i ? f29_mul<Fq29>(r, q[i - 1]) : r;
+    if (i) r = f29_mul<Fq29>(r, v[i]);
+    if (idx < T) pa_store(tot, T, idx, inv_i);
+  }
+}
+__global__ void __launch_bounds__(256) k_msm_pa_backward(const uint32_t* entries, const uint32_t* off, const uint32_t* toff, uint32_t nb,
+                                                          const uint32_t* s0_dev, const uint8_t* table, uint8_t* part, uint32_t T,
+                                                          const uint32_t* spill, const uint32_t* totinv) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = off[nb];
+  const uint32_t s0 = *s0_dev;
+  if (t >= T || (uint64_t)t * s0 >= total) return;
+  const uint32_t start = t * s0;
+  const uint32_t end = min(start + s0, total);
+  const bool pairs_on = s0 <= 2 * PA_MAX_PAIRS;  // longer chunks (a chunk override): the forward pass combined nothing
+  uint32_t b = find_bucket(off, nb, end - 1);  // the bucket that holds the chunk's LAST entry
+  uint32_t bstart = off[b];
+  uint32_t pidx = toff[b] + (t - off[b] / s0);
+  xyzz29 acc = xyzz29_identity();
+  f29 run = pa_load(totinv, T, t);
+  // make `idx` (below every entry handled so far) an entry of the current bucket: crossing a boundary closes a partial sum
+  auto cross = [&](uint32_t idx) {
+    if (idx >= bstart) return;
+    part_store(part + (size_t)pidx * PART_BYTES, acc);
+    pidx--;
+    acc = xyzz29_identity();
+    do {
+      b--;
+    } while (off[b] > idx);
+    bstart = off[b];
+  };
+  auto single = [&](const tab_entry& p, uint32_t neg) {
+    if (tab_is_identity(p)) return;
+    f29 y = tab_y(p);
+    if (neg) y = f29_sub(f29_zero(), y, Fq29::K2);
+    xyzz29_madd(acc, tab_x(p), y);
+  };
+  uint32_t hi = end;  // entries [hi, end) are done
+  if ((end - start) & 1u) {
+    const uint32_t e = entries[end - 1];
+    single(tab_load(table, e & 0x7fffffffu), e >> 31);
+    hi = end - 1;
+  }
+  uint32_t e0 = 0, e1 = 0;
+  tab_entry n0, n1;
+  if (hi > start) {
+    e0 = entries[hi - 2];
+    e1 = entries[hi - 1];
+    n0 = tab_load(table, e0 & 0x7fffffffu);
+    n1 = tab_load(table, e1 & 0x7fffffffu);
+  }
+  for (uint32_t k1 = hi; k1 > start; k1 -= 2) {  // the pair (k1 - 2, k1 - 1), j = (k1 - 2 - start) / 2
+    const uint32_t k0 = k1 - 2, j = (k0 - start) >> 1;
+    const tab_entry p0 = n0, p1 = n1;
+    const uint32_t neg0 = e0 >> 31, neg1 = e1 >> 31;
+    if (k0 > start) {
+      e0 = entries[k0 - 2];
+      e1 = entries[k0 - 1];
+      n0 = tab_load(table, e0 & 0x7fffffffu);
+      n1 = tab_load(table, e1 & 0x7fffffffu);
+    }
+    cross(k0 + 1);
+    if (pairs_on && k0 >= bstart && pa_pair_ok(p0, p1)) {
+      const f29 before = pa_load(spill + (size_t)j * 9 * T, T, t);
+      const f29 x0 = tab_x(p0), x1 = tab_x(p1);
+      const f29 dinv = f29_mul<Fq29>(run, before);
+      run = f29_mul<Fq29>(run, affine29_pair_diff(x0, x1));
+      f29 x3, y3;
+      affine29_pair_add(x0, tab_y(p0), neg0 != 0, x1, tab_y(p1), neg1 != 0, dinv, x3, y3);
+      xyzz29_madd(acc, x3, y3);
+    } else {
+      single(p1, neg1);
+      cross(k0);
+      single(p0, neg0);
+    }
+  }
+  part_store(part + (size_t)pidx * PART_BYTES, acc);
+}
+#endif  // H2MI_AB
+
 // ---- batched head: the partition and the accumulation of up to HEAD_BATCH MSMs of one length over ONE base set as ONE set of launches
 // (blockIdx.y = MSM; round 4).  At 2^16 rows and below a prover phase's three or four commitments were issued at the HOST's pace: eight
 // launches and six event operations per MSM, ~77 us each on the compiled host, while the kernels themselves run 4 - 13 us (proof
@@ -1391,6 +1594,7 @@ static void free_bases(Bases* B) {
     H2_IGNORE(hipFree(S.vals[0])); H2_IGNORE(hipFree(S.vals[1]));
     H2_IGNORE(hipFree(S.bkeys)); H2_IGNORE(hipFree(S.bincnt)); H2_IGNORE(hipFree(S.binbase)); H2_IGNORE(hipFree(S.binseg)); H2_IGNORE(hipFree(S.tile_live));
     H2_IGNORE(hipFree(S.off)); H2_IGNORE(hipFree(S.s0_dev));
+    if (S.pa_spill) { H2_IGNORE(hipFree(S.pa_spill)); H2_IGNORE(hipFree(S.pa_tot)); }
     for (int i = 0; i < 2; i++) { H2_IGNORE(hipFree(S.np[i])); H2_IGNORE(hipFree(S.toff[i])); }
     H2_IGNORE(hipFree(S.dense)); H2_IGNORE(hipFree(S.dense2)); H2_IGNORE(hipFree(S.vsum)); H2_IGNORE(hipFree(S.tseg[0])); H2_IGNORE(hipFree(S.tseg[1]));
     H2_IGNORE(hipFree(S.part[0])); H2_IGNORE(hipFree(S.part[1])); H2_IGNORE(hipFree(S.rc)); H2_IGNORE(hipFree(S.g)); H2_IGNORE(hipFree(S.stats)); H2_IGNORE(hipFree(S.shift));
@@ -1941,6 +2145,31 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // 56000 B holds it at two workgroups per CU and leaves half the registers and 48 KB of LDS per CU free:
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
+#ifdef H2MI_AB
+  // pair-affine accumulation (experiment, -DH2MI_AB library only): from H2MI_MSM_PA_MIN entries (default 2^22)
+  static const bool pa_on = ab_env("H2MI_MSM_PA") != nullptr;
+  static const uint32_t pa_min = ab_env("H2MI_MSM_PA_MIN") ? (uint32_t)atoll(ab_env("H2MI_MSM_PA_MIN")) : (1u << 22);
+  if (pa_on && !s0_fixed && total >= pa_min) {
+    if (S.pa_T < chunks0) {
+      if (S.pa_spill) { H2_HIP(hipFree(S.pa_spill)); H2_HIP(hipFree(S.pa_tot)); S.pa_spill = S.pa_tot = nullptr; S.pa_T = 0; }
+      const uint32_t cap = std::min(accum_rounds((uint32_t)(B->stride * W)) * ACCUM_RESIDENT_CHUNKS, (uint32_t)(B->stride * W));
+      H2_HIP(hipMalloc((void**)&S.pa_spill, (size_t)PA_MAX_PAIRS * 9 * 4 * cap));
+      H2_HIP(hipMalloc((void**)&S.pa_tot, (size_t)9 * 4 * cap));
+      S.pa_T = cap;
+    }
+    // the forward pass and the inversions belong to the head (they run beside the previous MSM's accumulation)
+    H2_LAUNCH("k_msm_pa_forward", k_msm_pa_forward, ceil_div_u32(chunks0, 256), 256, 0, hs, (const uint32_t*)S.vals[1], (const uint32_t*)S.off, nb,
+              (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, chunks0, S.pa_spill, S.pa_tot);
+    H2_LAUNCH("k_msm_pa_invert", k_msm_pa_invert, ceil_div_u32(chunks0, 1024), 256, 0, hs, S.pa_tot, chunks0);
+    if (pipelined) {
+      H2_HIP(hipEventRecord(S.head_done, hs));
+      H2_HIP(hipStreamWaitEvent(as, S.head_done, 0));
+    }
+    H2_LAUNCH("k_msm_accum", k_msm_pa_backward, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
+              (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, S.part[0], chunks0, (const uint32_t*)S.pa_spill,
+              (const uint32_t*)S.pa_tot);
+  } else
+#endif
   H2_LAUNCH("k_msm_accum", k_msm_accum, ceil_div_u32(chunks0, 256), 256, accum_lds, as, (const uint32_t*)S.vals[1], (const uint32_t*)S.off,
             (const uint32_t*)S.toff[0], nb, (const uint32_t*)S.s0_dev, (const uint8_t*)B->table, S.part[0]);
   S.d_out = d_out;

@@ -1,6 +1,7 @@
 // Host-side harness for the plain-C++ field/curve layer (halo2-scaffold_amd/csrc/f29.cuh, g1_29.cuh):
 // the same code the GPU kernels inline, compiled with g++ so the arithmetic is verified on the CPU
 // against the big-integer oracle before it ever runs on a GPU.  Test infrastructure only.
+#include <vector>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -124,6 +125,70 @@ void f29t_madd_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32
       xyzz29_add(s2, acc);              // identity + S = S
       acc = s2;
     }
+  }
+  if (xyzz29_is_identity(acc)) {
+    memset(out_xyzz, 0, 128);
+    return;
+  }
+  f29_to_mont256<Fq29>(acc.x, out_xyzz);
+  f29_to_mont256<Fq29>(acc.y, out_xyzz + 8);
+  f29_to_mont256<Fq29>(acc.zz, out_xyzz + 16);
+  f29_to_mont256<Fq29>(acc.zzz, out_xyzz + 24);
+}
+
+// the pair-affine accumulation on the host: consecutive points are added in pairs in AFFINE coordinates (affine29_pair_add, the
+// inverses of x2 - x1 by Montgomery's trick over the whole list, as the kernels share them), each pair's sum enters the XYZZ
+// accumulator by a mixed addition; a pair with equal x (P + P, P - P) or an identity member goes in as two singles — the routing
+// k_msm_pa_forward / k_msm_pa_backward apply.  Same input / output format as f29t_madd_chain.
+void f29t_pair_chain(const uint32_t* pts, const uint8_t* signs, size_t n, uint32_t* out_xyzz) {
+  std::vector<f29> xs(n), ys(n);
+  std::vector<bool> ident(n);
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t* p = pts + 16 * i;
+    bool id = true;
+    for (int k = 0; k < 16; k++) id = id && p[k] == 0;
+    ident[i] = id;
+    uint32_t xw[8], yw[8];
+    f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p)), xw);
+    f29_pack(f29_reduce_canonical<Fq29>(f29_from_mont256<Fq29>(p + 8)), yw);
+    xs[i] = f29_unpack(xw);
+    ys[i] = f29_unpack(yw);
+  }
+  auto same_x = [&](size_t a, size_t b) {
+    bool eq = true;
+    for (int k = 0; k < 9; k++) eq = eq && xs[a].v[k] == xs[b].v[k];
+    return eq;
+  };
+  const size_t npairs = n / 2;
+  std::vector<bool> valid(npairs);
+  std::vector<f29> before(npairs);
+  f29 prod = f29_const<Fq29>(Fq29::ONE);
+  for (size_t j = 0; j < npairs; j++) {
+    valid[j] = !ident[2 * j] && !ident[2 * j + 1] && !same_x(2 * j, 2 * j + 1);
+    if (!valid[j]) continue;
+    before[j] = prod;
+    prod = f29_mul<Fq29>(prod, affine29_pair_diff(xs[2 * j], xs[2 * j + 1]));
+  }
+  f29 run = f29_inv<Fq29>(prod);
+  xyzz29 acc = xyzz29_identity();
+  auto single = [&](size_t i) {
+    if (ident[i]) return;
+    f29 y = ys[i];
+    if (signs[i]) y = f29_sub(f29_zero(), y, Fq29::K2);
+    xyzz29_madd(acc, xs[i], y);
+  };
+  if (n & 1) single(n - 1);
+  for (size_t j = npairs; j-- > 0;) {
+    if (!valid[j]) {
+      single(2 * j + 1);
+      single(2 * j);
+      continue;
+    }
+    const f29 dinv = f29_mul<Fq29>(run, before[j]);
+    run = f29_mul<Fq29>(run, affine29_pair_diff(xs[2 * j], xs[2 * j + 1]));
+    f29 x3, y3;
+    affine29_pair_add(xs[2 * j], ys[2 * j], signs[2 * j] != 0, xs[2 * j + 1], ys[2 * j + 1], signs[2 * j + 1] != 0, dinv, x3, y3);
+    xyzz29_madd(acc, x3, y3);
   }
   if (xyzz29_is_identity(acc)) {
     memset(out_xyzz, 0, 128);

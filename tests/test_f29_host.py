@@ -216,3 +216,39 @@ def test_mul3_shared_reduction_at_the_contract_limits(host):
             got = val(out[i])
             assert got * (1 << 261) % mod == want % mod
             assert got < want // (1 << 261) + mod + 1
+
+
+def test_pair_affine_chain_matches_oracle(host):
+    """the pair-affine accumulation (g1_29.cuh affine29_pair_add: pairs of points added in affine coordinates with shared inversions,
+    their sums entering the XYZZ accumulator) against the oracle's group law: random points and signs, every sign combination, pairs
+    that must be routed around the affine formula (P + P, P - P, an identity member), an odd count, and the lazy-value bounds of the
+    accumulator exercised by long chains."""
+    host.f29t_pair_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(17)
+    base = [o.g1_mul(int(rng.integers(1, 1 << 62)), o.G1_GEN) for _ in range(40)]
+
+    def run(pts, signs):
+        P = o.pack_points(pts)
+        S = np.array(signs, dtype=np.uint8)
+        out = np.zeros(16, dtype=np.uint64)
+        host.f29t_pair_chain(P.ctypes.data, S.ctypes.data, len(pts), out.ctypes.data)
+        want = None
+        for p, s in zip(pts, signs):
+            want = o.g1_add(want, o.g1_neg(p) if s else p)
+        assert _xyzz_to_affine(out) == want
+
+    for n in (1, 2, 3, 4, 7, 40):
+        for trial in range(4):
+            pts = [base[int(rng.integers(0, 40))] for _ in range(n)]
+            run(pts, [int(rng.integers(0, 2)) for _ in range(n)])
+    a, b = base[0], base[1]
+    for s1 in (0, 1):
+        for s2 in (0, 1):
+            run([a, b], [s1, s2])
+            run([a, a], [s1, s2])          # doubling or cancellation: two singles
+            run([None, b], [s1, s2])       # identity members
+            run([a, None, None, b, a], [s1, s2, 0, 1, s2])
+    run([a, o.g1_neg(a)], [0, 0])
+    run([a, b, b, a, a, b], [0, 1, 0, 1, 1, 0])   # pair sums that cancel the accumulator
+    pts = [base[i % 40] for i in range(600)]
+    run(pts, [(i * 7 // 3) & 1 for i in range(600)])
