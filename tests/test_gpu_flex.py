@@ -196,6 +196,22 @@ def test_workspace_reuse_and_sliced_srs_world2(gpu):
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["proof_sha256"] == one["proof_sha256"]
     assert two["combines_per_proof"] == 6  # advice; permuted columns; z, lookup z, random; h pieces; the two SHPLONK commitments
+    # many columns (24 range checks at DEGREE 7: 11 gate + 4 lookup-advice columns): a phase now returns up to 15 points, more than the
+    # eight result slots the sliced path had until round 5 — every rank still ends with the single-process proof
+    wide = ["tools/flex_proof.py", "--shape", "range", "--k", "7", "--lookup-bits", "4", "--count", "24", "--configure", "--proofs", "2"]
+    r1 = subprocess.run([sys.executable] + wide, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["columns"] == [11, 4, 1] and one["combines_per_proof"] == 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + wide + ["--gpus", "2"]
+    r2 = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=dict(env, H2MI_DIST_BACKEND="gloo", H2MI_DEVICE="0"))
+    assert r2.returncode == 0, r2.stdout[-1000:] + r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["proof_sha256"] == one["proof_sha256"] and two["combines_per_proof"] == 6
 
 
 def _oracle_assignment(ocs, asg):

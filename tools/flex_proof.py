@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--lookup-bits", type=int, default=16)
     ap.add_argument("--x", type=lambda v: int(v, 0), default=0x0123456789ABCDEF)
     ap.add_argument("--seed", type=int, default=31337)
+    ap.add_argument("--count", type=int, default=1, help="range checks in one context (range shape): fills several columns at a small --k")
+    ap.add_argument("--configure", action="store_true", help="take the column counts builder.config(k, Some(9)) would (flex.configure)")
     ap.add_argument("--proofs", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--kernels", action="store_true", help="one more proof with events around every launch: per-kernel device time")
@@ -60,15 +62,16 @@ def main():
 
     h2.init(local_rank)
     lookup = args.shape == "range"
-    cs = flex.FlexGateCS(lookup=lookup)
     if args.shape == "poseidon":
         from halo2_scaffold_amd import poseidon
 
-        closure = lambda x: poseidon.hash_two_closure(cs, x, x ^ 0x5A5A5A5A)
+        build = lambda c, x: poseidon.hash_two_closure(c, x, x ^ 0x5A5A5A5A)
     elif lookup:
-        closure = lambda x: flex.range_closure(cs, x, args.lookup_bits)
+        build = lambda c, x: flex.range_closure(c, x, args.lookup_bits, args.count)
     else:
-        closure = lambda x: flex.halo2_lib_closure(cs, x)
+        build = lambda c, x: flex.halo2_lib_closure(c, x)
+    cs = flex.configure(lookup, args.k, lambda c: build(c, args.x)) if args.configure else flex.FlexGateCS(lookup=lookup)
+    closure = lambda x: build(cs, x)
     t0 = time.perf_counter()
     full = ParamsKZG.setup(args.k, SRS_SECRET)
     check(lib.h2mi_sync(), "sync")
@@ -141,7 +144,7 @@ def main():
         print(json.dumps({
             "circuit": args.shape, "k": args.k, "lookup_bits": args.lookup_bits if lookup else None, "n_gpus": world,
             "ms_per_proof": round(mean_ms, 3), "min_ms": round(min(times), 3) if times else None, "first_call_ms": round(first_ms, 3),
-            "proofs_timed": len(times), "proof_bytes": len(proof), "proof_sha256": digest, "srs_setup_seconds": round(setup_s, 3),
+            "proofs_timed": len(times), "proof_bytes": len(proof), "proof_sha256": digest, "columns": [cs.num_advice, cs.num_lookup_advice, cs.num_fixed], "srs_setup_seconds": round(setup_s, 3),
             "keygen_vk_pk_seconds": round(keygen_s, 3), "advice_cells": len(closure(args.x).advice[0]),
             "witness_generation_ms_host": round(sum(witness_ms) / max(len(witness_ms), 1), 3),
             "combine": (("RCCL all_gather_into_tensor + device fold" if backend == "nccl" else "gloo all-gather + device fold")
