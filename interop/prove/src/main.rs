@@ -48,6 +48,11 @@ struct Lookup {
     selector_fixed: i32,
     table_fixed: u32,
 }
+// the array lengths of include/h2mi_prover.h (H2MI_MAX_GATES / _PERM / _LOOKUPS / _QUERIES): tests/test_host.py compares them with the header
+const MAX_GATES: usize = 32;
+const MAX_PERM: usize = 64;
+const MAX_LOOKUPS: usize = 8;
+const MAX_QUERIES: usize = 192;
 #[repr(C)]
 struct ConstraintSystem {
     k: u32,
@@ -58,16 +63,16 @@ struct ConstraintSystem {
     blinding_factors: u32,
     gates: u32,
     n_gates: u32,
-    gate_advice: [u32; 4],
-    gate_selector: [u32; 4],
+    gate_advice: [u32; MAX_GATES],
+    gate_selector: [u32; MAX_GATES],
     n_perm: u32,
-    perm_columns: [Column; 8],
+    perm_columns: [Column; MAX_PERM],
     n_lookups: u32,
-    lookups: [Lookup; 2],
+    lookups: [Lookup; MAX_LOOKUPS],
     n_advice_queries: u32,
     n_fixed_queries: u32,
-    advice_queries: [Query; 24],
-    fixed_queries: [Query; 24],
+    advice_queries: [Query; MAX_QUERIES],
+    fixed_queries: [Query; MAX_QUERIES],
 }
 #[repr(C)]
 struct ColumnCells {
@@ -194,7 +199,7 @@ fn main() {
 
     let mut transcript = Blake2bWrite::<_, G1Affine, Challenge255<_>>::init(vec![]);
     vk.hash_into(&mut transcript).expect("hash_into"); // the crate's own transcript_repr
-    let mut pts = [G1Affine::default(); 8];
+    let mut pts = vec![G1Affine::default(); counts.advice.max(counts.lookups).max(counts.products).max(counts.quotient).max(1) as usize];
     let p = pts.as_mut_ptr() as *mut u64;
     check(unsafe { h2mi_prover_advice(prover, advice.as_ptr(), std::ptr::null(), 0, 1, p) }, "advice");
     for q in &pts[..counts.advice as usize] {

@@ -507,3 +507,27 @@ def test_cpp_host_layout_clean_under_sanitizers(tmp_path, h2):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # the HIP runtime the library pulls in keeps its own allocations until exit
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitize_flex: done" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_rust_mirror_of_the_prover_abi_matches_the_header():
+    """interop/prove (Rust, compiled by nobody here) declares h2mi_constraint_system by hand: its array lengths must be the header's
+    H2MI_MAX_* (a stale mirror would hand keygen a struct of the wrong size), its field order the header's, and the Python mirror
+    (engine.py) the same numbers."""
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "h2mi_prover.h")).read() + open(os.path.join(ROOT, "include", "h2mi.h")).read()
+    flex = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define H2MI_FLEX_MAX_(\w+) (\d+)", hdr)}
+    want = {"GATES": flex["GATES"], "PERM": flex["PERM"], "LOOKUPS": flex["LOOKUPS"],
+            "QUERIES": int(re.search(r"#define H2MI_MAX_QUERIES (\d+)", hdr).group(1))}
+    rs = open(os.path.join(ROOT, "interop", "prove", "src", "main.rs")).read()
+    got = {m.group(1): int(m.group(2)) for m in re.finditer(r"const MAX_(\w+): usize = (\d+);", rs)}
+    assert got == want
+    struct_c = re.search(r"typedef struct \{\s*uint32_t k;.*?\} h2mi_constraint_system;", hdr, re.S).group(0)
+    fields_c = re.findall(r"\b(k|n_advice|n_fixed|n_instance|degree|blinding_factors|gates|n_gates|gate_advice|gate_selector|n_perm|perm_columns|n_lookups|"
+                          r"lookups|n_advice_queries|n_fixed_queries|advice_queries|fixed_queries)\b(?=[\[;,])", struct_c)
+    struct_rs = re.search(r"struct ConstraintSystem \{(.*?)\n\}", rs, re.S).group(1)
+    fields_rs = re.findall(r"^\s*(\w+):", struct_rs, re.M)
+    assert fields_rs == fields_c, (fields_rs, fields_c)
+    eng = open(os.path.join(ROOT, "halo2-scaffold_amd", "engine.py")).read()
+    m = re.search(r"MAX_GATES, MAX_PERM, MAX_LOOKUPS, MAX_QUERIES = (\d+), (\d+), (\d+), (\d+)", eng)
+    assert [int(v) for v in m.groups()] == [want["GATES"], want["PERM"], want["LOOKUPS"], want["QUERIES"]]
