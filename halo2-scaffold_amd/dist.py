@@ -118,6 +118,31 @@ class PhaseCombiner:
             self.gathered_t = torch.zeros(12 * slots * self.world, dtype=torch.int64, device=torch_device)
             torch.cuda.synchronize(torch_device)
             self.partial_ptr = self.partial_t.data_ptr()
+            # First contact (N > 1 has never run on hardware here): one all-gather of a single point on the library's stream, exactly
+            # as combine() issues it.  Every rank reports whether it worked through an ordinary all-reduce; if ANY rank failed, ALL
+            # ranks take the host-synchronised form — the decision is collective, so the ranks cannot end up in different modes.
+            # (If the process group itself is unusable the all-reduce raises, as it would have anyway.)
+            ok = 1
+            try:
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(self.gathered_t[: 12 * self.world], self.partial_t[:12], group=group)
+                self.stream.synchronize()
+            except Exception as e:  # noqa: BLE001 - whatever the collective raises is the information
+                ok = 0
+                self.probe_error = repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=torch_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            torch.cuda.synchronize(torch_device)
+            if int(flag.item()) == 0:
+                import sys
+
+                print(f"[h2mi] stream-ordered RCCL all-gather failed on some rank ({getattr(self, 'probe_error', 'not on this rank')}): "
+                      "every rank falls back to H2MI_COMBINE=host", file=sys.stderr, flush=True)
+                self.mode, self.on_device = "host", False
+                del self.partial_t, self.gathered_t
+                self._partial = DevBuf(96 * slots)
+                self._gathered = DevBuf(96 * slots * self.world)
+                self.partial_ptr = self._partial.ptr
         else:
             self._partial = DevBuf(96 * slots)
             self._gathered = DevBuf(96 * slots * self.world)
