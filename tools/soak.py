@@ -76,4 +76,39 @@ for name, kk, lookup, closure, count in (("range", 12, True, None, n_rng), ("pos
     w2.release()
     keys.release()
     p2.release()
+# many columns (round 5): 24 range checks at DEGREE 7 (11 gate + 4 lookup-advice columns), keys and workspace created and released
+# every ten proofs — the per-prover buffers (three forms per column, result slots sized by the largest phase) must come back
+kk, bits, cnt = 7, 4, 24
+p3 = h2.ParamsKZG.setup(kk, S)
+mk = lambda cs, x: flex.range_closure(cs, x, bits, cnt)
+cs = flex.configure(True, kk, lambda c: mk(c, 5))
+ocs = FX.flex_multi_cs(True, cs.num_advice, cs.num_lookup_advice, cs.num_fixed)
+oasg = FX.range_many_assignment_multi(ocs, 5, bits, kk, cnt)
+ovk3 = FX.VerifierKeys(ocs, kk, S, oasg.fixed, oasg.copies)
+keys = flex.FlexKeys(p3, cs, mk(cs, 5))
+w3 = flex.FlexWorkspace(p3, keys)
+flex.create_proof(p3, keys, mk(cs, 5), 1, ws=w3)
+w3.release()
+keys.release()
+h2._lib.check(h2.lib.h2mi_sync(), "sync")
+m0 = free_bytes()
+bad = 0
+n_wide = max(n_pos, 10)
+for i in range(n_wide):
+    if i % 10 == 0:
+        if i:
+            w3.release()
+            keys.release()
+        keys = flex.FlexKeys(p3, cs, mk(cs, 5))
+        w3 = flex.FlexWorkspace(p3, keys)
+    asg = mk(cs, 0x1234500 + 31 * i)
+    proof = flex.create_proof(p3, keys, asg, 900 + i, ws=w3)
+    if not FX.verify(ovk3, proof, [asg.instance]):
+        bad += 1
+        print("REJECTED wide", i, flush=True)
+w3.release()
+keys.release()
+h2._lib.check(h2.lib.h2mi_sync(), "sync")
+print(f"range x{cnt} k={kk} ({cs.num_advice} + {cs.num_lookup_advice} columns): {n_wide} proofs, {bad} rejected, free memory delta {m0 - free_bytes()} B", flush=True)
+p3.release()
 print(f"soak done in {time.time() - t_all:.1f} s")
