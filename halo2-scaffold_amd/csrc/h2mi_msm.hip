@@ -340,6 +340,7 @@ __device__ __forceinline__ fe msm_scalar(const fe* scalars, size_t i, size_t n, 
 template <uint32_t CT>
 __device__ __forceinline__ void msm_bin_count_body(const fe* scalars, size_t n, const fe* shift, uint32_t c, uint32_t W, uint32_t lb, uint32_t nbins,
                                                    uint32_t ntiles, uint32_t* cnt_out, uint32_t* tile_live) {
+  H2_AB_PRIO();
   __shared__ uint32_t cnt[NBINS_MAX];
   __shared__ uint32_t any_live;
   const uint32_t tid = threadIdx.x;
@@ -373,6 +374,7 @@ template <uint32_t CT>
 __device__ __forceinline__ void msm_bin_scatter_body(const fe* scalars, size_t n, const fe* shift, size_t n_reg, uint32_t c, uint32_t W, uint32_t lb,
                                                      uint32_t nbins, uint32_t ntiles, const uint32_t* base, uint32_t* vals_out, void* keys_out_,
                                                      const uint32_t* tile_live) {
+  H2_AB_PRIO();
   constexpr bool WIDE = CT >= WIDE_MIN_C;  // in-bin keys of up to 10 bits: staged and written as 16-bit values
   if (!tile_live[blockIdx.x]) return;  // no non-zero scalar in this tile (k_msm_bin_count): block-uniform, before any barrier
   __shared__ uint32_t cnt[NBINS_MAX], lstart[NBINS_MAX + 1], wsum[NBINS_MAX / 64];
@@ -483,6 +485,7 @@ constexpr uint32_t NQ_MAX = 128;  // buckets per bin (c = 17: 2^16 buckets in 51
 __device__ __forceinline__ void msm_bin_sort_body(const uint8_t* keys_in, const uint32_t* vals_in, const uint32_t* base, uint32_t ntiles, uint32_t nbins,
                                                   uint32_t lb, uint32_t s0_fixed, uint32_t nb, uint32_t* vals_out, uint32_t* off, uint32_t* np0,
                                                   uint32_t* np1, uint32_t* s0_out) {
+  H2_AB_PRIO();
   __shared__ uint32_t wh[P2_THREADS / 64][NQ_MAX];
   __shared__ uint32_t run[NQ_MAX], ccnt[NQ_MAX], cstart[NQ_MAX], carry64;
   __shared__ uint32_t stage[P2_CH];
@@ -2146,6 +2149,12 @@ static int msm_dev(Bases* B, const void* d_scalars, size_t n, void* d_out, hipSt
   // back-to-back MSMs 2^20: 1.90 -> 1.74 ms.  H2MI_ACCUM_LDS=0 removes the cap.
   static const size_t accum_lds = ab_env("H2MI_ACCUM_LDS") ? (size_t)atoi(ab_env("H2MI_ACCUM_LDS")) : 56000;
 #ifdef H2MI_AB
+  static bool prio_set = false;
+  if (!prio_set && ab_env("H2MI_AB_PRIO")) {
+    const uint32_t one = 1;
+    H2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ab_prio), &one, 4));
+  }
+  prio_set = true;
   // pair-affine accumulation (experiment, -DH2MI_AB library only): from H2MI_MSM_PA_MIN entries (default 2^22)
   static const bool pa_on = ab_env("H2MI_MSM_PA") != nullptr;
   static const uint32_t pa_min = ab_env("H2MI_MSM_PA_MIN") ? (uint32_t)atoll(ab_env("H2MI_MSM_PA_MIN")) : (1u << 22);

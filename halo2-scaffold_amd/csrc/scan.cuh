@@ -1,6 +1,13 @@
 // Exclusive scans of 32-bit counters on the device, shared by the MSM's bucket partition and the lookup argument's
 // counting sort (own kernels: the library scans took 15-70 us at these sizes, mostly launch latency).
 #pragma once
+// A/B only (-DH2MI_AB, H2MI_AB_PRIO): issue priority of the partition / scan wavefronts over the accumulation wavefronts they share SIMDs with
+#ifdef H2MI_AB
+static __device__ uint32_t g_ab_prio = 0;
+#define H2_AB_PRIO() do { if (g_ab_prio) __builtin_amdgcn_s_setprio(3); } while (0)
+#else
+#define H2_AB_PRIO() do {} while (0)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,6 +42,7 @@ __device__ __forceinline__ uint32_t block_sum_1024(uint32_t v, uint32_t* wsum /*
 }
 template <uint32_t SEG>
 __device__ __forceinline__ void scan_segsum_body(const uint32_t* in, uint32_t m, uint32_t* segsum) {
+  H2_AB_PRIO();
   __shared__ uint32_t wsum[16];
   const uint32_t seg0 = blockIdx.x * SEG, len = min(SEG, m - seg0);
   uint32_t sum = 0;
@@ -52,6 +60,7 @@ __global__ void __launch_bounds__(1024) k_scan_segsum(const uint32_t* in, uint32
 // one array: segment blockIdx.x of `in_` -> `out_`
 template <uint32_t SEG>
 __device__ __forceinline__ void scan_seg_body(const uint32_t* in_, uint32_t* out_, uint32_t m, const uint32_t* segsum) {
+  H2_AB_PRIO();
   __shared__ uint32_t wsum[16], wsum2[16];
   constexpr uint32_t NV = SEG / 4096;  // 16-byte vectors per thread
   const uint32_t seg = blockIdx.x, seg0 = seg * SEG, len = min(SEG, m - seg0);
