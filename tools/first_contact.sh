@@ -30,6 +30,21 @@ for N in 2 4 8; do
   timeout -k 10 900 python3 bench.py --gpus "$N" --single-process --steps 10 --warmup 3 > "$OUT/bench_single_${N}.json" 2> "$OUT/bench_single_${N}.err" \
     || echo "   FAILED (rc $?): see $OUT/bench_single_${N}.err" | tee -a "$OUT/summary.txt"
 done
+echo "== a many-column halo2-lib proof over the sliced SRS (24 range checks at DEGREE 7: 11 + 4 columns, up to 15 partial points per phase), N = 2 over RCCL" | tee -a "$OUT/summary.txt"
+python3 tools/flex_proof.py --shape range --k 7 --lookup-bits 4 --count 24 --configure --proofs 2 > "$OUT/flex_wide_1.json" 2> "$OUT/flex_wide_1.err"
+PORT=$((PORT + 1))
+timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port "$PORT" \
+  tools/flex_proof.py --shape range --k 7 --lookup-bits 4 --count 24 --configure --proofs 2 --gpus 2 > "$OUT/flex_wide_2.json" 2> "$OUT/flex_wide_2.err" \
+  || echo "   FAILED (rc $?): see $OUT/flex_wide_2.err" | tee -a "$OUT/summary.txt"
+python3 - "$OUT" <<'P' | tee -a "$OUT/summary.txt"
+import json, os, sys
+try:
+    a, b = (json.loads([l for l in open(os.path.join(sys.argv[1], f"flex_wide_{i}.json")) if l.startswith("{")][-1]) for i in (1, 2))
+    print("wide sliced proof:", "SAME BYTES as the single-GPU proof" if a["proof_sha256"] == b["proof_sha256"] else "DIFFERS from the single-GPU proof",
+          f"({b['combines_per_proof']} combines per proof)")
+except Exception as e:  # noqa: BLE001
+    print("wide sliced proof: no result", e)
+P
 python3 - "$OUT" <<'P' | tee -a "$OUT/summary.txt"
 import glob, json, os, sys
 base = None
