@@ -306,11 +306,24 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int, count: int = 1) -> A
     return asg
 
 
-def mock(asg: Assignment) -> None:
+def mock(asg: Assignment, k: int = None) -> None:
     """scaffold::mock (src/scaffold.rs:205-243: MockProver::run(..).assert_satisfied()) for these constraint systems, on the
     host: every enabled row satisfies the vertical gate, every copy constraint joins equal cells, every looked-up cell is
-    a table value.  Raises ValueError naming the first violation — what the reference's users run before `prove`."""
+    a table value.  Raises ValueError naming the first violation — what the reference's users run before `prove`.  With the
+    DEGREE known (k, or the constraint system's own for the multi-column layouts) cells beyond the usable rows are refused as
+    MockProver::run refuses them (NotEnoughRowsAvailable) — the same rule h2mi_prover_keygen applies."""
     cs = asg.cs
+    k = k if k is not None else cs.k
+    if k is not None:
+        u = (1 << k) - (cs.blinding_factors + 1)
+        rows = [(f"fixed column {c}", max(cells)) for c, cells in enumerate(asg.fixed) if cells]
+        rows += [(f"advice column {c}", max(cells)) for c, cells in enumerate(asg.advice) if cells]
+        rows += [("a copy constraint", max(left[2], right[2])) for left, right in asg.copies]
+        if cs.lookup:
+            rows.append(("the lookup table", len(asg.table_values) - 1))
+        for what, row in rows:
+            if row >= u:
+                raise ValueError(f"NotEnoughRowsAvailable: {what} reaches row {row}, the usable rows end at {u}")
     for j, cq in enumerate(cs.col_qs):  # gate column j with its own selector
         a = asg.advice[j]
         for r in sorted(asg.fixed[cq]):

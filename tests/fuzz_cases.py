@@ -211,7 +211,12 @@ class Fuzzer:
             if "NOT ENOUGH" in str(e) or "prover ABI takes" in str(e):
                 return
             raise
-        flex.mock(asg)
+        mock_refused = False
+        try:
+            flex.mock(asg)
+        except ValueError as e:  # the host-side MockProver refuses what keygen will refuse
+            assert "NotEnoughRowsAvailable" in str(e), e
+            mock_refused = True
         params = h2.ParamsKZG.setup(k, S)
 
         def oracle_side(cs):
@@ -227,8 +232,9 @@ class Fuzzer:
 
         try:
             vk = oracle_side(cs)
+            assert not mock_refused, ("flex.mock refused what the oracle accepts", seed0, k, bits, count)
         except ValueError as e:  # the constants overflow the usable rows: the device keygen must refuse it too (NotEnoughRowsAvailable)
-            assert "NotEnoughRowsAvailable" in str(e)
+            assert "NotEnoughRowsAvailable" in str(e) and mock_refused
             try:
                 flex.FlexKeys(params, cs, asg).release()
                 raise AssertionError(("keygen accepted cells beyond the usable rows", seed0, k, bits, count))
