@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
     // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape
     auto pk = [&] { Timer t("Generating verifying and proving key"); return flex::keygen(params, cs, closure(0)); }();
     flex::Assignment asg = closure(x);
+    flex::mock(asg, k);  // scaffold::mock (the reference's examples run it first: MockProver::run(..).assert_satisfied())
     std::vector<uint8_t> proof;
     flex::FlexWorkspace ws(params, *pk);
     for (int run = 0; run < 3; run++) {

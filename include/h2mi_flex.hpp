@@ -480,6 +480,55 @@ inline Assignment poseidon_hash_two_closure(const FlexGateCS& cs, const Fr& x, c
   return asg;
 }
 
+// scaffold::mock (src/scaffold.rs:39-93: MockProver::run(k, &circuit, instances).assert_satisfied()) for these constraint systems, on
+// the host: no cell beyond the usable rows (MockProver::run's NotEnoughRowsAvailable; the rule h2mi_prover_keygen applies), every
+// enabled row satisfies its column's vertical gate, every copy constraint joins equal cells, every looked-up cell is a table
+// value.  Throws Error(H2MI_EUNSAT / H2MI_ERANGE) naming the first violation — what the reference's users run before `prove`.
+inline void mock(const Assignment& asg, uint32_t k) {
+  const FlexGateCS& cs = *asg.cs;
+  const uint64_t u = ((uint64_t)1 << k) - (cs.blinding_factors + 1);
+  auto rows_ok = [&](const char* what, uint64_t last_row) {
+    if (last_row >= u) throw Error(H2MI_ERANGE, std::string("mock: NotEnoughRowsAvailable: ") + what + " reaches beyond the usable rows");
+  };
+  for (const auto& col : asg.advice)
+    if (!col.empty()) rows_ok("an advice column", col.size() - 1);
+  for (const auto& col : asg.fixed)
+    if (!col.empty()) rows_ok("a fixed column", col.rbegin()->first);
+  if (cs.lookup && !asg.table_values.empty()) rows_ok("the lookup table", asg.table_values.size() - 1);
+  auto adv = [&](uint32_t c, uint64_t r) { return r < asg.advice[c].size() ? asg.advice[c][r] : fr_zero(); };
+  for (size_t j = 0; j < cs.col_qs.size(); j++)
+    for (const auto& on : asg.fixed[cs.col_qs[j]]) {
+      const uint64_t r = on.first;
+      const Fr lhs = fr::add(adv((uint32_t)j, r), fr::mul(adv((uint32_t)j, r + 1), adv((uint32_t)j, r + 2)));
+      if (!(fr::mul(on.second, fr::sub(lhs, adv((uint32_t)j, r + 3))) == fr_zero()))
+        throw Error(H2MI_EUNSAT, "mock: gate not satisfied at row " + std::to_string(r) + " of gate column " + std::to_string(j));
+    }
+  auto value = [&](const CellRef& c) -> Fr {
+    if (c.kind == ADVICE) return adv(c.col, c.row);
+    if (c.kind == INSTANCE) return c.row < asg.instance.size() ? asg.instance[c.row] : fr_zero();
+    const auto it = asg.fixed[c.col].find(c.row);
+    return it == asg.fixed[c.col].end() ? fr_zero() : it->second;
+  };
+  for (const auto& cp : asg.copies) {
+    rows_ok("a copy constraint", std::max(cp.first.row, cp.second.row));
+    if (!(value(cp.first) == value(cp.second))) throw Error(H2MI_EUNSAT, "mock: a copy constraint joins unequal cells");
+  }
+  if (cs.lookup) {
+    auto in_table = [&](const Fr& v) {
+      const Fr c = plonk::to_canonical(v);
+      return c.l[1] == 0 && c.l[2] == 0 && c.l[3] == 0 && (c.l[0] == 0 || std::find(asg.table_values.begin(), asg.table_values.end(), c.l[0]) != asg.table_values.end());
+    };
+    if (cs.num_advice == 1) {
+      for (const auto& on : asg.fixed[cs.col_qlookup])
+        if (!in_table(adv(0, on.first))) throw Error(H2MI_EUNSAT, "mock: lookup not satisfied at row " + std::to_string(on.first));
+    } else {
+      for (uint32_t l = 0; l < cs.num_lookup_advice; l++)
+        for (const Fr& v : asg.advice[cs.num_advice + l])
+          if (!in_table(v)) throw Error(H2MI_EUNSAT, "mock: lookup not satisfied in lookup-advice column " + std::to_string(l));
+    }
+  }
+}
+
 // GateThreadBuilder::config (src/scaffold.rs:268 `builder.config(k, Some(minimum_rows))`): run the closure once on the one-column
 // constraint system to count its cells and cells to look up, and take ceil(count / (2^k - minimum_rows)) columns of each kind
 template <class Closure>
