@@ -78,3 +78,14 @@ def test_mock_accepts_the_example_closures_and_names_violations():
     bad.advice[0][row] = 16
     with pytest.raises(ValueError):  # the limb no longer recomposes (gate) — and is outside the table
         flex.mock(bad)
+    # MockProver::run's row budget: 32 limb bases (LOOKUP_BITS 2) in the 25 usable rows of a DEGREE-5 constants column, one column by
+    # config's own count; a second constants column set by hand holds them; a one-column circuit longer than its DEGREE allows
+    cs = flex.configure(True, 5, lambda c: flex.range_closure(c, 0xDEADBEEFCAFE1234, 2))
+    assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (5, 2, 1)
+    with pytest.raises(ValueError, match="NotEnoughRowsAvailable: fixed column"):
+        flex.mock(flex.range_closure(cs, 0xDEADBEEFCAFE1234, 2))
+    cs2 = flex.FlexGateCS(True, 5, 2, k=5, num_fixed=2)
+    flex.mock(flex.range_closure(cs2, 0xDEADBEEFCAFE1234, 2))
+    flex.mock(flex.range_closure(rng, 12345, 4), k=7)
+    with pytest.raises(ValueError, match="NotEnoughRowsAvailable: advice column"):
+        flex.mock(flex.range_closure(rng, 12345, 4), k=5)
