@@ -45,15 +45,17 @@ static std::string hex(const std::vector<uint8_t>& b) {
 int main(int argc, char** argv) {
   const std::string shape = argc > 1 ? argv[1] : "halo2_lib";
   const uint32_t k = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 10;  // DEGREE
-  const uint32_t lookup_bits = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 8;
+  const uint32_t lookup_bits = std::getenv("LOOKUP_BITS") ? (uint32_t)std::atoi(std::getenv("LOOKUP_BITS")) : argc > 3 ? (uint32_t)std::atoi(argv[3]) : 8;
   const uint64_t x = argc > 4 ? std::stoull(argv[4], nullptr, 0) : 12;
   const Fr s = fr_from_hex(argc > 5 ? argv[5] : "5ec2e7");
   const uint64_t seed = argc > 6 ? std::stoull(argv[6]) : 11;
   const uint32_t count = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
   const uint32_t set_advice = argc > 9 ? (uint32_t)std::atoi(argv[8]) : 0, set_lookup = argc > 9 ? (uint32_t)std::atoi(argv[9]) : 0;
   const uint32_t set_fixed = argc > 10 ? (uint32_t)std::max(1, std::atoi(argv[10])) : 1;
-  const bool lookup = shape == "range";
-  if (!lookup && shape != "halo2_lib" && shape != "poseidon") {
+  // the reference takes the Range builder whenever LOOKUP_BITS is set, whatever the closure (src/scaffold.rs:44-48): so does this
+  const char* env_bits = std::getenv("LOOKUP_BITS");
+  const bool lookup = shape == "range" || env_bits != nullptr;
+  if (shape != "range" && shape != "halo2_lib" && shape != "poseidon") {
     std::fprintf(stderr, "usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed]]]]]\n");
     return 1;
   }
@@ -61,8 +63,10 @@ int main(int argc, char** argv) {
     init();
     auto params = [&] { Timer t("Generating params"); return poly::kzg::ParamsKZG::setup(k, s); }();
     auto run = [&](const flex::FlexGateCS& c, uint64_t v) {
-      if (shape == "poseidon") return flex::poseidon_hash_two_closure(c, fr::from_u64(v), fr::from_u64(v + 1));
-      return lookup ? flex::range_closure(c, v, lookup_bits, count) : flex::halo2_lib_closure(c, fr::from_u64(v));
+      if (shape == "range") return flex::range_closure(c, v, lookup_bits, count);
+      flex::Assignment a = shape == "poseidon" ? flex::poseidon_hash_two_closure(c, fr::from_u64(v), fr::from_u64(v + 1)) : flex::halo2_lib_closure(c, fr::from_u64(v));
+      if (lookup) flex::load_lookup_table(a, lookup_bits);  // the Range builder loads its table whatever the closure looks up
+      return a;
     };
     // `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268): more than one gate column when the closure's cells overflow 2^k rows
     const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, 9, set_fixed)

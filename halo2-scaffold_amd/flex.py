@@ -80,7 +80,7 @@ class FlexGateCS:
         constants out round-robin (constant i: column i mod num_fixed, row i div num_fixed)."""
         A, Lc, Fc = self.num_advice, self.num_lookup_advice, self.num_fixed
         assert 2 <= A <= engine.MAX_GATES and Lc <= engine.MAX_LOOKUPS, "the prover ABI takes up to 32 gate columns and 8 lookup-advice columns"
-        assert (Lc >= 1) == bool(self.lookup), "the Range builder needs a lookup-advice column, the Gate builder has none"
+        assert Lc == 0 or self.lookup, "the Gate builder has no lookup-advice column"  # Range builder, nothing looked up: Lc = 0, no lookup argument
         assert self.k is not None, "the multi-column layout needs k (rows per column = 2^k - minimum_rows)"
         self.n_advice = A + Lc
         self.col_table, self.col_const = (0, 1) if self.lookup else (None, 0)
@@ -89,10 +89,10 @@ class FlexGateCS:
         self.col_qs = [self.col_const + Fc + j for j in range(A)]
         self.col_q = None
         self.n_fixed = self.col_const + Fc + A
-        self.fixed_queries = [(c, 0) for c in self.col_consts] + ([(self.col_table, 0)] if self.lookup else []) + [(c, 0) for c in self.col_qs]
+        self.fixed_queries = [(c, 0) for c in self.col_consts] + ([(self.col_table, 0)] if Lc else []) + [(c, 0) for c in self.col_qs]
         self.perm_columns = [(FIXED, c) for c in self.col_consts] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
         self.advice_queries = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
-        self.degree = 4 if self.lookup else 3
+        self.degree = 4 if Lc else 3  # the lookup arguments are what raises it
         self.blinding_factors = 6
         self.chunk = self.degree - 2
 
@@ -121,7 +121,7 @@ def configure(lookup: bool, k: int, closure, minimum_rows: int = 9) -> FlexGateC
         return FlexGateCS(lookup, k=k, minimum_rows=minimum_rows)
     looked_up = len(asg.fixed[probe.col_qlookup]) if lookup else 0
     num_fixed = max(1, -(-len(asg.fixed[probe.col_const]) // (1 << k)))  # `(total_fixed + (1 << k) - 1) >> k` over the distinct constants
-    return FlexGateCS(lookup, num_advice, max(1, -(-looked_up // max_rows)) if lookup else 0, k=k, minimum_rows=minimum_rows, num_fixed=num_fixed)
+    return FlexGateCS(lookup, num_advice, -(-looked_up // max_rows) if lookup else 0, k=k, minimum_rows=minimum_rows, num_fixed=num_fixed)
 
 
 class Assignment:
@@ -301,7 +301,15 @@ def range_closure(cs: FlexGateCS, x: int, lookup_bits: int, count: int = 1) -> A
         ctx.add(xc, xc)
         public.append(xc)
     ctx.finish(public)
-    asg.fixed[cs.col_table] = None  # dense: filled by keygen from `table_values`
+    return load_lookup_table(asg, lookup_bits)
+
+
+def load_lookup_table(asg: Assignment, lookup_bits: int) -> Assignment:
+    """RangeConfig::load_lookup_table (src/scaffold.rs:462): the Range builder's synthesize assigns 0 .. 2^LOOKUP_BITS - 1 to the table
+    column whatever the closure does — also for a closure that looks nothing up (the reference picks the Range builder whenever
+    LOOKUP_BITS is set: src/scaffold.rs:44-48)."""
+    assert asg.cs.lookup, "the Gate builder has no table column"
+    asg.fixed[asg.cs.col_table] = None  # dense: filled by keygen from `table_values`
     asg.table_values = list(range(1 << lookup_bits))
     return asg
 

@@ -123,8 +123,8 @@ class PoseidonChip:
 
 
 def hash_two_closure(cs: FlexGateCS, x: int, y: int) -> Assignment:
-    """reference examples/poseidon.rs:15-36; public inputs [x, y, hash]"""
-    assert not cs.lookup
+    """reference examples/poseidon.rs:15-36; public inputs [x, y, hash].  Under the Range builder (LOOKUP_BITS set) the caller adds the
+    table with flex.load_lookup_table."""
     asg = Assignment(cs)
     ctx = Context(asg)
     xc, yc = ctx.load_witness(x), ctx.load_witness(y)

@@ -76,7 +76,8 @@ struct FlexGateCS {
     if (gate_columns <= 1) return;
     num_fixed = std::max(1u, constants_columns);
     const uint32_t A = gate_columns, Lc = lookup_columns;
-    if (A > H2MI_MAX_GATES || Lc > H2MI_MAX_LOOKUPS || (Lc >= 1) != lookup) throw Error(H2MI_EINVAL, "FlexGateCS: up to 32 gate columns and 8 lookup-advice columns");
+    if (A > H2MI_MAX_GATES || Lc > H2MI_MAX_LOOKUPS || (Lc >= 1 && !lookup))  // Range builder, nothing looked up: no lookup-advice column
+      throw Error(H2MI_EINVAL, "FlexGateCS: up to 32 gate columns and 8 lookup-advice columns (none for the Gate builder)");
     num_advice = A;
     num_lookup_advice = Lc;
     n_advice = A + Lc;
@@ -88,7 +89,7 @@ struct FlexGateCS {
     n_fixed = (uint32_t)col_const + num_fixed + A;
     fixed_queries.clear();
     for (uint32_t c = 0; c < num_fixed; c++) fixed_queries.push_back({(uint32_t)col_const + c, 0});
-    if (lookup) fixed_queries.push_back({(uint32_t)col_table, 0});
+    if (Lc) fixed_queries.push_back({(uint32_t)col_table, 0});  // the table column is queried by the lookup arguments only
     for (uint32_t q : col_qs) fixed_queries.push_back({q, 0});
     perm_columns.clear();
     for (uint32_t c = 0; c < num_fixed; c++) perm_columns.push_back({FIXED, (uint32_t)col_const + c});
@@ -98,7 +99,7 @@ struct FlexGateCS {
     for (uint32_t j = 0; j < A; j++)
       for (int32_t r = 0; r < 4; r++) advice_queries.push_back({j, r});
     for (uint32_t l = 0; l < Lc; l++) advice_queries.push_back({A + l, 0});
-    degree = lookup ? 4 : 3;
+    degree = Lc ? 4 : 3;
     chunk = degree - 2;
   }
   // the same constraint system as the numbers create_proof reads off it (h2mi_prover.h)
@@ -315,6 +316,12 @@ inline Assignment halo2_lib_closure(const FlexGateCS& cs, const Fr& x) {
   ctx.finish({xc, out});
   return asg;
 }
+// RangeConfig::load_lookup_table (src/scaffold.rs:462): the Range builder assigns 0 .. 2^LOOKUP_BITS - 1 to the table column whatever the
+// closure does — also for one that looks nothing up (the reference takes the Range builder whenever LOOKUP_BITS is set)
+inline void load_lookup_table(Assignment& asg, uint32_t lookup_bits) {
+  asg.table_values.resize((size_t)1 << lookup_bits);
+  for (size_t i = 0; i < asg.table_values.size(); i++) asg.table_values[i] = i;
+}
 // reference examples/range.rs:10-34: make_public = [x]; range_check(x, 64); x + x.  Table: 0 .. 2^LOOKUP_BITS - 1
 // count > 1: the same body for x, x + step, x + 2 step, ... (mod 2^64) in one context, every value public: fills several gate and
 // lookup-advice columns while the limb bases, shared by all the checks, still fit the one constants column
@@ -329,8 +336,7 @@ inline Assignment range_closure(const FlexGateCS& cs, uint64_t x, uint32_t looku
     pub.push_back(xc);
   }
   ctx.finish(pub);
-  asg.table_values.resize((size_t)1 << lookup_bits);
-  for (size_t i = 0; i < asg.table_values.size(); i++) asg.table_values[i] = i;
+  load_lookup_table(asg, lookup_bits);
   return asg;
 }
 
@@ -538,7 +544,7 @@ inline FlexGateCS configure(bool lookup, uint32_t k, Closure closure, uint32_t m
   const size_t max_rows = ((size_t)1 << k) - minimum_rows;
   const uint32_t num_advice = (uint32_t)std::max<size_t>(1, (asg.n_cells + max_rows - 1) / max_rows);
   if (num_advice == 1) return FlexGateCS(lookup, 1, 0, k, minimum_rows);
-  const uint32_t num_lookup = lookup ? (uint32_t)std::max<size_t>(1, (asg.n_lookup_cells + max_rows - 1) / max_rows) : 0;
+  const uint32_t num_lookup = lookup ? (uint32_t)((asg.n_lookup_cells + max_rows - 1) / max_rows) : 0;
   const size_t total_fixed = asg.fixed[probe.col_const].size();  // distinct constants: `(total_fixed + (1 << k) - 1) >> k` columns
   return FlexGateCS(lookup, num_advice, num_lookup, k, minimum_rows, (uint32_t)std::max<size_t>(1, (total_fixed + ((size_t)1 << k) - 1) >> k));
 }

@@ -104,7 +104,7 @@ def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0, num
         single one was); assign_constants deals the distinct constants out round-robin: constant i to column i mod num_fixed, row
         i div num_fixed.
     num_advice = 1 is flex_gate_cs (the q_lookup form): not built here."""
-    assert num_advice >= 2 and (lookup or num_lookup_advice == 0) and (not lookup or num_lookup_advice >= 1) and num_fixed >= 1
+    assert num_advice >= 2 and (lookup or num_lookup_advice == 0) and num_fixed >= 1  # Range builder without a looked-up cell: no lookup-advice column, no lookup argument
     A, Lc = num_advice, num_lookup_advice
     TABLE, CONST = (0, 1) if lookup else (None, 0)
     CONSTS = list(range(CONST, CONST + num_fixed))
@@ -113,10 +113,10 @@ def flex_multi_cs(lookup: bool, num_advice: int, num_lookup_advice: int = 0, num
     gates = [gate_of(j) for j in range(A)]
     perm = [(FIXED, c) for c in CONSTS] + [(ADVICE, j) for j in range(A + Lc)] + [(INSTANCE, 0)]
     adv_q = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(Lc)]
-    fix_q = [(c, 0) for c in CONSTS] + ([(TABLE, 0)] if lookup else []) + [(q0 + j, 0) for j in range(A)]
+    fix_q = [(c, 0) for c in CONSTS] + ([(TABLE, 0)] if Lc else []) + [(q0 + j, 0) for j in range(A)]  # the table column is queried by the lookups only
     lookups = [([(ADVICE, A + l)], (FIXED, TABLE)) for l in range(Lc)]
     cs = ConstraintSystem(f"{'range' if lookup else 'flex_gate'}_{A}x{Lc}" + (f"x{num_fixed}" if num_fixed > 1 else ""), A + Lc, q0 + A, 1, gates, perm,
-                          lookups, adv_q, fix_q, [(0, 0)], 4 if lookup else 3, 6)
+                          lookups, adv_q, fix_q, [(0, 0)], 4 if Lc else 3, 6)
     cs.col_const, cs.col_table, cs.col_qlookup = CONST, TABLE, None
     cs.col_consts, cs.num_fixed = CONSTS, num_fixed
     cs.col_q = [q0 + j for j in range(A)]

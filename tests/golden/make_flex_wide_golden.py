@@ -14,6 +14,9 @@ circuit whose cells fill dozens of columns at the chosen DEGREE, and what a call
   (halo2's NotEnoughRowsAvailable), e.g. LOOKUP_BITS 2 at DEGREE 5: 32 limb bases for 25 usable rows, where config's
   ceil(constants / 2^k) still says one column; with num_fixed = 2 set by hand (the last case: 5 + 2 columns, two constants columns,
   the constants dealt out round-robin) it proves.
+  The Range builder under closures that look nothing up (the reference takes it whenever LOOKUP_BITS is set: src/scaffold.rs:44-48):
+  halo2_lib at DEGREE 6 with LOOKUP_BITS 4 (one column: the q_lookup selector stays empty) and poseidon at DEGREE 11 with LOOKUP_BITS 8
+  (4 gate columns, NO lookup-advice column and no lookup argument: degree 3, the table column committed but never queried).
 Usage: python tests/golden/make_flex_wide_golden.py
 """
 import json
@@ -31,10 +34,40 @@ SRS_SECRET = MM.SRS_SECRET
 # (shape, k, lookup bits, x, seed, range checks, explicit (num_advice, num_lookup_advice[, num_fixed]) or None)
 CASES = [("poseidon", 8, 0, 0xFEEDFACE, 17, 0, None), ("poseidon", 9, 0, 0xABCDEF, 23, 0, None),
          ("range", 6, 4, 0xDEADBEEFCAFE1234, 31, 8, None), ("range", 6, 4, 0x0123456789ABCDEF, 41, 10, (11, 8)),
-         ("range", 7, 4, 0x0F1E2D3C4B5A6978, 43, 24, None), ("range", 5, 2, 0xDEADBEEFCAFE1234, 47, 1, (5, 2, 2))]
+         ("range", 7, 4, 0x0F1E2D3C4B5A6978, 43, 24, None), ("range", 5, 2, 0xDEADBEEFCAFE1234, 47, 1, (5, 2, 2)),
+         ("halo2_lib+range_builder", 6, 4, 12, 5, 0, None), ("poseidon+range_builder", 11, 8, 0xFEED, 9, 0, None)]
+
+
+def _closure_table(shape, x):
+    """-> (table, public rows) of the halo2_lib / poseidon closure"""
+    if shape == "halo2_lib":
+        return FX._halo2_lib_table(x), [0, 8]
+    import make_flex_golden as MG
+
+    probe = FX.flex_gate_cs(False)
+    box = {}
+    orig = FX._Table.assignment
+    FX._Table.assignment = lambda self, cs, pub: box.update(t=self, pub=pub) or orig(self, cs, pub)  # catch the table the generator lays out
+    try:
+        MG.poseidon_assignment(probe, x, x + 1)
+    finally:
+        FX._Table.assignment = orig
+    return box["t"], box["pub"]
 
 
 def build(shape, k, bits, x, count, explicit):
+    if shape.endswith("+range_builder"):  # a closure without range checks under the Range builder: the table is loaded all the same
+        t, pub = _closure_table(shape.split("+")[0], x)
+        A, Lc = FX.multi_column_counts(len(t.rows), len(t.lookups), k)
+        assert Lc == 0
+        if A == 1:
+            cs = FX.flex_gate_cs(True)
+            asg = t.assignment(cs, pub)
+        else:
+            cs = FX.flex_multi_cs(True, A, 0, FX.num_fixed_columns(t, k))
+            asg = FX.multi_column_assignment(t, cs, pub, k)
+        asg.fixed[cs.col_table] = {i: i for i in range(1 << bits)}
+        return cs, asg
     if shape != "range":
         return MM.build(shape, k, bits, x)
     t, _ = FX._range_many_table(FX.range_many_values(x, count), bits)
@@ -56,9 +89,9 @@ def main():
             bkeys = FX.Keys(cs, k, SRS_SECRET, asg.fixed, asg.copies)
             assert FX.prove(bkeys, asg, seed)["proof"] == r["proof"] and bkeys.vk_bytes() == keys.vk_bytes()
         out["cases"].append({"shape": shape, "k": k, "lookup_bits": bits, "x": "0x%x" % x, "seed": seed, "count": count, "explicit": explicit is not None,
-                             "num_advice": cs.num_advice, "num_lookup_advice": cs.num_lookup_advice, "num_fixed": cs.num_fixed,
+                             "num_advice": getattr(cs, "num_advice", 1), "num_lookup_advice": getattr(cs, "num_lookup_advice", 0), "num_fixed": getattr(cs, "num_fixed", 1),
                              "instance": ["0x%x" % v for v in asg.instance[0]], "vk_bytes": keys.vk_bytes().hex(), "proof": r["proof"].hex()})
-        print(shape, k, bits, cs.num_advice, cs.num_lookup_advice, len(r["proof"]), flush=True)
+        print(shape, k, bits, getattr(cs, "num_advice", 1), getattr(cs, "num_lookup_advice", 0), len(r["proof"]), flush=True)
     with open(os.path.join(HERE, "flex_wide_proofs.json"), "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")

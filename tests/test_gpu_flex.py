@@ -426,7 +426,8 @@ def test_wide_column_counts_match_golden(gpu):
     """round 5: the prover ABI's column limits (32 gate columns, 8 lookup-advice columns, 64 permutation columns, 192 queries) —
     poseidon at DEGREE 8 / 9 (31 / 15 gate columns through `flex.configure`), 8 and 24 range checks in one context at DEGREE 6 / 7
     (8 + 3 and 11 + 4 columns), 10 range checks over 11 + 8 columns set by hand (eight lookup arguments), one over 5 + 2 columns with
-    TWO constants columns (the constants dealt out round-robin).  Keys and proof bytes equal
+    TWO constants columns (the constants dealt out round-robin); halo2_lib and poseidon under the RANGE builder (LOOKUP_BITS set, nothing
+    looked up: no lookup-advice column, the table committed but never queried).  Keys and proof bytes equal
     the committed golden (tests/golden/flex_wide_proofs.json, made by the oracle's vector engine and re-verified on the CPU by
     tests/test_oracle_fast.py); the oracle's verifier accepts the device proof and refuses another public input; the C++ host
     (its own Context / configure over the same prover ABI) prints the same bytes.  A configuration whose constants overflow the
@@ -448,11 +449,17 @@ def test_wide_column_counts_match_golden(gpu):
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
     for case in g["cases"]:
         shape, k, bits, x, seed, count = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16), case["seed"], case["count"]
-        closure = ((lambda cs: flex.range_closure(cs, x, bits, count)) if shape == "range" else (lambda cs: poseidon.hash_two_closure(cs, x, x + 1)))
+        base, _, builder = shape.partition("+")
+        range_builder = base == "range" or builder == "range_builder"  # the reference takes the Range builder whenever LOOKUP_BITS is set
+        if base == "range":
+            closure = lambda cs: flex.range_closure(cs, x, bits, count)
+        else:
+            plain = (lambda cs: poseidon.hash_two_closure(cs, x, x + 1)) if base == "poseidon" else (lambda cs: flex.halo2_lib_closure(cs, x))
+            closure = (lambda cs: flex.load_lookup_table(plain(cs), bits)) if range_builder else plain
         if case["explicit"]:
             cs = flex.FlexGateCS(True, case["num_advice"], case["num_lookup_advice"], k=k, num_fixed=case["num_fixed"])
         else:
-            cs = flex.configure(shape == "range", k, closure)
+            cs = flex.configure(range_builder, k, closure)
         assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (case["num_advice"], case["num_lookup_advice"], case["num_fixed"])
         asg = closure(cs)
         flex.mock(asg)
@@ -470,13 +477,14 @@ def test_wide_column_counts_match_golden(gpu):
         ws.release()
         keys.release()
         params.release()
-        argv = [os.path.join(root, "examples", "halo2_lib"), shape, str(k), str(bits), str(x), hex(secret), str(seed), str(max(count, 1))]
+        argv = [os.path.join(root, "examples", "halo2_lib"), base, str(k), str(bits), str(x), hex(secret), str(seed), str(max(count, 1))]
         if case["explicit"]:
             argv += [str(cs.num_advice), str(cs.num_lookup_advice), str(cs.num_fixed)]
-        r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, LOOKUP_BITS=str(bits)) if builder else {k_: v for k_, v in os.environ.items() if k_ != "LOOKUP_BITS"}
+        r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-1000:]
         out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("vk ", "proof ", "columns ")))
-        assert out["columns"] == f"{cs.num_advice} gate + {cs.num_lookup_advice} lookup-advice"
+        assert out.get("columns", "1 gate + 0 lookup-advice") == f"{cs.num_advice} gate + {cs.num_lookup_advice} lookup-advice"
         assert out["vk"] == case["vk_bytes"] and out["proof"] == case["proof"], ("C++", shape, k)
     # 32 limb bases (LOOKUP_BITS 2) do not fit the 25 usable rows of a DEGREE-5 constants column, and config's ceil(32 / 2^5) says one
     # column (the golden's last case sets two by hand)

@@ -157,11 +157,12 @@ def test_wide_golden_fixture_is_self_consistent():
     shapes = {(c["num_advice"], c["num_lookup_advice"]) for c in g["cases"]}
     assert max(a for a, _ in shapes) >= 31 and max(l for _, l in shapes) == 8  # the limits of include/h2mi_prover.h are exercised
     assert any(c["num_fixed"] == 2 for c in g["cases"])  # and two constants columns
+    assert {c["shape"] for c in g["cases"]} >= {"halo2_lib+range_builder", "poseidon+range_builder"}  # the Range builder with nothing looked up
     for case in g["cases"]:
         shape, k, bits, x = case["shape"], case["k"], case["lookup_bits"], int(case["x"], 16)
         explicit = (case["num_advice"], case["num_lookup_advice"], case["num_fixed"]) if case["explicit"] else None
         cs, asg = MW.build(shape, k, bits, x, case["count"], explicit)
-        assert (cs.num_advice, cs.num_lookup_advice, cs.num_fixed) == (case["num_advice"], case["num_lookup_advice"], case["num_fixed"])
+        assert (getattr(cs, "num_advice", 1), getattr(cs, "num_lookup_advice", 0), getattr(cs, "num_fixed", 1)) == (case["num_advice"], case["num_lookup_advice"], case["num_fixed"])
         assert ["0x%x" % v for v in asg.instance[0]] == case["instance"]
         proof = bytes.fromhex(case["proof"])
         vk = FX.VerifierKeys(cs, k, secret, asg.fixed, asg.copies)
