@@ -85,14 +85,14 @@ fn range_body(ctx: &mut Context<Fr>, x: Fr, make_public: &mut Vec<AssignedValue<
 
 /// keygen through the reference's scaffold::gen_key at DEGREE / LOOKUP_BITS -> (fixed commitments, permutation commitments, break
 /// points of phase 0, the FLEX_GATE_CONFIG_PARAMS builder.config left in the environment)
-fn keygen_case(degree: &str, lookup_bits: Option<&str>) -> (String, String, String, String) {
+fn keygen_case(degree: &str, lookup_bits: Option<&str>, range_closure: bool) -> (String, String, String, String) {
     std::env::set_var("DEGREE", degree);
     match lookup_bits {
         Some(b) => std::env::set_var("LOOKUP_BITS", b),
         None => std::env::remove_var("LOOKUP_BITS"),
     }
     let (pk, break_points) =
-        if lookup_bits.is_some() { gen_key(range_body, Fr::from(0xdeadbeefcafe1234u64)) } else { gen_key(halo2_lib_body, Fr::from(12)) };
+        if range_closure { gen_key(range_body, Fr::from(0xdeadbeefcafe1234u64)) } else { gen_key(halo2_lib_body, Fr::from(12)) };
     let vk = pk.get_vk();
     (
         list(vk.fixed_commitments().iter().map(point).collect()),
@@ -196,19 +196,24 @@ fn main() {
     // from the environment, takes the column counts from builder.config(k, Some(9)) and the SRS from gen_srs(k) — the same
     // fixed-seed SRS as above, cached under ./params): the verifying key's commitments pin halo2-base's layout conventions, the
     // break points the rule that ends a gate column.  The closures are the reference's two examples.
-    let (f, p, b, c1) = keygen_case("5", None);
+    let (f, p, b, c1) = keygen_case("5", None, false);
     put("halo2lib_k5_fixed_commitments", f);
     put("halo2lib_k5_permutation_commitments", p);
     put("halo2lib_k5_break_points_phase0", b);
-    let (f, p, b, c2) = keygen_case("7", Some("4"));
+    let (f, p, b, c2) = keygen_case("7", Some("4"), true);
     put("range_k7_bits4_fixed_commitments", f);
     put("range_k7_bits4_permutation_commitments", p);
     put("range_k7_bits4_break_points_phase0", b);
-    let (f, p, b, c3) = keygen_case("5", Some("4"));
+    let (f, p, b, c3) = keygen_case("5", Some("4"), true);
     put("range_k5_bits4_fixed_commitments", f);
     put("range_k5_bits4_permutation_commitments", p);
     put("range_k5_bits4_break_points_phase0", b);
-    let flex_config = vec![format!("\"halo2lib_k5\": {:?}", c1), format!("\"range_k7_bits4\": {:?}", c2), format!("\"range_k5_bits4\": {:?}", c3)];
+    // the Gate closure under the Range builder (LOOKUP_BITS set, nothing looked up: src/scaffold.rs:44-48 switches on the variable alone)
+    let (f, p, b, c4) = keygen_case("6", Some("4"), false);
+    put("halo2lib_range_builder_k6_bits4_fixed_commitments", f);
+    put("halo2lib_range_builder_k6_bits4_permutation_commitments", p);
+    put("halo2lib_range_builder_k6_bits4_break_points_phase0", b);
+    let flex_config = vec![format!("\"halo2lib_range_builder_k6_bits4\": {:?}", c4), format!("\"halo2lib_k5\": {:?}", c1), format!("\"range_k7_bits4\": {:?}", c2), format!("\"range_k5_bits4\": {:?}", c3)];
 
     // informational: no expectation exists for these
     let info = format!(

@@ -110,6 +110,13 @@ def expectations() -> dict:
     vk = FX.VerifierKeys(cs, 5, s, asg.fixed, asg.copies)
     e["range_k5_bits4_fixed_commitments"], e["range_k5_bits4_permutation_commitments"] = pts(vk.fixed_commitments), pts(vk.permutation_commitments)
     e["range_k5_bits4_break_points_phase0"] = FX.break_point_rows(t, 5)
+    cs = FX.flex_gate_cs(True)  # examples/halo2_lib.rs with LOOKUP_BITS = 4 at DEGREE 6: the Range builder, nothing looked up
+    asg = FX.halo2_lib_assignment(cs, 12)
+    asg.fixed[cs.col_table] = {i: i for i in range(16)}
+    vk = FX.VerifierKeys(cs, 6, s, asg.fixed, asg.copies)
+    e["halo2lib_range_builder_k6_bits4_fixed_commitments"] = pts(vk.fixed_commitments)
+    e["halo2lib_range_builder_k6_bits4_permutation_commitments"] = pts(vk.permutation_commitments)
+    e["halo2lib_range_builder_k6_bits4_break_points_phase0"] = []
     return e
 
 
