@@ -4,7 +4,7 @@
 // HBM; public inputs and proof bytes printed.  The proof bytes are checked by the test-suite against the oracle engine
 // and the Python host (tests/test_gpu_flex.py).
 //
-// Usage: halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed [count [num_advice num_lookup_advice [num_fixed]]]]]]]]
+// Usage: [DEGREE=k] [LOOKUP_BITS=b] [MINIMUM_ROWS=r] halo2_lib <halo2_lib | range | poseidon> [k [lookup_bits [x [srs_secret_hex [seed [count [num_advice num_lookup_advice [num_fixed]]]]]]]]
 //        (poseidon hashes x and x + 1: examples/poseidon.rs `hash_two`; count: range checks in one context, see flex::range_closure;
 //        num_advice / num_lookup_advice: the column counts set by hand instead of taken from builder.config)
 //        (the reference reads DEGREE and LOOKUP_BITS from the environment and draws x and the rng from OsRng)
@@ -44,7 +44,10 @@ static std::string hex(const std::vector<uint8_t>& b) {
 
 int main(int argc, char** argv) {
   const std::string shape = argc > 1 ? argv[1] : "halo2_lib";
-  const uint32_t k = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 10;  // DEGREE
+  // DEGREE, LOOKUP_BITS and MINIMUM_ROWS are read from the environment as the reference does (README: `DEGREE=<k> LOOKUP_BITS=8 cargo run
+  // --example range`; src/scaffold.rs:44-50); the arguments override them
+  const uint32_t k = argc > 2 ? (uint32_t)std::atoi(argv[2]) : std::getenv("DEGREE") ? (uint32_t)std::atoi(std::getenv("DEGREE")) : 10;
+  const uint32_t minimum_rows = std::getenv("MINIMUM_ROWS") ? (uint32_t)std::atoi(std::getenv("MINIMUM_ROWS")) : 9;
   const uint32_t lookup_bits = std::getenv("LOOKUP_BITS") ? (uint32_t)std::atoi(std::getenv("LOOKUP_BITS")) : argc > 3 ? (uint32_t)std::atoi(argv[3]) : 8;
   const uint64_t x = argc > 4 ? std::stoull(argv[4], nullptr, 0) : 12;
   const Fr s = fr_from_hex(argc > 5 ? argv[5] : "5ec2e7");
@@ -69,8 +72,8 @@ int main(int argc, char** argv) {
       return a;
     };
     // `builder.config(k, Some(minimum_rows))` (src/scaffold.rs:268): more than one gate column when the closure's cells overflow 2^k rows
-    const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, 9, set_fixed)
-                                               : flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); });
+    const flex::FlexGateCS cs = set_advice > 1 ? flex::FlexGateCS(lookup, set_advice, set_lookup, k, minimum_rows, set_fixed)
+                                               : flex::configure(lookup, k, [&](const flex::FlexGateCS& c) { return run(c, x); }, minimum_rows);
     if (cs.num_advice > 1) std::printf("columns %u gate + %u lookup-advice\n", cs.num_advice, cs.num_lookup_advice);
     auto closure = [&](uint64_t v) { return run(cs, v); };
     // keygen: the reference runs the closure once on dummy inputs to fix the circuit's shape
