@@ -8,6 +8,7 @@ reaches through ``create_proof`` (reference examples/standard_plonk.rs:41-49, sr
   params.ParamsKZG                         halo2_proofs::poly::kzg::commitment::ParamsKZG
   replay.StandardPlonkReplay               the MSM/NTT sequence one StandardPlonk proof issues
   transcript.Blake2bWrite / Blake2bRead    halo2_proofs::transcript (Challenge255), serde: to_repr / to_bytes
+  scaffold.mock / gen_key / prove_private / prove   the reference's src/scaffold.rs, name for name, over flex.* (the halo2-lib builders)
 
 All arithmetic runs in hand-written HIP kernels; there is no CPU fallback — importing this package
 without a built ``libh2mi.so`` raises, and compute calls without a GPU return H2MI_ENODEV.

@@ -131,6 +131,7 @@ class Assignment:
         self.fixed = [dict() for _ in range(cs.n_fixed)]
         self.instance = []   # public inputs (column 0)
         self.copies = []     # ((kind, column, row), (kind, column, row)) in constrain_equal order
+        self.break_points = []  # rows at which a gate column ended (several gate columns only)
 
 
 class Context:
@@ -244,6 +245,7 @@ class Context:
                 if col + 1 >= A:
                     raise ValueError(f"NOT ENOUGH ADVICE COLUMNS: more than {A} gate columns needed at 2^{cs.k} rows")
                 asg.copies.append(((ADVICE, col + 1, 0), (ADVICE, col, row)))
+                asg.break_points.append(row)  # what scaffold::gen_key returns next to the proving key (phase 0)
                 col, row = col + 1, 0
                 asg.advice[col][0] = v
             if q:

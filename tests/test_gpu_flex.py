@@ -497,6 +497,94 @@ def test_wide_column_counts_match_golden(gpu):
     params.release()
 
 
+def test_scaffold_functions_mirror_the_reference(gpu, tmp_path, monkeypatch):
+    """halo2_scaffold_amd.scaffold = the reference's src/scaffold.rs name for name (mock :39, gen_key :95, prove_private :158, prove :246):
+    closures f(ctx, input, make_public) like its examples, DEGREE / LOOKUP_BITS / MINIMUM_ROWS from the environment, the fixed-seed SRS of
+    gen_srs cached under PARAMS_DIR, column counts from builder.config.  The examples/range.rs closure at DEGREE 6 (one column) and at
+    DEGREE 5 (3 gate + 1 lookup-advice columns: gen_key's break points are the ones interop/probe expects from the real crate, [22, 21]),
+    examples/halo2_lib.rs under the Gate builder and — LOOKUP_BITS set — under the Range builder: every proof accepted by the oracle's
+    verifier against the closed-form verifying key, the public inputs returned as the reference returns them; an unsatisfied closure
+    fails in mock as MockProver does."""
+    import json
+    import os
+
+    from halo2_scaffold_amd import scaffold
+    from halo2_scaffold_amd.params import gen_srs_secret
+
+    monkeypatch.setenv("PARAMS_DIR", str(tmp_path))
+    monkeypatch.delenv("MINIMUM_ROWS", raising=False)
+
+    def range_example(ctx, x, make_public):  # examples/range.rs:10-34
+        xc = ctx.load_witness(x)
+        make_public.append(xc)
+        ctx.range_check(xc, 64, ctx.lookup_bits)
+        ctx.add(xc, xc)
+
+    def halo2_lib_example(ctx, x, make_public):  # examples/halo2_lib.rs:14-60
+        xc = ctx.load_witness(x)
+        make_public.append(xc)
+        x_sq = ctx.mul(xc, xc)
+        make_public.append(ctx.add_constant(x_sq, 72))
+        ctx.assign_region_last([("constant", 72), ("existing", xc), ("existing", xc), ("witness", x * x + 72)], [0])
+        ctx.mul_add_constant(xc, xc, 72)
+
+    s = gen_srs_secret()
+    x = 0xDEADBEEFCAFE1234
+    # examples/range.rs, one column
+    monkeypatch.setenv("DEGREE", "6")
+    monkeypatch.setenv("LOOKUP_BITS", "4")
+    scaffold.mock(range_example, x)
+    pk, bp = scaffold.gen_key(range_example, 0)
+    assert bp == [[]] and os.path.exists(tmp_path / "kzg_bn254_6.srs")
+    assert scaffold.prove_private(range_example, x, pk, bp) == [x]
+    ocs = FX.flex_gate_cs(True)
+    oasg = FX.range_assignment(ocs, x, 4, 64)
+    vk = FX.VerifierKeys(ocs, 6, s, oasg.fixed, oasg.copies)
+    assert pk.get_vk().transcript_repr == vk.transcript_repr
+    first = pk.last_proof
+    assert FX.verify(vk, first, [[x]]) and not FX.verify(vk, first, [[x + 1]])
+    assert scaffold.prove_private(range_example, x, pk, bp) == [x] and pk.last_proof != first and FX.verify(vk, pk.last_proof, [[x]])  # fresh blinding
+    pk.release()
+    # ... over 3 gate + 1 lookup-advice columns: the break points the probe expects from the real crate
+    monkeypatch.setenv("DEGREE", "5")
+    pk, bp = scaffold.gen_key(range_example, 0)
+    expect = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "recall_expectations.json")))
+    assert bp == [expect["range_k5_bits4_break_points_phase0"]] == [[22, 21]]
+    assert (pk.cs.num_advice, pk.cs.num_lookup_advice) == (3, 1)
+    assert scaffold.prove_private(range_example, x, pk, bp) == [x]
+    ocs = FX.flex_multi_cs(True, 3, 1)
+    oasg = FX.range_assignment_multi(ocs, x, 4, 5)
+    vk = FX.VerifierKeys(ocs, 5, s, oasg.fixed, oasg.copies)
+    assert [fm.g1_to_bytes(c).hex() for c in vk.fixed_commitments] == expect["range_k5_bits4_fixed_commitments"]  # the same keys the probe pins
+    assert FX.verify(vk, pk.last_proof, [[x]])
+    pk.release()
+    # examples/halo2_lib.rs: Gate builder, then (LOOKUP_BITS set) the Range builder
+    monkeypatch.delenv("LOOKUP_BITS")
+    proof, public = scaffold.prove(halo2_lib_example, 12, 3)
+    assert public == [12, 12 * 12 + 72] and len(proof) == 864
+    ocs = FX.flex_gate_cs(False)
+    oasg = FX.halo2_lib_assignment(ocs, 12)
+    assert FX.verify(FX.VerifierKeys(ocs, 5, s, oasg.fixed, oasg.copies), proof, [public])
+    monkeypatch.setenv("DEGREE", "6")
+    monkeypatch.setenv("LOOKUP_BITS", "4")
+    proof, public = scaffold.prove(halo2_lib_example, 12, 3)
+    ocs = FX.flex_gate_cs(True)
+    oasg = FX.halo2_lib_assignment(ocs, 12)
+    oasg.fixed[ocs.col_table] = {i: i for i in range(16)}
+    assert public == [12, 216] and len(proof) == 992 and FX.verify(FX.VerifierKeys(ocs, 6, s, oasg.fixed, oasg.copies), proof, [public])
+
+    # MockProver's verdicts: an unsatisfied gate; LOOKUP_BITS >= DEGREE
+    def broken(ctx, x, make_public):
+        c = ctx.load_witness(x)
+        ctx.assign_region_last([("constant", 0), ("existing", c), ("existing", c), ("witness", x * x + 1)], [0])
+
+    with pytest.raises(ValueError, match="gate not satisfied"):
+        scaffold.mock(broken, 5)
+    monkeypatch.setenv("LOOKUP_BITS", "6")
+    with pytest.raises(AssertionError, match="LOOKUP_BITS needs to be less than DEGREE"):
+        scaffold.mock(range_example, x)
+
+
 def test_general_quotient_kernel_agrees_with_the_specialised_one(gpu):
     """k_evaluate_h_flex (every operand converted to the multiplier's radix, Horner in y as the oracle writes it) and
     k_evaluate_h_range (level bookkeeping, shared reductions) are two independent implementations of the same function of their

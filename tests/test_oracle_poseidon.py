@@ -89,3 +89,30 @@ def test_mock_accepts_the_example_closures_and_names_violations():
     flex.mock(flex.range_closure(rng, 12345, 4), k=7)
     with pytest.raises(ValueError, match="NotEnoughRowsAvailable"):  # 51 cells (and their selector rows) in 25 usable rows
         flex.mock(flex.range_closure(rng, 12345, 4), k=5)
+
+
+def test_scaffold_mock_runs_on_the_host(monkeypatch):
+    """scaffold.mock (the reference's src/scaffold.rs:39-93, MockProver only) needs no GPU: configure from the environment, run the
+    closure, check rows / gates / copies / lookups.  gen_key / prove_private / prove need the device (tests/test_gpu_flex.py)."""
+    import pytest
+
+    _load_pkg.load()
+    from halo2_scaffold_amd import scaffold
+
+    def range_example(ctx, x, make_public):  # examples/range.rs:10-34
+        xc = ctx.load_witness(x)
+        make_public.append(xc)
+        ctx.range_check(xc, 64, ctx.lookup_bits)
+        ctx.add(xc, xc)
+
+    monkeypatch.setenv("DEGREE", "5")
+    monkeypatch.setenv("LOOKUP_BITS", "4")
+    monkeypatch.delenv("MINIMUM_ROWS", raising=False)
+    scaffold.mock(range_example, 0xDEADBEEFCAFE1234)  # 3 gate + 1 lookup-advice columns
+    monkeypatch.setenv("LOOKUP_BITS", "2")           # 32 limb bases in a 25-row constants column
+    with pytest.raises(ValueError, match="NotEnoughRowsAvailable"):
+        scaffold.mock(range_example, 0xDEADBEEFCAFE1234)
+    monkeypatch.setenv("DEGREE", "4")
+    monkeypatch.setenv("LOOKUP_BITS", "3")
+    with pytest.raises(ValueError, match="NOT ENOUGH ADVICE COLUMNS"):  # the column count of config's formula is too small here, as in halo2-base
+        scaffold.mock(range_example, 5)
